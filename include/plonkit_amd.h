@@ -1,0 +1,135 @@
+/*
+ * plonkit_amd — C ABI of the MI355X-native PLONK prover hot path (libplonkit_amd.so).
+ *
+ * This is the drop-in boundary for the arithmetic that fluidex/plonkit reaches in bellman_ce
+ * (reference call sites in parentheses; file:line under /root/reference).  plonkit has no FFI of
+ * its own — it links bellman_ce statically — so each entry point below names the Rust call it
+ * replaces; INTEGRATION.md shows the `extern "C"` block a plonkit maintainer would add.
+ *
+ * Conventions
+ *   - plk_fr          = 4 x u64 little-endian limbs, MONTGOMERY form (R = 2^256): byte-identical
+ *                       to ff_ce's in-memory `Fr`, so a Rust `&[Fr]` can be passed as is.
+ *   - plk_g1_affine   = x[4] || y[4], Montgomery Fq; the point at infinity is x = y = 0
+ *                       (pairing_ce's G1Affine carries a separate `infinity` flag: repack once).
+ *   - plk_g1_jacobian = X || Y || Z, infinity is Z = 0.
+ *   - every function returns int32_t: PLK_OK or an error code; text via plk_last_error().
+ *     Nothing throws across the boundary.  Calls are blocking unless a stream is passed.
+ *   - one plk_ctx drives ONE GPU (one process per GPU; multi-GPU MSM = ranks exchanging the
+ *     96-byte partial sums of plk_msm_g1_partial_dev over RCCL, see plonkit_amd/sharded.py).
+ *   - `*_dev` entry points take HIP device pointers (e.g. torch tensors' data_ptr()) and a
+ *     hipStream_t passed as void* (NULL = the context's own stream); `host` ones take host memory.
+ *   - There is NO CPU fallback: without a gfx950 device plk_create fails with PLK_ERR_HIP.
+ */
+#ifndef PLONKIT_AMD_H
+#define PLONKIT_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+typedef struct { uint64_t l[4]; } plk_fr;
+typedef struct { uint64_t x[4], y[4]; } plk_g1_affine;
+typedef struct { uint64_t x[4], y[4], z[4]; } plk_g1_jacobian;
+typedef struct plk_ctx plk_ctx;
+
+enum {
+    PLK_OK = 0,
+    PLK_ERR_ARG = 1,        /* null pointer, bad flag                                         */
+    PLK_ERR_SIZE = 2,       /* size not a power of two / log_n > 28 (2-adicity of Fr)         */
+    PLK_ERR_SRS = 3,        /* no SRS uploaded or SRS shorter than the request                */
+    PLK_ERR_HIP = 4,        /* HIP runtime error, or no gfx950 device                         */
+    PLK_ERR_UNSAT = 5,      /* witness does not satisfy the circuit ("must satisfy")          */
+    PLK_ERR_FORMAT = 6,     /* malformed r1cs / wtns / key / proof bytes                      */
+    PLK_ERR_IO = 7
+};
+
+const char *plk_last_error(void);
+const char *plk_version(void);
+int32_t plk_device_count(void);
+
+/* bellman_ce::worker::Worker::new() (src/plonk.rs:41,47,183): the execution resource handle. */
+int32_t plk_create(int32_t device, plk_ctx **out);
+void plk_destroy(plk_ctx *ctx);
+int32_t plk_synchronize(plk_ctx *ctx);
+
+/* ---- SRS: Crs<Bn256, CrsForMonomialForm> kept resident in HBM (src/plonk.rs:53; src/reader.rs:74-77) */
+int32_t plk_srs_upload(plk_ctx *ctx, const plk_g1_affine *bases_host, uint64_t n);
+int32_t plk_srs_set_dev(plk_ctx *ctx, const void *bases_dev, uint64_t n);       /* borrowed, not copied */
+uint64_t plk_srs_size(const plk_ctx *ctx);
+
+/* ---- Polynomial::{fft,ifft,coset_fft,icoset_fft} over Fr (bellman_ce::plonk::polynomials; driven
+ *      from setup() src/plonk.rs:104 and prove_by_steps src/plonk.rs:152-159).
+ *      Natural order in and out.  inverse=0: evaluate on coset*<omega_n>; inverse=1: interpolate
+ *      (scaled by 1/n, then by coset^-i).  coset == NULL means 1.                                  */
+int32_t plk_ntt(plk_ctx *ctx, plk_fr *data_host, uint32_t log_n, int32_t inverse, const plk_fr *coset);
+int32_t plk_ntt_dev(plk_ctx *ctx, void *data_dev, uint32_t log_n, int32_t inverse, const plk_fr *coset, void *stream);
+/* Polynomial::coset_lde(4): n coefficients -> 4n evaluations on 7*<omega_4n> */
+int32_t plk_lde4(plk_ctx *ctx, const plk_fr *coeffs_host, uint32_t log_n, plk_fr *out_4n_host);
+int32_t plk_lde4_dev(plk_ctx *ctx, const void *coeffs_dev, uint32_t log_n, void *out_4n_dev, void *stream);
+
+/* ---- kate_commitment::commit_using_monomials -> multiexp::dense_multiexp (src/plonk.rs:122-124 and
+ *      the 11 commitments of prove): sum_i scalars[i] * srs[base_offset + i], scalars Montgomery Fr. */
+int32_t plk_msm_g1(plk_ctx *ctx, const plk_fr *scalars_host, uint64_t n, uint64_t base_offset, plk_g1_affine *out);
+int32_t plk_msm_g1_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, plk_g1_affine *out, void *stream);
+/* the same sum left in Jacobian form, for cross-rank combination (multi-GPU shards) */
+int32_t plk_msm_g1_partial_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, plk_g1_jacobian *out, void *stream);
+/* enqueue only (no host sync): window sums land in an internal device buffer; finish with _finish */
+int32_t plk_msm_g1_enqueue_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, void *stream);
+int32_t plk_msm_g1_finish(plk_ctx *ctx, plk_g1_jacobian *out);
+
+/* ---- Crs::<Lagrange>::from_powers (src/plonk.rs:179-185): inverse NTT over G1 (dump-lagrange)  */
+int32_t plk_g1_intt(plk_ctx *ctx, const plk_g1_affine *in_host, uint32_t log_n, plk_g1_affine *out_host);
+
+/* ---- host-side G1 helpers (pure CPU, usable without a GPU) ---------------------------------- */
+int32_t plk_g1_sum_jacobian(const plk_g1_jacobian *parts, uint64_t n, plk_g1_affine *out);
+int32_t plk_g1_on_curve(const plk_g1_affine *p);                       /* 1 / 0                   */
+/* big-endian canonical 64-byte encoding of Proof/VerificationKey/Crs::write     */
+int32_t plk_g1_to_bytes(const plk_g1_affine *p, uint8_t out[64]);
+int32_t plk_g1_from_bytes(const uint8_t in[64], plk_g1_affine *out);
+int32_t plk_fr_to_bytes(const plk_fr *a, uint8_t out[32]);
+int32_t plk_fr_from_bytes(const uint8_t in[32], plk_fr *out);
+
+/* ---- RollingKeccakTranscript (src/plonk.rs:10,140,152; spec contrib/template.sol:267-307) ---- */
+typedef struct { uint8_t state0[32], state1[32]; uint32_t counter; } plk_transcript;
+void plk_transcript_init(plk_transcript *t);
+void plk_transcript_absorb_fr(plk_transcript *t, const plk_fr *v);
+void plk_transcript_absorb_g1(plk_transcript *t, const plk_g1_affine *p);
+void plk_transcript_challenge(plk_transcript *t, plk_fr *out);
+void plk_keccak256(const uint8_t *in, uint64_t len, uint8_t out[32]);
+
+/* ---- circuit pipeline: circom loaders + transpile + setup + prove ----------------------------
+ * plk_circuit mirrors CircomCircuit{r1cs, witness, wire_mapping: None, aux_offset: 1}
+ * (src/circom_circuit.rs:41-47).  Loaders follow src/reader.rs:178-241, src/r1cs_file.rs:100-154
+ * (r1cs), src/reader.rs:92-175 (witness).  `is_json` selects the parser as the reference does by
+ * file suffix (src/reader.rs:93,179).                                                          */
+typedef struct plk_circuit plk_circuit;
+int32_t plk_circuit_load(const uint8_t *r1cs, uint64_t r1cs_len, int32_t r1cs_is_json,
+                         const uint8_t *witness, uint64_t witness_len, int32_t witness_is_json,
+                         plk_circuit **out);                            /* witness may be NULL    */
+void plk_circuit_free(plk_circuit *c);
+/* plonk::analyse (src/plonk.rs:72-93): JSON as serde_json::to_string prints it (src/tests.rs:14) */
+int32_t plk_circuit_analyse(const plk_circuit *c, char *out_json, uint64_t cap);
+
+/* SetupForProver (src/plonk.rs:50-55): setup polynomials resident on the GPU */
+typedef struct plk_setup plk_setup;
+/* SetupForProver::prepare_setup_for_prover (src/plonk.rs:97-119): transpile + setup() = 11 iNTT(N) */
+int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out);
+void plk_setup_free(plk_setup *s);
+uint64_t plk_setup_domain_size(const plk_setup *s);                    /* N = n + 1              */
+/* make_verification_key + VerificationKey::write (src/plonk.rs:122-124; src/bin/main.rs:501-502).
+ * g2_bytes = the 2 x 128 bytes of the key file's G2 section, copied through.                    */
+int32_t plk_setup_write_vk(plk_ctx *ctx, const plk_setup *s, const uint8_t g2_bytes[256], uint8_t *out, uint64_t cap, uint64_t *len);
+/* SetupForProver::prove(circuit, "keccak") with the monomial key (src/plonk.rs:132-159) followed by
+ * Proof::write (src/bin/main.rs:407-408).  Fails with PLK_ERR_UNSAT like the reference's
+ * `expect("must satisfy")` (src/plonk.rs:137).                                                  */
+int32_t plk_prove(plk_ctx *ctx, const plk_setup *s, const plk_circuit *c, uint8_t *proof_out, uint64_t cap, uint64_t *len);
+/* per-phase wall-clock of the last plk_prove on this ctx, milliseconds (tracing hook) */
+int32_t plk_prove_timings(const plk_ctx *ctx, double *out_ms, uint32_t cap, uint32_t *count);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif

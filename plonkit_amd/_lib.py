@@ -1,0 +1,231 @@
+"""ctypes binding of include/plonkit_amd.h (lib/libplonkit_amd.so).
+
+Arrays cross as numpy uint64 ([n,4] Fr Montgomery, [n,8] G1 affine, [12] Jacobian) or as raw device
+pointers (ints / torch tensors).  Nothing here computes: every function forwards to the C ABI, and
+a missing library or a missing GPU raises — there is no Python or CPU fallback.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "lib", "libplonkit_amd.so")
+_lib = None
+
+ERR_NAMES = {1: "PLK_ERR_ARG", 2: "PLK_ERR_SIZE", 3: "PLK_ERR_SRS", 4: "PLK_ERR_HIP", 5: "PLK_ERR_UNSAT",
+             6: "PLK_ERR_FORMAT", 7: "PLK_ERR_IO"}
+
+
+class PlkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (ERR_NAMES.get(code, code), msg))
+        self.code = code
+
+
+def lib_path():
+    return _SO
+
+
+def lib():
+    """Loads the shared library; raises loudly if it has not been built (python -m plonkit_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise ImportError("plonkit_amd: %s is missing — build it with `python -m plonkit_amd.build` "
+                              "(hipcc, gfx950). There is no fallback implementation." % _SO)
+        L = ctypes.CDLL(_SO)
+        L.plk_last_error.restype = ctypes.c_char_p
+        L.plk_version.restype = ctypes.c_char_p
+        L.plk_srs_size.restype = ctypes.c_uint64
+        if hasattr(L, "plk_setup_domain_size"):
+            L.plk_setup_domain_size.restype = ctypes.c_uint64
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().plk_last_error().decode()
+
+
+def _check(rc):
+    if rc != 0:
+        raise PlkError(rc, last_error())
+
+
+def have_gpu():
+    return lib().plk_device_count() > 0
+
+
+def _np(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _devptr(x):
+    """torch tensor / int -> void*"""
+    if hasattr(x, "data_ptr"):
+        return ctypes.c_void_p(x.data_ptr())
+    return ctypes.c_void_p(int(x))
+
+
+def _stream(s):
+    if s is None:
+        return ctypes.c_void_p(0)
+    if hasattr(s, "cuda_stream"):
+        return ctypes.c_void_p(s.cuda_stream)
+    return ctypes.c_void_p(int(s))
+
+
+class Context:
+    """plk_ctx: one GPU.  Mirrors where the reference builds `Worker::new()` (src/plonk.rs:41,47,183)."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        _check(lib().plk_create(ctypes.c_int32(device), ctypes.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().plk_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(lib().plk_synchronize(self._h))
+
+    # ---- SRS
+    def srs_upload(self, bases):
+        bases = np.ascontiguousarray(bases, dtype=np.uint64)
+        assert bases.ndim == 2 and bases.shape[1] == 8
+        _check(lib().plk_srs_upload(self._h, _np(bases), ctypes.c_uint64(bases.shape[0])))
+
+    def srs_set_dev(self, ptr, n):
+        _check(lib().plk_srs_set_dev(self._h, _devptr(ptr), ctypes.c_uint64(n)))
+
+    def srs_size(self):
+        return lib().plk_srs_size(self._h)
+
+    # ---- NTT
+    def ntt(self, data, log_n, inverse=False, coset=None):
+        """host array in, new host array out (natural order)."""
+        a = np.ascontiguousarray(data, dtype=np.uint64).copy()
+        assert a.shape == (1 << log_n, 4)
+        c = np.ascontiguousarray(coset, dtype=np.uint64) if coset is not None else None
+        _check(lib().plk_ntt(self._h, _np(a), ctypes.c_uint32(log_n), ctypes.c_int32(1 if inverse else 0),
+                             _np(c) if c is not None else None))
+        return a
+
+    def ntt_dev(self, ptr, log_n, inverse=False, coset=None, stream=None):
+        c = np.ascontiguousarray(coset, dtype=np.uint64) if coset is not None else None
+        _check(lib().plk_ntt_dev(self._h, _devptr(ptr), ctypes.c_uint32(log_n), ctypes.c_int32(1 if inverse else 0),
+                                 _np(c) if c is not None else None, _stream(stream)))
+
+    def lde4(self, coeffs, log_n):
+        a = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        assert a.shape == (1 << log_n, 4)
+        out = np.zeros((4 << log_n, 4), dtype=np.uint64)
+        _check(lib().plk_lde4(self._h, _np(a), ctypes.c_uint32(log_n), _np(out)))
+        return out
+
+    def lde4_dev(self, in_ptr, log_n, out_ptr, stream=None):
+        _check(lib().plk_lde4_dev(self._h, _devptr(in_ptr), ctypes.c_uint32(log_n), _devptr(out_ptr), _stream(stream)))
+
+    # ---- MSM
+    def msm(self, scalars, base_offset=0):
+        s = np.ascontiguousarray(scalars, dtype=np.uint64)
+        out = np.zeros(8, dtype=np.uint64)
+        _check(lib().plk_msm_g1(self._h, _np(s), ctypes.c_uint64(s.shape[0]), ctypes.c_uint64(base_offset), _np(out)))
+        return out
+
+    def msm_dev(self, ptr, n, base_offset=0, stream=None):
+        out = np.zeros(8, dtype=np.uint64)
+        _check(lib().plk_msm_g1_dev(self._h, _devptr(ptr), ctypes.c_uint64(n), ctypes.c_uint64(base_offset), _np(out), _stream(stream)))
+        return out
+
+    def msm_partial_dev(self, ptr, n, base_offset=0, stream=None):
+        out = np.zeros(12, dtype=np.uint64)
+        _check(lib().plk_msm_g1_partial_dev(self._h, _devptr(ptr), ctypes.c_uint64(n), ctypes.c_uint64(base_offset), _np(out), _stream(stream)))
+        return out
+
+    def msm_enqueue_dev(self, ptr, n, base_offset=0, stream=None):
+        _check(lib().plk_msm_g1_enqueue_dev(self._h, _devptr(ptr), ctypes.c_uint64(n), ctypes.c_uint64(base_offset), _stream(stream)))
+
+    def msm_finish(self):
+        out = np.zeros(12, dtype=np.uint64)
+        _check(lib().plk_msm_g1_finish(self._h, _np(out)))
+        return out
+
+    def g1_intt(self, points, log_n):
+        p = np.ascontiguousarray(points, dtype=np.uint64)
+        assert p.shape == (1 << log_n, 8)
+        out = np.zeros_like(p)
+        _check(lib().plk_g1_intt(self._h, _np(p), ctypes.c_uint32(log_n), _np(out)))
+        return out
+
+
+# ------------------------------------------------------------------ CPU-only helpers of the ABI
+def g1_sum_jacobian(parts):
+    parts = np.ascontiguousarray(parts, dtype=np.uint64).reshape(-1, 12)
+    out = np.zeros(8, dtype=np.uint64)
+    _check(lib().plk_g1_sum_jacobian(_np(parts), ctypes.c_uint64(parts.shape[0]), _np(out)))
+    return out
+
+
+def g1_to_bytes(p):
+    p = np.ascontiguousarray(p, dtype=np.uint64)
+    out = ctypes.create_string_buffer(64)
+    _check(lib().plk_g1_to_bytes(_np(p), out))
+    return out.raw
+
+
+def g1_from_bytes(b):
+    out = np.zeros(8, dtype=np.uint64)
+    _check(lib().plk_g1_from_bytes(bytes(b), _np(out)))
+    return out
+
+
+def fr_to_bytes(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = ctypes.create_string_buffer(32)
+    _check(lib().plk_fr_to_bytes(_np(a), out))
+    return out.raw
+
+
+def fr_from_bytes(b):
+    out = np.zeros(4, dtype=np.uint64)
+    _check(lib().plk_fr_from_bytes(bytes(b), _np(out)))
+    return out
+
+
+def keccak256(data):
+    out = ctypes.create_string_buffer(32)
+    lib().plk_keccak256(bytes(data), ctypes.c_uint64(len(data)), out)
+    return out.raw
+
+
+class _TranscriptStruct(ctypes.Structure):
+    _fields_ = [("state0", ctypes.c_uint8 * 32), ("state1", ctypes.c_uint8 * 32), ("counter", ctypes.c_uint32)]
+
+
+class Transcript:
+    """RollingKeccakTranscript (src/plonk.rs:10; contrib/template.sol:267-307)."""
+
+    def __init__(self):
+        self._t = _TranscriptStruct()
+        lib().plk_transcript_init(ctypes.byref(self._t))
+
+    def absorb_fr(self, a):
+        lib().plk_transcript_absorb_fr(ctypes.byref(self._t), _np(np.ascontiguousarray(a, dtype=np.uint64)))
+
+    def absorb_g1(self, p):
+        lib().plk_transcript_absorb_g1(ctypes.byref(self._t), _np(np.ascontiguousarray(p, dtype=np.uint64)))
+
+    def challenge(self):
+        out = np.zeros(4, dtype=np.uint64)
+        lib().plk_transcript_challenge(ctypes.byref(self._t), _np(out))
+        return out

@@ -1,0 +1,74 @@
+// Execution context: one GPU, one stream, cached twiddle tables, resident SRS, scratch arenas.
+// Stands where bellman_ce's `Worker` stands in the reference (src/plonk.rs:41,47,183).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/plonkit_amd.h"
+#include "field.cuh"
+
+namespace plk {
+
+void set_error(const std::string &msg);
+int32_t hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define PLK_HIP(expr)                                                          \
+    do {                                                                       \
+        hipError_t _e = (expr);                                                \
+        if (_e != hipSuccess) return plk::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define PLK_TRY(expr)                         \
+    do {                                      \
+        int32_t _rc = (expr);                 \
+        if (_rc != PLK_OK) return _rc;        \
+    } while (0)
+
+constexpr uint32_t MAX_LOG_N = 28;          // 2-adicity of Fr
+constexpr uint32_t POW_SPLIT = 14;          // two-level power tables: e = hi * 2^14 + lo
+constexpr uint32_t POW_TAB = 1u << POW_SPLIT;
+
+// base^e for e < 2^28 as lo[e & 16383] * hi[e >> 14]
+struct PowTable {
+    const Fr *lo = nullptr;
+    const Fr *hi = nullptr;
+};
+
+// grows-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int32_t reserve(size_t bytes);
+    void release();
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace plk
+
+struct plk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    // NTT tables (device): omega_{2^28} powers forward / inverse, coset generator 7 and 7^-1
+    plk::DevBuf tables;
+    plk::PowTable tw_fwd, tw_inv;            // omega_{2^28}^{+-e}
+    std::map<std::vector<uint32_t>, plk::PowTable> coset_tabs;   // keyed by the 8 limbs of the shift
+    std::vector<void *> coset_allocs;
+    std::map<std::vector<uint32_t>, plk::Fr> inv_cache;
+    plk::Fr n_inv[plk::MAX_LOG_N + 1];      // 2^-k
+    plk::DevBuf ntt_scratch;                 // ping-pong buffer for the transposing final pass
+    // SRS
+    const void *srs = nullptr;               // device, Montgomery affine, 64 B per point
+    uint64_t srs_n = 0;
+    plk::DevBuf srs_own;
+    // MSM scratch
+    plk::DevBuf msm_a, msm_b, msm_c, msm_d, msm_e;
+    plk::DevBuf stage;                       // host<->device staging for the host-pointer API
+    void *pinned = nullptr;                  // small pinned host buffer for results
+    size_t pinned_cap = 0;
+    uint32_t msm_windows = 0, msm_c_bits = 0, msm_pending_parts = 0;
+    hipStream_t msm_stream = nullptr;
+    std::vector<double> timings;
+};

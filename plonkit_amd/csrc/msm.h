@@ -1,0 +1,10 @@
+#pragma once
+#include "ctx.h"
+#include "hostmath.h"
+namespace plk {
+// enqueue the whole Pippenger pipeline on `stream`; results (window sums) are copied to ctx->pinned
+int32_t msm_enqueue(plk_ctx *ctx, const Fr *scalars_dev, uint64_t n, uint64_t base_offset, hipStream_t stream);
+// synchronise and fold the window sums on the host
+int32_t msm_finish(plk_ctx *ctx, hipStream_t stream, host::HJac *out);
+int32_t ensure_pinned(plk_ctx *ctx, size_t bytes);
+}  // namespace plk

@@ -1,0 +1,304 @@
+// Radix-2 NTT / iNTT / coset NTT over BN254 Fr for gfx950 — natural order in, natural order out.
+//
+// Replaces bellman_ce's Polynomial::{fft, ifft, coset_fft, icoset_fft} / fft::best_fft, which the
+// reference drives from setup() (src/plonk.rs:104, 11 iNTT(N)) and prove_by_steps
+// (src/plonk.rs:152-159: 6 iNTT(N), ~18 coset NTT(4N), 1 coset iNTT(4N)).  omega_n, ordering and
+// the coset generator 7 are those of SURVEY.md A.2/A.4.
+//
+// Design (MI355X-first, not a translation of bellman's thread-split FFT):
+//   * n = 2^log_n is factored into p <= 4 digits of <= 9 bits: n = R1*R2*..*Rp (mixed-radix
+//     Cooley-Tukey, "four-step" generalised).  Pass i transforms digit i for every combination of
+//     the other digits; between passes the element (k_i, m) is multiplied by omega_L^(k_i*m).
+//   * A workgroup owns a tile of 2048 elements = R rows x C adjacent columns (C*32 B contiguous
+//     per row, >= 128 B), stages it in LDS as two 16-byte planes (conflict-free ds_read_b128 for
+//     lane-contiguous columns) and runs the log2(R) butterfly stages there: HBM sees exactly one
+//     read and one write of the vector per pass (p = 3 at 2^20..2^27).
+//   * Bit reversal never touches LDS: passes 1..p-1 run DIT and fetch their rows in bit-reversed
+//     order (a row is its own memory segment, so the order is free); the last pass runs DIF on
+//     contiguous rows and scatters whole C-element segments to the digit-reversed output index.
+//   * coset shift (g^i on load), 1/n and g^-i (on store) are fused into the first / last pass;
+//     powers come from two-level tables (base^(lo + 2^14*hi)), one multiply per use.
+//   * No MFMA: this is 256-bit modular integer arithmetic, bound by v_mad_u64_u32 issue.
+#include "ctx.h"
+#include "ntt.h"
+
+namespace plk {
+
+constexpr int NTT_THREADS = 256;
+constexpr int LOG_TILE = 11;                   // 2048 elements per workgroup
+
+struct NttPassArgs {
+    const Fr *in;
+    Fr *out;
+    uint32_t log_n, log_r, log_c;
+    uint32_t log_inner;                        // type-A: row stride = 2^log_inner
+    uint32_t log_r1, log_m1, log_m2;           // final pass: digit widths of k1 and the middle digits
+    PowTable tw;                               // omega_{2^28}^(+-e)
+    PowTable pre;                              // optional: multiply input i by pre^i (first pass)
+    PowTable post;                             // optional: multiply output k by post^k (last pass)
+    Fr scale;                                  // optional 1/n on the last pass
+    uint32_t has_scale;
+};
+
+__device__ __forceinline__ Fr pow2l(const PowTable &t, uint32_t e) {
+    Fr lo = load_fp(t.lo + (e & (POW_TAB - 1)));
+    Fr hi = load_fp(t.hi + (e >> POW_SPLIT));
+    return mul(lo, hi);
+}
+
+__device__ __forceinline__ uint32_t brev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+struct LdsTile {
+    u32x4 *p0, *p1;
+    __device__ __forceinline__ Fr get(uint32_t i) const {
+        u32x4 a = p0[i], b = p1[i];
+        Fr r;
+        r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+        r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+        return r;
+    }
+    __device__ __forceinline__ void put(uint32_t i, const Fr &v) const {
+        p0[i] = u32x4{v.l[0], v.l[1], v.l[2], v.l[3]};
+        p1[i] = u32x4{v.l[4], v.l[5], v.l[6], v.l[7]};
+    }
+};
+
+// omega_R^i (i < R/2) straight out of the hi table: omega_{2^28}^(i << (28 - log_r)), low part 0
+__device__ __forceinline__ Fr small_tw(const PowTable &t, uint32_t i, uint32_t log_r) {
+    return load_fp(t.hi + (i << (POW_SPLIT - log_r)));
+}
+
+// Passes 1..p-1: strided columns, DIT, in place, post-multiplied by the inter-digit twiddle.
+__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t log_r = a.log_r, log_c = a.log_c, C = 1u << log_c;
+    const uint32_t T = 1u << (log_r + log_c);
+    LdsTile L{reinterpret_cast<u32x4 *>(smem), reinterpret_cast<u32x4 *>(smem) + T};
+    const uint32_t tid = threadIdx.x, t = blockIdx.x;
+    const uint32_t tiles_log = a.log_inner - log_c;
+    const uint32_t o = t >> tiles_log, c0 = (t & ((1u << tiles_log) - 1)) << log_c;
+    const size_t base = ((size_t)o << (log_r + a.log_inner)) + c0;
+
+    for (uint32_t idx = tid; idx < T; idx += NTT_THREADS) {
+        uint32_t c = idx & (C - 1), p = idx >> log_c;
+        size_t g = base + ((size_t)brev(p, log_r) << a.log_inner) + c;
+        Fr v = load_fp(a.in + g);
+        if (a.pre.lo) v = mul(v, pow2l(a.pre, (uint32_t)g));
+        L.put(idx, v);
+    }
+    __syncthreads();
+    for (uint32_t s = 0; s < log_r; s++) {
+        const uint32_t h = 1u << s;
+        for (uint32_t b = tid; b < (T >> 1); b += NTT_THREADS) {
+            uint32_t c = b & (C - 1), j = b >> log_c;
+            uint32_t jl = j & (h - 1);
+            uint32_t i0 = (((j >> s) << (s + 1)) | jl), i1 = i0 + h;
+            Fr u = L.get((i0 << log_c) + c), v = L.get((i1 << log_c) + c);
+            if (s) v = mul(v, small_tw(a.tw, jl << (log_r - s - 1), log_r));
+            L.put((i0 << log_c) + c, add(u, v));
+            L.put((i1 << log_c) + c, sub(u, v));
+        }
+        __syncthreads();
+    }
+    const uint32_t eshift = MAX_LOG_N - (log_r + a.log_inner);
+    for (uint32_t idx = tid; idx < T; idx += NTT_THREADS) {
+        uint32_t c = idx & (C - 1), k = idx >> log_c;
+        uint32_t e = (k * (c0 + c)) << eshift;
+        Fr v = mul(L.get(idx), pow2l(a.tw, e));
+        store_fp(a.out + base + ((size_t)k << a.log_inner) + c, v);
+    }
+}
+
+// Last pass: C contiguous rows of R elements, DIF, scattered to the digit-reversed output index.
+__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t log_r = a.log_r, log_c = a.log_c, C = 1u << log_c, R = 1u << log_r;
+    const uint32_t T = 1u << (log_r + log_c);
+    const uint32_t pitch = C | 1;              // odd pitch: the transposing LDS write is conflict-free
+    LdsTile L{reinterpret_cast<u32x4 *>(smem), reinterpret_cast<u32x4 *>(smem) + R * pitch};
+    const uint32_t tid = threadIdx.x, t = blockIdx.x;
+    const uint32_t kb_log = a.log_r1 - log_c, log_m = a.log_m1 + a.log_m2;
+    const uint32_t k1_0 = (t & ((1u << kb_log) - 1)) << log_c, mu = t >> kb_log;
+
+    for (uint32_t idx = tid; idx < T; idx += NTT_THREADS) {
+        uint32_t n = idx & (R - 1), c = idx >> log_r;
+        size_t rho = ((size_t)(k1_0 + c) << log_m) + mu;
+        size_t g = (rho << log_r) + n;
+        Fr v = load_fp(a.in + g);
+        if (a.pre.lo) v = mul(v, pow2l(a.pre, (uint32_t)g));
+        L.put(n * pitch + c, v);
+    }
+    __syncthreads();
+    for (int s = (int)log_r - 1; s >= 0; s--) {
+        const uint32_t h = 1u << s;
+        for (uint32_t b = tid; b < (T >> 1); b += NTT_THREADS) {
+            uint32_t c = b & (C - 1), j = b >> log_c;
+            uint32_t jl = j & (h - 1);
+            uint32_t i0 = (((j >> s) << (s + 1)) | jl), i1 = i0 + h;
+            Fr u = L.get(i0 * pitch + c), v = L.get(i1 * pitch + c);
+            Fr d = sub(u, v);
+            if (s) d = mul(d, small_tw(a.tw, jl << (log_r - s - 1), log_r));
+            L.put(i0 * pitch + c, add(u, v));
+            L.put(i1 * pitch + c, d);
+        }
+        __syncthreads();
+    }
+    const uint32_t k2 = mu >> a.log_m2, k3 = mu & ((1u << a.log_m2) - 1);
+    const size_t drev = (size_t)k2 + ((size_t)k3 << a.log_m1);
+    for (uint32_t idx = tid; idx < T; idx += NTT_THREADS) {
+        uint32_t c = idx & (C - 1), p = idx >> log_c;
+        uint32_t k = brev(p, log_r);
+        size_t o = (size_t)(k1_0 + c) + (drev << a.log_r1) + ((size_t)k << (a.log_n - log_r));
+        Fr v = L.get(p * pitch + c);
+        if (a.post.lo) v = mul(v, pow2l(a.post, (uint32_t)o));
+        if (a.has_scale) v = mul(v, a.scale);
+        store_fp(a.out + o, v);
+    }
+}
+
+// ------------------------------------------------------------------------------- tables
+__global__ void fill_pow_table(Fr *lo, Fr *hi, Fr base) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * POW_TAB) return;
+    if (i < POW_TAB) store_fp(lo + i, pow_u64(base, i));
+    else store_fp(hi + (i - POW_TAB), pow_u64(base, (uint64_t)(i - POW_TAB) << POW_SPLIT));
+}
+
+// canonical omega_{2^28} — 7^((r-1)/2^28)
+static Fr root28() {
+    Fr c;
+    const uint32_t w[8] = {0x60c37c9cu, 0xd34f1ed9u, 0xd39329c8u, 0x3215cf6du, 0x3dd31f74u, 0x98865ea9u, 0x166d18b7u, 0x03ddb9f5u};
+    for (int i = 0; i < 8; i++) c.l[i] = w[i];
+    return from_canonical(c);
+}
+
+Fr ntt_omega(uint32_t log_n) {
+    Fr w = root28();
+    for (uint32_t i = log_n; i < MAX_LOG_N; i++) w = sqr(w);
+    return w;
+}
+
+static int32_t make_pow_table(plk_ctx *ctx, const Fr &base, PowTable *out, void **alloc_out) {
+    Fr *buf = nullptr;
+    PLK_HIP(hipMalloc(&buf, sizeof(Fr) * 2 * POW_TAB));
+    hipLaunchKernelGGL(fill_pow_table, dim3(2 * POW_TAB / 256), dim3(256), 0, ctx->stream, buf, buf + POW_TAB, base);
+    PLK_HIP(hipGetLastError());
+    out->lo = buf;
+    out->hi = buf + POW_TAB;
+    if (alloc_out) *alloc_out = buf;
+    return PLK_OK;
+}
+
+Fr cached_inverse(plk_ctx *ctx, const Fr &g) {
+    std::vector<uint32_t> key(g.l, g.l + 8);
+    auto it = ctx->inv_cache.find(key);
+    if (it != ctx->inv_cache.end()) return it->second;
+    Fr gi = inv(g);
+    ctx->inv_cache[key] = gi;
+    return gi;
+}
+
+int32_t ntt_init_tables(plk_ctx *ctx) {
+    if (ctx->tw_fwd.lo) return PLK_OK;
+    Fr half = inv(from_u64<FrParams>(2));
+    ctx->n_inv[0] = Fr::one();
+    for (uint32_t i = 1; i <= MAX_LOG_N; i++) ctx->n_inv[i] = mul(ctx->n_inv[i - 1], half);
+    Fr w = root28();
+    void *a = nullptr, *b = nullptr;
+    PLK_TRY(make_pow_table(ctx, w, &ctx->tw_fwd, &a));
+    PLK_TRY(make_pow_table(ctx, inv(w), &ctx->tw_inv, &b));
+    ctx->coset_allocs.push_back(a);
+    ctx->coset_allocs.push_back(b);
+    return PLK_OK;
+}
+
+int32_t ntt_coset_table(plk_ctx *ctx, const Fr &g, PowTable *out) {
+    std::vector<uint32_t> key(g.l, g.l + 8);
+    auto it = ctx->coset_tabs.find(key);
+    if (it != ctx->coset_tabs.end()) { *out = it->second; return PLK_OK; }
+    void *a = nullptr;
+    PLK_TRY(make_pow_table(ctx, g, out, &a));
+    ctx->coset_allocs.push_back(a);
+    ctx->coset_tabs[key] = *out;
+    return PLK_OK;
+}
+
+// ------------------------------------------------------------------------------- driver
+static bool g_attr_set = false;
+
+int32_t ntt_dev(plk_ctx *ctx, Fr *data, uint32_t log_n, bool inverse, const Fr *coset, hipStream_t stream) {
+    if (!data) { set_error("ntt: null data"); return PLK_ERR_ARG; }
+    if (log_n > MAX_LOG_N) { set_error("ntt: log_n exceeds the 2-adicity of Fr (28)"); return PLK_ERR_SIZE; }
+    if (log_n == 0) return PLK_OK;
+    PLK_TRY(ntt_init_tables(ctx));
+    if (!g_attr_set) {
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_cols), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        g_attr_set = true;
+    }
+    PowTable pre{}, post{};
+    if (coset) {
+        if (!inverse) PLK_TRY(ntt_coset_table(ctx, *coset, &pre));
+        else PLK_TRY(ntt_coset_table(ctx, cached_inverse(ctx, *coset), &post));
+    }
+    // digit plan
+    uint32_t d[4] = {0, 0, 0, 0}, p = 1;
+    if (log_n <= LOG_TILE) d[0] = log_n;
+    else {
+        p = (log_n + 8) / 9;
+        for (uint32_t i = 0; i < p; i++) d[i] = log_n / p + (i < log_n % p ? 1 : 0);
+    }
+    const size_t n = (size_t)1 << log_n;
+    Fr *scratch = nullptr;
+    PLK_TRY(ctx->ntt_scratch.reserve(n * sizeof(Fr)));
+    scratch = ctx->ntt_scratch.as<Fr>();
+
+    NttPassArgs a{};
+    a.log_n = log_n;
+    a.tw = inverse ? ctx->tw_inv : ctx->tw_fwd;
+    // ping-pong: pass 1 data -> scratch, middle passes in place in scratch, last pass scratch -> data
+    uint32_t rem = log_n;
+    for (uint32_t i = 0; i + 1 < p; i++) {
+        rem -= d[i];
+        a.in = (i == 0) ? data : scratch; a.out = scratch;
+        a.log_r = d[i]; a.log_inner = rem;
+        a.log_c = (LOG_TILE - d[i]) < rem ? (LOG_TILE - d[i]) : rem;
+        a.pre = (i == 0) ? pre : PowTable{};
+        a.post = PowTable{}; a.has_scale = 0;
+        uint32_t tiles = (uint32_t)(n >> (a.log_r + a.log_c));
+        size_t lds = (size_t)2 * 16 << (a.log_r + a.log_c);
+        hipLaunchKernelGGL(ntt_pass_cols, dim3(tiles), dim3(NTT_THREADS), lds, stream, a);
+    }
+    {
+        a.in = (p == 1) ? data : scratch; a.out = (p == 1) ? scratch : data;
+        a.log_r = d[p - 1];
+        if (p == 1) { a.log_r1 = 0; a.log_m1 = a.log_m2 = 0; a.log_c = 0; }
+        else {
+            a.log_r1 = d[0];
+            a.log_m1 = p >= 3 ? d[1] : 0;
+            a.log_m2 = p >= 4 ? d[2] : 0;
+            a.log_c = (LOG_TILE - a.log_r) < d[0] ? (LOG_TILE - a.log_r) : d[0];
+        }
+        a.pre = (p == 1) ? pre : PowTable{};
+        a.post = post;
+        a.has_scale = inverse ? 1 : 0;
+        if (inverse) a.scale = ctx->n_inv[log_n];
+        uint32_t tiles = (uint32_t)(n >> (a.log_r + a.log_c));
+        size_t lds = (size_t)2 * 16 * (((size_t)1 << a.log_r) * ((1u << a.log_c) | 1));
+        hipLaunchKernelGGL(ntt_pass_rows, dim3(tiles), dim3(NTT_THREADS), lds, stream, a);
+    }
+    PLK_HIP(hipGetLastError());
+    if (p == 1) PLK_HIP(hipMemcpyAsync(data, scratch, n * sizeof(Fr), hipMemcpyDeviceToDevice, stream));
+    return PLK_OK;
+}
+
+int32_t lde4_dev(plk_ctx *ctx, const Fr *coeffs, uint32_t log_n, Fr *out_4n, hipStream_t stream) {
+    if (log_n + 2 > MAX_LOG_N) { set_error("lde4: 4n exceeds 2^28"); return PLK_ERR_SIZE; }
+    const size_t n = (size_t)1 << log_n;
+    PLK_HIP(hipMemcpyAsync(out_4n, coeffs, n * sizeof(Fr), hipMemcpyDeviceToDevice, stream));
+    PLK_HIP(hipMemsetAsync(out_4n + n, 0, 3 * n * sizeof(Fr), stream));
+    Fr g = from_u64<FrParams>(7);
+    return ntt_dev(ctx, out_4n, log_n + 2, false, &g, stream);
+}
+
+}  // namespace plk

@@ -1,0 +1,175 @@
+// Context lifetime, error reporting, SRS residency and the host-pointer wrappers of the C ABI.
+// (The reference's counterpart is bellman_ce::worker::Worker + Crs held in SetupForProver,
+//  src/plonk.rs:41-55; here the resource is one MI355X, its stream and its HBM-resident tables.)
+#include "ctx.h"
+#include "ntt.h"
+#include "msm.h"
+#include <cstring>
+#include <cstdio>
+
+namespace plk {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+int32_t hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in `%s` at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    g_last_error = buf;
+    (void)hipGetLastError();
+    return PLK_ERR_HIP;
+}
+
+int32_t DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return PLK_OK;
+    if (p) { PLK_HIP(hipFree(p)); p = nullptr; cap = 0; }
+    size_t want = bytes + (bytes >> 3);           // a little slack so that growth is rare
+    PLK_HIP(hipMalloc(&p, want));
+    cap = want;
+    return PLK_OK;
+}
+
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+int32_t ensure_pinned(plk_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->pinned_cap) return PLK_OK;
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = nullptr;
+    PLK_HIP(hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
+    ctx->pinned_cap = bytes;
+    return PLK_OK;
+}
+
+}  // namespace plk
+
+using namespace plk;
+
+extern "C" {
+
+const char *plk_last_error(void) { return g_last_error.c_str(); }
+const char *plk_version(void) { return "plonkit_amd 0.1 (gfx950)"; }
+
+int32_t plk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int32_t plk_create(int32_t device, plk_ctx **out) {
+    if (!out) { set_error("plk_create: null out"); return PLK_ERR_ARG; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        set_error("plk_create: no HIP device visible — plonkit_amd has no CPU fallback (needs gfx950 / MI355X)");
+        return PLK_ERR_HIP;
+    }
+    if (device < 0 || device >= n) { set_error("plk_create: device index out of range"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PLK_HIP(hipGetDeviceProperties(&prop, device));
+    plk_ctx *ctx = new plk_ctx();
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
+    }
+    int32_t rc = ntt_init_tables(ctx);
+    if (rc == PLK_OK) rc = ensure_pinned(ctx, 1 << 16);
+    if (rc != PLK_OK) { plk_destroy(ctx); return rc; }
+    *out = ctx;
+    return PLK_OK;
+}
+
+void plk_destroy(plk_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+    for (void *p : ctx->coset_allocs) (void)hipFree(p);
+    ctx->tables.release(); ctx->ntt_scratch.release(); ctx->srs_own.release();
+    ctx->msm_a.release(); ctx->msm_b.release(); ctx->msm_c.release(); ctx->msm_d.release(); ctx->msm_e.release();
+    ctx->stage.release();
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int32_t plk_synchronize(plk_ctx *ctx) {
+    if (!ctx) { set_error("null ctx"); return PLK_ERR_ARG; }
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLK_OK;
+}
+
+// ------------------------------------------------------------------------------------ SRS
+int32_t plk_srs_upload(plk_ctx *ctx, const plk_g1_affine *bases, uint64_t n) {
+    if (!ctx || !bases || n == 0) { set_error("plk_srs_upload: bad argument"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(ctx->srs_own.reserve(n * sizeof(plk_g1_affine)));
+    PLK_HIP(hipMemcpyAsync(ctx->srs_own.p, bases, n * sizeof(plk_g1_affine), hipMemcpyHostToDevice, ctx->stream));
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->srs = ctx->srs_own.p;
+    ctx->srs_n = n;
+    return PLK_OK;
+}
+
+int32_t plk_srs_set_dev(plk_ctx *ctx, const void *bases_dev, uint64_t n) {
+    if (!ctx || !bases_dev || n == 0) { set_error("plk_srs_set_dev: bad argument"); return PLK_ERR_ARG; }
+    ctx->srs = bases_dev;
+    ctx->srs_n = n;
+    return PLK_OK;
+}
+
+uint64_t plk_srs_size(const plk_ctx *ctx) { return ctx ? ctx->srs_n : 0; }
+
+// ------------------------------------------------------------------------------------ NTT
+int32_t plk_ntt_dev(plk_ctx *ctx, void *data_dev, uint32_t log_n, int32_t inverse, const plk_fr *coset, void *stream) {
+    if (!ctx) { set_error("null ctx"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    Fr g;
+    if (coset) memcpy(&g, coset, 32);
+    return ntt_dev(ctx, (Fr *)data_dev, log_n, inverse != 0, coset ? &g : nullptr, s);
+}
+
+int32_t plk_ntt(plk_ctx *ctx, plk_fr *data, uint32_t log_n, int32_t inverse, const plk_fr *coset) {
+    if (!ctx || !data) { set_error("plk_ntt: bad argument"); return PLK_ERR_ARG; }
+    if (log_n > MAX_LOG_N) { set_error("ntt: log_n exceeds the 2-adicity of Fr (28)"); return PLK_ERR_SIZE; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    size_t bytes = sizeof(plk_fr) << log_n;
+    PLK_TRY(ctx->stage.reserve(bytes));
+    PLK_HIP(hipMemcpyAsync(ctx->stage.p, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PLK_TRY(plk_ntt_dev(ctx, ctx->stage.p, log_n, inverse, coset, nullptr));
+    PLK_HIP(hipMemcpyAsync(data, ctx->stage.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLK_OK;
+}
+
+int32_t plk_lde4_dev(plk_ctx *ctx, const void *coeffs_dev, uint32_t log_n, void *out_4n_dev, void *stream) {
+    if (!ctx || !coeffs_dev || !out_4n_dev) { set_error("plk_lde4_dev: bad argument"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    return lde4_dev(ctx, (const Fr *)coeffs_dev, log_n, (Fr *)out_4n_dev, s);
+}
+
+int32_t plk_lde4(plk_ctx *ctx, const plk_fr *coeffs, uint32_t log_n, plk_fr *out_4n) {
+    if (!ctx || !coeffs || !out_4n) { set_error("plk_lde4: bad argument"); return PLK_ERR_ARG; }
+    if (log_n + 2 > MAX_LOG_N) { set_error("lde4: 4n exceeds 2^28"); return PLK_ERR_SIZE; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    size_t bytes = sizeof(plk_fr) << log_n;
+    PLK_TRY(ctx->stage.reserve(5 * bytes));
+    char *d_in = (char *)ctx->stage.p, *d_out = d_in + bytes;
+    PLK_HIP(hipMemcpyAsync(d_in, coeffs, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PLK_TRY(lde4_dev(ctx, (const Fr *)d_in, log_n, (Fr *)d_out, ctx->stream));
+    PLK_HIP(hipMemcpyAsync(out_4n, d_out, 4 * bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+"""-m gpu: parity of the HIP hot path (through the C ABI) against the CPU oracle, bit-exact.
+
+Covers the reference's kernels on this path: Polynomial::{fft,ifft,coset_fft,icoset_fft}, coset_lde(4)
+and commit_using_monomials/dense_multiexp (call sites src/plonk.rs:104,122-124,132-176)."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle_lib as ol
+from oracle.oracle_lib import R_MOD
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import plonkit_amd as pa
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def _rand_fr(n, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)          # < 2^252 < r: valid Montgomery residues
+    return a
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 10, 11, 12, 13, 14, 16, 18])
+def test_ntt_matches_oracle(ctx, log_n):
+    a = _rand_fr(1 << log_n, 100 + log_n)
+    assert np.array_equal(ctx.ntt(a, log_n), ol.ntt(a, log_n))
+    assert np.array_equal(ctx.ntt(a, log_n, inverse=True), ol.ntt(a, log_n, inverse=True))
+
+
+@pytest.mark.parametrize("log_n", [3, 9, 12, 15, 17])
+def test_coset_ntt_and_roundtrip(ctx, log_n):
+    a = _rand_fr(1 << log_n, 7 + log_n)
+    g = ol.fr_mont(7)
+    f = ctx.ntt(a, log_n, coset=g)
+    assert np.array_equal(f, ol.ntt(a, log_n, coset=7))
+    assert np.array_equal(ctx.ntt(f, log_n, inverse=True, coset=g), a)
+    other = 0x123456789abcdef
+    assert np.array_equal(ctx.ntt(a, log_n, inverse=True, coset=ol.fr_mont(other)), ol.ntt(a, log_n, inverse=True, coset=other))
+
+
+@pytest.mark.parametrize("log_n", [20, 22])
+def test_ntt_large_properties(ctx, log_n):
+    """full BASELINE size: oracle parity at 2^20, plus size-independent properties (round trip,
+    linearity, evaluation at a point)."""
+    n = 1 << log_n
+    a, b = _rand_fr(n, 1), _rand_fr(n, 2)
+    fa = ctx.ntt(a, log_n)
+    if log_n <= 20:
+        assert np.array_equal(fa, ol.ntt(a, log_n))
+    assert np.array_equal(ctx.ntt(fa, log_n, inverse=True), a)
+    fb = ctx.ntt(b, log_n)
+    assert np.array_equal(ctx.ntt(ol.vadd(a, b), log_n), ol.vadd(fa, fb))
+    w = ol.omega(log_n)
+    for k in (0, 1, 12345, n - 1):
+        assert ol.fr_ints(fa[k:k + 1])[0] == ol.poly_eval(a, pow(w, k, R_MOD))
+
+
+@pytest.mark.parametrize("log_n", [3, 10, 14])
+def test_lde4(ctx, log_n):
+    a = _rand_fr(1 << log_n, 40 + log_n)
+    ext = np.zeros((4 << log_n, 4), dtype=np.uint64)
+    ext[:1 << log_n] = a
+    assert np.array_equal(ctx.lde4(a, log_n), ol.ntt(ext, log_n + 2, coset=7))
+
+
+def test_ntt_errors(ctx):
+    import plonkit_amd as pa
+    with pytest.raises(pa.PlkError) as e:
+        pa._lib._check(pa.lib().plk_ntt_dev(ctx._h, None, 29, 0, None, None))
+    assert e.value.code in (1, 2)
+
+
+# ------------------------------------------------------------------------------------ MSM
+@pytest.fixture(scope="module")
+def srs16():
+    return ol.crs42(1 << 16)
+
+
+def _trapdoor(ks):
+    """MSM(s, crs_42) = (sum s_i 42^i) * G  (the tau = 42 known-answer oracle)."""
+    acc, p = 0, 1
+    for k in ks:
+        acc = (acc + k * p) % R_MOD
+        p = p * 42 % R_MOD
+    return ol.g1_mul(ol.g1_generator(), acc)
+
+
+@pytest.mark.parametrize("n", [1, 2, 8, 33, 255, 256, 1000, 4095, 4096, 5000, 1 << 15, 40000, 1 << 16])
+def test_msm_matches_oracle(ctx, srs16, n):
+    ctx.srs_upload(srs16)
+    rng = random.Random(n)
+    ks = [rng.randrange(R_MOD) for _ in range(n)]
+    got = ctx.msm(ol.fr_vec(ks))
+    assert np.array_equal(got, _trapdoor(ks))
+    if n <= 5000:
+        assert np.array_equal(got, ol.msm(srs16[:n], ol.fr_vec(ks)))
+
+
+def test_msm_base_offset(ctx, srs16):
+    ctx.srs_upload(srs16)
+    rng = random.Random(5)
+    ks = [rng.randrange(R_MOD) for _ in range(6000)]
+    assert np.array_equal(ctx.msm(ol.fr_vec(ks), base_offset=1000), ol.msm(srs16[1000:7000], ol.fr_vec(ks)))
+
+
+@pytest.mark.parametrize("kind", ["zeros", "ones", "minus_one", "witness_like", "small", "one_hot"])
+@pytest.mark.parametrize("n", [300, 1 << 14])
+def test_msm_scalar_distributions(ctx, srs16, kind, n):
+    """the four distributions of SURVEY.md §8(d) + degenerate ones; hot buckets and all-zero output"""
+    ctx.srs_upload(srs16)
+    rng = random.Random(11)
+    if kind == "zeros":
+        ks = [0] * n
+    elif kind == "ones":
+        ks = [1] * n
+    elif kind == "minus_one":
+        ks = [R_MOD - 1] * n
+    elif kind == "witness_like":
+        ks = [0 if rng.random() < 0.5 else (rng.randrange(1 << 16) if rng.random() < 0.5 else rng.randrange(R_MOD)) for _ in range(n)]
+    elif kind == "small":
+        ks = [rng.randrange(4) for _ in range(n)]
+    else:
+        ks = [0] * n
+        ks[n // 3] = R_MOD - 2
+    got = ctx.msm(ol.fr_vec(ks))
+    assert np.array_equal(got, _trapdoor(ks))
+    if kind == "zeros":
+        import plonkit_amd as pa
+        assert pa.g1_to_bytes(got) == b"\x40" + b"\x00" * 63
+
+
+def test_msm_duplicate_and_opposite_bases(ctx, srs16):
+    """add == double and P + (-P) inside one bucket; infinity bases are skipped"""
+    p = srs16[3]
+    bases = np.stack([p] * 3000 + [ol.g1_neg(p)] * 3000 + [np.zeros(8, dtype=np.uint64)] * 144)
+    ctx.srs_upload(bases)
+    ks = [5] * 3000 + [5] * 3000 + [77] * 144
+    assert ol.g1_is_inf(ctx.msm(ol.fr_vec(ks)))
+    ks = [9] * 3000 + [1] * 3000 + [77] * 144
+    assert np.array_equal(ctx.msm(ol.fr_vec(ks)), ol.g1_mul(p, 8 * 3000))
+    ctx.srs_upload(bases[:300])
+    assert np.array_equal(ctx.msm(ol.fr_vec([7] * 300)), ol.g1_mul(p, 7 * 300))
+
+
+def test_msm_errors(ctx, srs16):
+    import plonkit_amd as pa
+    ctx.srs_upload(srs16[:100])
+    with pytest.raises(pa.PlkError) as e:
+        ctx.msm(ol.fr_vec([1] * 101))
+    assert e.value.code == 3
+
+
+def test_msm_2pow20_trapdoor(ctx):
+    """BASELINE config 2 size: 2^20 uniform scalars against the O(N) trapdoor answer."""
+    n = 1 << 20
+    srs = ol.crs42(n)
+    ctx.srs_upload(srs)
+    s = _rand_fr(n, 99)
+    ks = ol.fr_ints(s)
+    assert np.array_equal(ctx.msm(s), _trapdoor(ks))
