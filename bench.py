@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the PLONK prove hot path on MI355X (BASELINE.json metric:
+"PLONK prove wall-clock (s) + G1 MSM throughput (Mscalar·mul/s) at 2^20 domain, 1/2/4/8 GPU").
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one KZG commitment (G1 MSM) of 2^20 uniform scalars per GPU against that GPU's resident
+shard of a tau = 42 monomial SRS (BASELINE.json configs[1]; with N GPUs the job is one commitment
+of N*2^20 terms with the bases split across ranks, partial sums exchanged over RCCL — "weak").
+`value` = total scalar·muls per second over all ranks, inputs resident in HBM.
+The one JSON line also carries `roofline` (dominant kernel: msm_accumulate, HIP-event timed),
+`cpu_baseline` (oracle restatement of bellman's dense_multiexp on the host cores, bounded sample)
+and, at N=1, `prove` (wall-clock of a full prove at the 2^20 domain once the prover is built in).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+ALGO_BYTES_PER_TERM = 96         # 64 B base + 32 B scalar
+
+
+def rand_scalars(n, seed, device):
+    """uniform 252-bit residues (valid Montgomery Fr representatives), generated on the GPU"""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    t = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device=device, generator=g)
+    t[:, 3] &= (1 << 60) - 1
+    return t
+
+
+def cpu_baseline(ctx, log_sample, seed):
+    """bellman dense_multiexp restatement (oracle/, kind "port") on the host cores, bounded sample"""
+    from oracle import oracle_lib as ol          # checker / baseline only — never on the product path
+    m = 1 << log_sample
+    bases = ctx.srs_download(0, m)
+    rng = np.random.default_rng(seed)
+    s = rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64)
+    s[:, 3] &= np.uint64((1 << 60) - 1)
+    cores = os.cpu_count() or 1
+    ol.msm(bases[:1024], s[:1024], threads=cores)            # warm the library
+    t0 = time.perf_counter()
+    ref = ol.msm(bases, s, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": m / dt / 1e6, "unit": "Mscalar·mul/s", "cores": cores, "kind": "port",
+            "sample": "one dense_multiexp (c=ceil(ln n), per-thread buckets) of 2^%d uniform scalars, %.2f s" % (log_sample, dt)}, ref, s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=20, help="log2 of the per-GPU commitment size")
+    ap.add_argument("--cpu-log-n", type=int, default=20, help="log2 of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import plonkit_amd as pa
+    from plonkit_amd.sharded import ShardedMsm
+
+    ctx = pa.Context(local_rank)
+    n = 1 << args.log_n
+    ctx.srs_generate(n, start=rank * n, tau=42)          # this rank's shard of the N*2^20 monomial SRS
+    scalars = rand_scalars(n, 0x706c6f6e6b6974 + rank, device)
+    stream = torch.cuda.Stream(device=device)
+    msm = ShardedMsm(ctx, dist if world > 1 else None, device)
+    ctx.set_kernel_timing(True)
+
+    def step():
+        return msm.commit(scalars, n, stream=stream)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        kernel_ms.append(ctx.msm_last_kernel_ms())
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = world * n / (elapsed / args.steps) / 1e6
+        k_ms = float(np.mean(kernel_ms))
+        achieved = ALGO_BYTES_PER_TERM * n / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "G1 MSM throughput at 2^%d terms per GPU (KZG commitment of the PLONK prover)" % args.log_n,
+            "value": round(value, 3), "unit": "Mscalar·mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u256 (BN254 Fr/Fq Montgomery, 8x32-bit limbs)", "data": "synthetic",
+            "config": {"workload": "Pippenger G1 MSM, 2^%d uniform scalars per GPU, tau=42 monomial SRS sharded by rank "
+                                   "(BASELINE.json configs[1]: SRS 2^20, single MI355X at N=1)" % args.log_n,
+                       "terms_per_gpu": n, "parallelism": "srs-shard x%d + all_gather of partial sums" % world,
+                       "result_x_be": pa.g1_to_bytes(out).hex()[:64]},
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel_ms": round(k_ms, 4), "algorithmic_bytes": ALGO_BYTES_PER_TERM * n,
+                         "note": "MSM is bound by 32-bit integer multiply-add issue, not HBM (SURVEY.md §8d): "
+                                 "%.2f G mixed-adds/s" % (n * (254 // 16 + 1) / (k_ms * 1e-3) / 1e9)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, ref, s_host = cpu_baseline(ctx, min(args.cpu_log_n, args.log_n), 1234)
+            got = ctx.msm(s_host)                         # same sample through the HIP path
+            cb["matches_gpu"] = bool(np.array_equal(got, ref))
+            line["cpu_baseline"] = cb
+        try:
+            from plonkit_amd import prover_bench
+            line["prove"] = prover_bench.run(ctx, args.log_n)
+        except ImportError:
+            pass
+        print(json.dumps(line, ensure_ascii=False), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,10 @@ int32_t plk_synchronize(plk_ctx *ctx);
 int32_t plk_srs_upload(plk_ctx *ctx, const plk_g1_affine *bases_host, uint64_t n);
 int32_t plk_srs_set_dev(plk_ctx *ctx, const void *bases_dev, uint64_t n);       /* borrowed, not copied */
 uint64_t plk_srs_size(const plk_ctx *ctx);
+/* Crs::crs_42(size, &Worker) generalised (src/plonk.rs:30-48, `plonkit setup`): fills the resident SRS
+ * with tau^(start+i)*G, i < n, computed on the GPU; tau = 42 reproduces the reference's local keys. */
+int32_t plk_srs_generate(plk_ctx *ctx, uint64_t n, uint64_t start, uint32_t tau);
+int32_t plk_srs_download(plk_ctx *ctx, uint64_t offset, uint64_t n, plk_g1_affine *out_host);
 
 /* ---- Polynomial::{fft,ifft,coset_fft,icoset_fft} over Fr (bellman_ce::plonk::polynomials; driven
  *      from setup() src/plonk.rs:104 and prove_by_steps src/plonk.rs:152-159).
@@ -78,6 +82,9 @@ int32_t plk_msm_g1_partial_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n
 /* enqueue only (no host sync): window sums land in an internal device buffer; finish with _finish */
 int32_t plk_msm_g1_enqueue_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, void *stream);
 int32_t plk_msm_g1_finish(plk_ctx *ctx, plk_g1_jacobian *out);
+/* tracing hook: HIP events around the bucket-accumulation kernel of the last MSM (bench roofline) */
+int32_t plk_set_kernel_timing(plk_ctx *ctx, int32_t on);
+int32_t plk_msm_last_kernel_ms(plk_ctx *ctx, float *accumulate_ms);
 
 /* ---- Crs::<Lagrange>::from_powers (src/plonk.rs:179-185): inverse NTT over G1 (dump-lagrange)  */
 int32_t plk_g1_intt(plk_ctx *ctx, const plk_g1_affine *in_host, uint32_t log_n, plk_g1_affine *out_host);

@@ -110,6 +110,23 @@ class Context:
     def srs_size(self):
         return lib().plk_srs_size(self._h)
 
+    def srs_generate(self, n, start=0, tau=42):
+        """Crs::crs_42 on the GPU (src/plonk.rs:30-48): resident SRS <- tau^(start+i) * G."""
+        _check(lib().plk_srs_generate(self._h, ctypes.c_uint64(n), ctypes.c_uint64(start), ctypes.c_uint32(tau)))
+
+    def srs_download(self, offset, n):
+        out = np.zeros((n, 8), dtype=np.uint64)
+        _check(lib().plk_srs_download(self._h, ctypes.c_uint64(offset), ctypes.c_uint64(n), _np(out)))
+        return out
+
+    def set_kernel_timing(self, on=True):
+        _check(lib().plk_set_kernel_timing(self._h, ctypes.c_int32(1 if on else 0)))
+
+    def msm_last_kernel_ms(self):
+        v = ctypes.c_float(0)
+        _check(lib().plk_msm_last_kernel_ms(self._h, ctypes.byref(v)))
+        return v.value
+
     # ---- NTT
     def ntt(self, data, log_n, inverse=False, coset=None):
         """host array in, new host array out (natural order)."""

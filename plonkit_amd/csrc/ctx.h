@@ -71,4 +71,7 @@ struct plk_ctx {
     uint32_t msm_windows = 0, msm_c_bits = 0, msm_pending_parts = 0;
     hipStream_t msm_stream = nullptr;
     std::vector<double> timings;
+    // optional HIP-event bracket around the dominant kernel of the last MSM (bench roofline)
+    bool ev_on = false;
+    hipEvent_t ev[2] = {nullptr, nullptr};
 };

@@ -32,6 +32,7 @@ constexpr uint32_t FINE_BITS = 7;                 // 128 buckets per accumulate 
 constexpr uint32_t FINE = 1u << FINE_BITS;
 constexpr uint32_t CHUNK = 4096;                  // entries sorted in LDS at a time
 constexpr uint32_t SCALARS_PER_BLOCK = 4096;      // partition kernels
+constexpr uint32_t TASK_MAX = 2 * CHUNK;             // entries per accumulate workgroup
 constexpr uint32_t HEAVY = 96;                    // per-chunk bucket population handled cooperatively
 constexpr uint32_t REDUCE_GROUP = 16;             // buckets per thread in the running-sum kernel
 
@@ -117,24 +118,33 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_partition(const Fr *scalars, 
     }
 }
 
-// exclusive scan of the (W * nbins) histogram -> bin_start[total+1]; clears the cursors
-__global__ void __launch_bounds__(1024) msm_scan_bins(uint32_t *hist, uint32_t *bin_start, uint32_t total_bins) {
-    __shared__ uint32_t sums[1024];
+// exclusive scan of the (W * nbins) histogram -> bin_start[total+1], and of the per-bin task counts
+// ceil(count / TASK_MAX) -> task_start[total+1]; clears the cursors.  A bin that is much larger
+// than the others (top window with few bits, repeated scalars) is cut into several tasks so that
+// no single workgroup walks it alone.
+__global__ void __launch_bounds__(1024) msm_scan_bins(uint32_t *hist, uint32_t *bin_start, uint32_t *task_start, uint32_t total_bins) {
+    __shared__ uint32_t sums[1024], tsums[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (total_bins + 1023) / 1024;
-    uint32_t lo = tid * per, hi = lo + per < total_bins ? lo + per : total_bins, s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += hist[i];
-    sums[tid] = s;
+    uint32_t lo = tid * per, hi = lo + per < total_bins ? lo + per : total_bins, s = 0, ts = 0;
+    if (lo > total_bins) lo = total_bins;
+    for (uint32_t i = lo; i < hi; i++) { s += hist[i]; ts += (hist[i] + TASK_MAX - 1) / TASK_MAX; }
+    sums[tid] = s; tsums[tid] = ts;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t v = tid >= off ? sums[tid - off] : 0;
+        uint32_t v = tid >= off ? sums[tid - off] : 0, tv = tid >= off ? tsums[tid - off] : 0;
         __syncthreads();
-        sums[tid] += v;
+        sums[tid] += v; tsums[tid] += tv;
         __syncthreads();
     }
-    uint32_t run = tid ? sums[tid - 1] : 0;
-    for (uint32_t i = lo; i < hi; i++) { uint32_t c = hist[i]; bin_start[i] = run; run += c; hist[i] = 0; }
-    if (tid == 1023) bin_start[total_bins] = sums[1023];
+    uint32_t run = tid ? sums[tid - 1] : 0, trun = tid ? tsums[tid - 1] : 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        uint32_t c = hist[i];
+        bin_start[i] = run; run += c;
+        task_start[i] = trun; trun += (c + TASK_MAX - 1) / TASK_MAX;
+        hist[i] = 0;
+    }
+    if (tid == 1023) { bin_start[total_bins] = sums[1023]; task_start[total_bins] = tsums[1023]; }
 }
 
 // --------------------------------------------------------------------- bucket accumulation
@@ -164,15 +174,23 @@ __device__ __forceinline__ void accumulate_run(G1Xyzz &acc, const G1Affine *base
     }
 }
 
-// one workgroup per (window, coarse bin): 128 buckets, two lanes per bucket
+// one workgroup per task = (window, coarse bin, slice of <= TASK_MAX entries): 128 buckets, two lanes per bucket
 __global__ void __launch_bounds__(MSM_THREADS) msm_accumulate(const G1Affine *bases, const uint32_t *entries,
-                                                               const uint32_t *bin_start, G1Xyzz *buckets, MsmParams p) {
+                                                               const uint32_t *bin_start, const uint32_t *task_start,
+                                                               G1Xyzz *bucket_parts, MsmParams p) {
     __shared__ uint32_t sorted[CHUNK];
     __shared__ uint32_t cnt[FINE], start[FINE + 1], cursor[FINE];
     __shared__ __attribute__((aligned(16))) G1Xyzz wave_part[MSM_THREADS / 64];
     __shared__ uint32_t heavy_list[FINE], heavy_n;
     const uint32_t tid = threadIdx.x, task = blockIdx.x;
-    const uint32_t s = bin_start[task], e = bin_start[task + 1];
+    const uint32_t total_bins = p.windows * p.nbins;
+    if (task >= task_start[total_bins]) return;
+    // bin = last index with task_start[bin] <= task  (binary search, uniform across the workgroup)
+    uint32_t blo = 0, bhi = total_bins;
+    while (bhi - blo > 1) { uint32_t mid = (blo + bhi) >> 1; if (task_start[mid] <= task) blo = mid; else bhi = mid; }
+    const uint32_t bin = blo, slice = task - task_start[bin];
+    const uint32_t bs = bin_start[bin], be = bin_start[bin + 1];
+    const uint32_t s = bs + slice * TASK_MAX, e = (s + TASK_MAX < be) ? s + TASK_MAX : be;
     const uint32_t my_bucket = tid >> 1, half = tid & 1;
     G1Xyzz acc = xyzz_identity();
 
@@ -239,22 +257,26 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_accumulate(const G1Affine *ba
     G1Xyzz other = shfl_xor_xyzz(acc, 1);
     if (half == 0) {
         xyzz_add_noinline(acc, other);
-        store_xyzz(buckets + (size_t)task * FINE + my_bucket, acc);
+        store_xyzz(bucket_parts + (size_t)task * FINE + my_bucket, acc);
     }
 }
 
 // ------------------------------------------------------------------------ bucket reduction
 // thread: 16 consecutive buckets [g0, g0+16) of one window -> sum_b (b+1) * B_b over its group
-__global__ void __launch_bounds__(MSM_THREADS) msm_reduce_groups(const G1Xyzz *buckets, G1Xyzz *group_out, uint32_t buckets_per_window, uint32_t total_groups) {
+__global__ void __launch_bounds__(MSM_THREADS) msm_reduce_groups(const G1Xyzz *bucket_parts, const uint32_t *task_start, G1Xyzz *group_out,
+                                                                  uint32_t buckets_per_window, uint32_t nbins, uint32_t total_groups) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total_groups) return;
     uint32_t groups_per_window = buckets_per_window / REDUCE_GROUP;
     uint32_t w = g / groups_per_window, gi = g % groups_per_window;
-    const G1Xyzz *b = buckets + (size_t)w * buckets_per_window + (size_t)gi * REDUCE_GROUP;
+    uint32_t bin = w * nbins + ((gi * REDUCE_GROUP) >> FINE_BITS), f0 = (gi * REDUCE_GROUP) & (FINE - 1);
+    uint32_t t0 = task_start[bin], t1 = task_start[bin + 1];
     G1Xyzz run = xyzz_identity(), sum = xyzz_identity();
     for (int i = REDUCE_GROUP - 1; i >= 0; i--) {
-        G1Xyzz v = load_xyzz(b + i);
-        xyzz_add_noinline(run, v);
+        for (uint32_t t = t0; t < t1; t++) {          // usually one part per bucket
+            G1Xyzz v = load_xyzz(bucket_parts + (size_t)t * FINE + f0 + i);
+            xyzz_add_noinline(run, v);
+        }
         xyzz_add_noinline(sum, run);
     }
     // sum = sum_i (i+1) B[g0+i];  add g0 * run
@@ -351,11 +373,12 @@ int32_t msm_enqueue(plk_ctx *ctx, const Fr *scalars_dev, uint64_t n, uint64_t ba
     const uint32_t groups_per_window = buckets_per_window / REDUCE_GROUP;
     const uint32_t total_groups = groups_per_window * p.windows;
 
-    PLK_TRY(ctx->msm_a.reserve((size_t)(2 * total_bins + 2) * sizeof(uint32_t)));           // hist/cursor + bin_start
+    const uint32_t max_tasks = total_bins + (uint32_t)(((uint64_t)p.windows * n) / TASK_MAX) + 1;
+    PLK_TRY(ctx->msm_a.reserve((size_t)(3 * total_bins + 4) * sizeof(uint32_t)));             // hist/cursor + bin_start + task_start
     PLK_TRY(ctx->msm_b.reserve((size_t)p.windows * n * sizeof(uint32_t)));                     // entries
-    PLK_TRY(ctx->msm_c.reserve((size_t)p.windows * buckets_per_window * sizeof(G1Xyzz)));      // buckets
+    PLK_TRY(ctx->msm_c.reserve((size_t)max_tasks * FINE * sizeof(G1Xyzz)));                    // per-task bucket sums
     PLK_TRY(ctx->msm_d.reserve((size_t)(total_groups + p.windows) * sizeof(G1Xyzz)));          // group sums + window sums
-    uint32_t *hist = ctx->msm_a.as<uint32_t>(), *bin_start = hist + total_bins;
+    uint32_t *hist = ctx->msm_a.as<uint32_t>(), *bin_start = hist + total_bins, *task_start = bin_start + total_bins + 1;
     uint32_t *entries = ctx->msm_b.as<uint32_t>();
     G1Xyzz *buckets = ctx->msm_c.as<G1Xyzz>();
     G1Xyzz *groups = ctx->msm_d.as<G1Xyzz>(), *window_out = groups + total_groups;
@@ -364,11 +387,14 @@ int32_t msm_enqueue(plk_ctx *ctx, const Fr *scalars_dev, uint64_t n, uint64_t ba
     const uint32_t pblocks = (uint32_t)((n + SCALARS_PER_BLOCK - 1) / SCALARS_PER_BLOCK);
     const size_t plds = (size_t)2 * total_bins * sizeof(uint32_t);
     hipLaunchKernelGGL(msm_partition<false>, dim3(pblocks), dim3(MSM_THREADS), plds, stream, scalars_dev, p, hist, (const uint32_t *)nullptr, (uint32_t *)nullptr);
-    hipLaunchKernelGGL(msm_scan_bins, dim3(1), dim3(1024), 0, stream, hist, bin_start, total_bins);
+    hipLaunchKernelGGL(msm_scan_bins, dim3(1), dim3(1024), 0, stream, hist, bin_start, task_start, total_bins);
     hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks), dim3(MSM_THREADS), plds, stream, scalars_dev, p, hist, (const uint32_t *)bin_start, entries);
-    hipLaunchKernelGGL(msm_accumulate, dim3(total_bins), dim3(MSM_THREADS), 0, stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start, buckets, p);
+    if (ctx->ev_on) PLK_HIP(hipEventRecord(ctx->ev[0], stream));
+    hipLaunchKernelGGL(msm_accumulate, dim3(max_tasks), dim3(MSM_THREADS), 0, stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
+                       (const uint32_t *)task_start, buckets, p);
+    if (ctx->ev_on) PLK_HIP(hipEventRecord(ctx->ev[1], stream));
     hipLaunchKernelGGL(msm_reduce_groups, dim3((total_groups + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
-                       (const G1Xyzz *)buckets, groups, buckets_per_window, total_groups);
+                       (const G1Xyzz *)buckets, (const uint32_t *)task_start, groups, buckets_per_window, p.nbins, total_groups);
     hipLaunchKernelGGL(msm_sum_window, dim3(p.windows), dim3(MSM_THREADS), 0, stream, (const G1Xyzz *)groups, window_out, groups_per_window);
     PLK_HIP(hipGetLastError());
     PLK_TRY(ensure_pinned(ctx, p.windows * sizeof(G1Xyzz)));
@@ -448,6 +474,22 @@ int32_t plk_msm_g1(plk_ctx *ctx, const plk_fr *scalars, uint64_t n, uint64_t bas
     PLK_TRY(ctx->stage.reserve(n * sizeof(plk_fr) + 32));
     PLK_HIP(hipMemcpyAsync(ctx->stage.p, scalars, n * sizeof(plk_fr), hipMemcpyHostToDevice, ctx->stream));
     return plk_msm_g1_dev(ctx, ctx->stage.p, n, base_offset, out, nullptr);
+}
+
+int32_t plk_set_kernel_timing(plk_ctx *ctx, int32_t on) {
+    if (!ctx) { set_error("null ctx"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    if (on && !ctx->ev[0]) { PLK_HIP(hipEventCreate(&ctx->ev[0])); PLK_HIP(hipEventCreate(&ctx->ev[1])); }
+    ctx->ev_on = on != 0;
+    return PLK_OK;
+}
+
+int32_t plk_msm_last_kernel_ms(plk_ctx *ctx, float *accumulate_ms) {
+    if (!ctx || !accumulate_ms) { set_error("plk_msm_last_kernel_ms: bad argument"); return PLK_ERR_ARG; }
+    if (!ctx->ev_on || !ctx->ev[0]) { set_error("kernel timing is off (plk_set_kernel_timing)"); return PLK_ERR_ARG; }
+    PLK_HIP(hipEventSynchronize(ctx->ev[1]));
+    PLK_HIP(hipEventElapsedTime(accumulate_ms, ctx->ev[0], ctx->ev[1]));
+    return PLK_OK;
 }
 
 int32_t plk_g1_sum_jacobian(const plk_g1_jacobian *parts, uint64_t n, plk_g1_affine *out) {

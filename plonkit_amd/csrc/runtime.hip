@@ -97,6 +97,7 @@ void plk_destroy(plk_ctx *ctx) {
     ctx->msm_a.release(); ctx->msm_b.release(); ctx->msm_c.release(); ctx->msm_d.release(); ctx->msm_e.release();
     ctx->stage.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->ev[0]) { (void)hipEventDestroy(ctx->ev[0]); (void)hipEventDestroy(ctx->ev[1]); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

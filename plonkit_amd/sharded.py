@@ -1,0 +1,41 @@
+"""Multi-GPU KZG commitment: the SRS bases are split across ranks (one process per GPU), every rank
+runs the Pippenger MSM of its shard on its own MI355X, and the 96-byte Jacobian partial sums are
+exchanged with ONE all_gather over RCCL/xGMI, then added on the host (EC addition is not an RCCL
+reduction op, so a literal all_reduce is impossible — SURVEY.md §8e).  NTTs stay single-GPU.
+
+In the reference there is no counterpart (one process, bellman's Worker threads, src/plonk.rs:41);
+the sharded commitment is mathematically the same sum commit_using_monomials computes.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def combine_partials(partial, dist=None, device=None):
+    """partial: uint64[12] Jacobian of this rank -> affine uint64[8] of the sum over all ranks.
+    With dist == None (single process) it is just the Jacobian -> affine conversion."""
+    partial = np.ascontiguousarray(partial, dtype=np.uint64).reshape(12)
+    if dist is None or dist.get_world_size() == 1:
+        return _lib.g1_sum_jacobian(partial)
+    world = dist.get_world_size()
+    t = torch.from_numpy(partial.view(np.int64).copy())
+    if device is not None:
+        t = t.to(device)
+    out = torch.empty((world, 12), dtype=torch.int64, device=t.device)
+    dist.all_gather_into_tensor(out, t) if hasattr(dist, "all_gather_into_tensor") and t.device.type != "cpu" else \
+        dist.all_gather(list(out.unbind(0)), t)
+    parts = out.cpu().numpy().view(np.uint64)
+    return _lib.g1_sum_jacobian(parts)
+
+
+class ShardedMsm:
+    """commit(scalars) = sum over ranks of MSM(local scalars, local SRS shard)."""
+
+    def __init__(self, ctx, dist=None, device=None):
+        self.ctx, self.dist, self.device = ctx, dist, device
+
+    def commit(self, scalars_dev, n, base_offset=0, stream=None):
+        self.ctx.msm_enqueue_dev(scalars_dev, n, base_offset, stream=stream)
+        partial = self.ctx.msm_finish()
+        return combine_partials(partial, self.dist, self.device)

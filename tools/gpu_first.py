@@ -14,8 +14,8 @@ def rnd(n, seed):
 for log_n in (16, 20, 22, 24):
     n = 1 << log_n
     t = torch.from_numpy(rnd(n, 1).view(np.int64)).to(dev)
-    st = torch.cuda.current_stream()
-    for inv in (False,):
+    st = torch.cuda.Stream(); torch.cuda.set_stream(st)
+    for inv in (False, True):
         ctx.ntt_dev(t, log_n, inverse=inv, stream=st); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); reps = 10
@@ -26,7 +26,7 @@ for log_n in (16, 20, 22, 24):
 n = 1 << 20
 t0 = time.time(); srs = ol.crs42(n); print("crs42 gen", time.time() - t0, flush=True)
 ctx.srs_upload(srs)
-for ln in (16, 18, 20):
+for ln in (12, 14, 16, 17, 18, 20):
     m = 1 << ln
     s = torch.from_numpy(rnd(m, 3).view(np.int64)).to(dev)
     st = torch.cuda.current_stream()
