@@ -88,6 +88,8 @@ int32_t plk_msm_last_kernel_ms(plk_ctx *ctx, float *accumulate_ms);
 
 /* ---- Crs::<Lagrange>::from_powers (src/plonk.rs:179-185): inverse NTT over G1 (dump-lagrange)  */
 int32_t plk_g1_intt(plk_ctx *ctx, const plk_g1_affine *in_host, uint32_t log_n, plk_g1_affine *out_host);
+/* same, from the first 2^log_n points of the resident SRS into a device buffer (64 B per point) */
+int32_t plk_g1_intt_srs_dev(plk_ctx *ctx, uint32_t log_n, void *out_dev, void *stream);
 
 /* ---- host-side G1 helpers (pure CPU, usable without a GPU) ---------------------------------- */
 int32_t plk_g1_sum_jacobian(const plk_g1_jacobian *parts, uint64_t n, plk_g1_affine *out);

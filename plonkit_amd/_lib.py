@@ -185,6 +185,91 @@ class Context:
         return out
 
 
+    def g1_intt_srs_dev(self, log_n, out_ptr, stream=None):
+        _check(lib().plk_g1_intt_srs_dev(self._h, ctypes.c_uint32(log_n), _devptr(out_ptr), _stream(stream)))
+
+
+# ------------------------------------------------- circuit pipeline (mirrors src/plonk.rs's API)
+class Circuit:
+    """CircomCircuit{r1cs, witness, wire_mapping: None, aux_offset: 1} (src/circom_circuit.rs:41-47).
+    File type is chosen from the suffix exactly as the reference does (src/reader.rs:93,179)."""
+
+    def __init__(self, r1cs_bytes, r1cs_is_json, witness_bytes=None, witness_is_json=False):
+        self._h = ctypes.c_void_p()
+        _check(lib().plk_circuit_load(bytes(r1cs_bytes), ctypes.c_uint64(len(r1cs_bytes)), ctypes.c_int32(1 if r1cs_is_json else 0),
+                                      bytes(witness_bytes) if witness_bytes is not None else None,
+                                      ctypes.c_uint64(len(witness_bytes) if witness_bytes is not None else 0),
+                                      ctypes.c_int32(1 if witness_is_json else 0), ctypes.byref(self._h)))
+
+    @classmethod
+    def from_files(cls, r1cs_path, witness_path=None):
+        w = open(witness_path, "rb").read() if witness_path else None
+        return cls(open(r1cs_path, "rb").read(), r1cs_path.endswith("json"), w, bool(witness_path) and witness_path.endswith("json"))
+
+    def analyse(self):
+        """plonk::analyse (src/plonk.rs:72-93) as the serde_json string of src/tests.rs:14"""
+        buf = ctypes.create_string_buffer(1 << 20)
+        _check(lib().plk_circuit_analyse(self._h, buf, ctypes.c_uint64(len(buf))))
+        return buf.value.decode()
+
+    def close(self):
+        if self._h:
+            lib().plk_circuit_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SetupForProver:
+    """SetupForProver (src/plonk.rs:50-176): prepare_setup_for_prover / make_verification_key / prove."""
+
+    def __init__(self, ctx, circuit):
+        self.ctx = ctx
+        self._h = ctypes.c_void_p()
+        _check(lib().plk_setup_prepare(ctx._h, circuit._h, ctypes.byref(self._h)))
+
+    @property
+    def domain_size(self):
+        return lib().plk_setup_domain_size(self._h)
+
+    def verification_key_bytes(self, g2_bytes):
+        assert len(g2_bytes) == 256
+        out = ctypes.create_string_buffer(4096)
+        n = ctypes.c_uint64(0)
+        _check(lib().plk_setup_write_vk(self.ctx._h, self._h, bytes(g2_bytes), out, ctypes.c_uint64(len(out)), ctypes.byref(n)))
+        return out.raw[:n.value]
+
+    def prove(self, circuit):
+        """proof.bin bytes (keccak transcript, monomial key — src/plonk.rs:152-159)"""
+        cap = 1 << 16
+        out = ctypes.create_string_buffer(cap)
+        n = ctypes.c_uint64(0)
+        _check(lib().plk_prove(self.ctx._h, self._h, circuit._h, out, ctypes.c_uint64(cap), ctypes.byref(n)))
+        return out.raw[:n.value]
+
+    def timings_ms(self):
+        arr = (ctypes.c_double * 16)()
+        cnt = ctypes.c_uint32(0)
+        _check(lib().plk_prove_timings(self.ctx._h, arr, ctypes.c_uint32(16), ctypes.byref(cnt)))
+        names = ["synthesis+check", "round1", "round2", "round3", "round4", "round5", "serialise"]
+        return {names[i] if i < len(names) else str(i): arr[i] for i in range(cnt.value)}
+
+    def close(self):
+        if self._h:
+            lib().plk_setup_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------ CPU-only helpers of the ABI
 def g1_sum_jacobian(parts):
     parts = np.ascontiguousarray(parts, dtype=np.uint64).reshape(-1, 12)

@@ -1,0 +1,424 @@
+// see circuit.h for the reference mapping
+#include "circuit.h"
+#include "../../include/plonkit_amd.h"
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <unordered_map>
+
+namespace plk {
+void set_error(const std::string &msg);
+
+// ------------------------------------------------------------------------------- scalars
+bool fr_from_decimal(const std::string &s, HFr *out) {
+    if (s.empty()) return false;
+    HFr acc = HFr::zero(), ten = HFr::from_u64(10);
+    for (char ch : s) {
+        if (ch < '0' || ch > '9') return false;
+        acc = acc * ten + HFr::from_u64((uint64_t)(ch - '0'));
+    }
+    *out = acc;
+    return true;
+}
+
+static bool fr_from_le32(const uint8_t *p, HFr *out) {
+    uint64_t c[4];
+    memcpy(c, p, 32);
+    if (HFr::geq_p(c)) return false;          // read_field: rejected when >= r (src/r1cs_file.rs:37-42)
+    *out = HFr::from_canonical(c);
+    return true;
+}
+
+static const uint8_t BN254_R_LE[32] = {0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x70, 0xb9, 0x79, 0x48, 0xe8, 0x33, 0x28,
+                                       0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45, 0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};
+
+struct Rd {
+    const uint8_t *p; size_t len, off = 0; bool ok = true;
+    Rd(const uint8_t *p_, size_t l) : p(p_), len(l) {}
+    bool need(size_t n) { if (off + n > len || off + n < off) { ok = false; return false; } return true; }
+    uint32_t u32() { if (!need(4)) return 0; uint32_t v; memcpy(&v, p + off, 4); off += 4; return v; }
+    uint64_t u64() { if (!need(8)) return 0; uint64_t v; memcpy(&v, p + off, 8); off += 8; return v; }
+};
+
+// ------------------------------------------------------------------------- .r1cs (binary)
+bool parse_r1cs_bin(const uint8_t *data, size_t len, R1cs *out) {
+    Rd r(data, len);
+    if (len < 12 || memcmp(data, "r1cs", 4) != 0) { set_error("Invalid magic number"); return false; }
+    r.off = 4;
+    if (r.u32() != 1) { set_error("Unsupported version"); return false; }
+    uint32_t nsec = r.u32();
+    std::map<uint32_t, std::pair<size_t, uint64_t>> secs;
+    for (uint32_t i = 0; i < nsec; i++) {
+        uint32_t t = r.u32(); uint64_t sz = r.u64();
+        if (!r.ok || !r.need(sz)) { set_error("InvalidData: truncated section table"); return false; }
+        secs[t] = {r.off, sz};
+        r.off += sz;
+    }
+    if (!secs.count(1) || !secs.count(2) || !secs.count(3)) { set_error("InvalidData: missing section"); return false; }
+    r.off = secs[1].first;
+    uint32_t field_size = r.u32();
+    if (!r.ok || !r.need(field_size)) { set_error("InvalidData: truncated header"); return false; }
+    const uint8_t *prime = data + r.off;
+    r.off += field_size;
+    if (secs[1].second != 32 + (uint64_t)field_size) { set_error("Invalid header section size"); return false; }
+    uint32_t n_wires = r.u32(), n_pub_out = r.u32(), n_pub_in = r.u32(), n_prv_in = r.u32();
+    uint64_t n_labels = r.u64(); uint32_t n_constraints = r.u32();
+    (void)n_prv_in; (void)n_labels;
+    if (!r.ok) { set_error("InvalidData: truncated header"); return false; }
+    if (field_size != 32) { set_error("This parser only supports 32-byte fields"); return false; }
+    if (memcmp(prime, BN254_R_LE, 32) != 0) { set_error("This parser only supports bn256"); return false; }
+    r.off = secs[2].first;
+    out->constraints.clear();
+    out->constraints.resize(n_constraints);
+    for (uint32_t i = 0; i < n_constraints; i++) {
+        Lc *abc[3] = {&out->constraints[i].a, &out->constraints[i].b, &out->constraints[i].c};
+        for (int k = 0; k < 3; k++) {
+            uint32_t nv = r.u32();
+            if (!r.ok || !r.need((size_t)nv * 36)) { set_error("InvalidData: truncated constraint"); return false; }
+            abc[k]->resize(nv);
+            for (uint32_t j = 0; j < nv; j++) {
+                (*abc[k])[j].wire = r.u32();
+                if (!fr_from_le32(data + r.off, &(*abc[k])[j].coeff)) { set_error("InvalidData: coefficient not in field"); return false; }
+                r.off += 32;
+            }
+        }
+    }
+    if (secs[3].second != (uint64_t)n_wires * 8) { set_error("Invalid map section size"); return false; }
+    r.off = secs[3].first;
+    if (n_wires) { uint64_t first = r.u64(); if (!r.ok || first != 0) { set_error("Wire 0 should always be mapped to 0"); return false; } }
+    out->num_inputs = 1 + (uint64_t)n_pub_in + n_pub_out;        // src/reader.rs:229
+    out->num_variables = n_wires;
+    if (out->num_variables < out->num_inputs) { set_error("InvalidData: fewer wires than inputs"); return false; }
+    out->num_aux = out->num_variables - out->num_inputs;
+    return true;
+}
+
+// ---------------------------------------------------------------------------- tiny JSON
+struct JVal {
+    enum { NUL, BOOL, NUM, STR, ARR, OBJ } t = NUL;
+    std::string s;                                   // NUM / STR text
+    std::vector<JVal> a;
+    std::vector<std::pair<std::string, JVal>> o;
+    const JVal *get(const char *k) const { for (auto &kv : o) if (kv.first == k) return &kv.second; return nullptr; }
+};
+
+struct JParser {
+    const char *p, *e; bool ok = true;
+    void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) p++; }
+    bool str(std::string *out) {
+        if (p >= e || *p != '"') return ok = false;
+        p++; out->clear();
+        while (p < e && *p != '"') { if (*p == '\\' && p + 1 < e) { p++; } out->push_back(*p++); }
+        if (p >= e) return ok = false;
+        p++; return true;
+    }
+    bool val(JVal *v, int depth = 0) {
+        if (depth > 64) return ok = false;
+        ws();
+        if (p >= e) return ok = false;
+        if (*p == '{') {
+            v->t = JVal::OBJ; p++; ws();
+            if (p < e && *p == '}') { p++; return true; }
+            while (ok) {
+                ws(); std::string k; if (!str(&k)) return false;
+                ws(); if (p >= e || *p != ':') return ok = false; p++;
+                v->o.emplace_back(k, JVal());
+                if (!val(&v->o.back().second, depth + 1)) return false;
+                ws(); if (p < e && *p == ',') { p++; continue; }
+                if (p < e && *p == '}') { p++; return true; }
+                return ok = false;
+            }
+        } else if (*p == '[') {
+            v->t = JVal::ARR; p++; ws();
+            if (p < e && *p == ']') { p++; return true; }
+            while (ok) {
+                v->a.emplace_back();
+                if (!val(&v->a.back(), depth + 1)) return false;
+                ws(); if (p < e && *p == ',') { p++; continue; }
+                if (p < e && *p == ']') { p++; return true; }
+                return ok = false;
+            }
+        } else if (*p == '"') { v->t = JVal::STR; return str(&v->s);
+        } else if (*p == 't' && e - p >= 4) { v->t = JVal::BOOL; v->s = "1"; p += 4; return true;
+        } else if (*p == 'f' && e - p >= 5) { v->t = JVal::BOOL; v->s = "0"; p += 5; return true;
+        } else if (*p == 'n' && e - p >= 4) { v->t = JVal::NUL; p += 4; return true;
+        } else {
+            v->t = JVal::NUM; const char *s0 = p;
+            while (p < e && (isdigit((unsigned char)*p) || *p == '-' || *p == '+' || *p == '.' || *p == 'e' || *p == 'E')) p++;
+            if (p == s0) return ok = false;
+            v->s.assign(s0, p); return true;
+        }
+        return ok;
+    }
+};
+
+static bool json_parse(const uint8_t *data, size_t len, JVal *out) {
+    JParser P{(const char *)data, (const char *)data + len};
+    if (!P.val(out)) return false;
+    P.ws();
+    return P.p == P.e;
+}
+
+static bool json_u64(const JVal *v, uint64_t *out) {
+    if (!v || (v->t != JVal::NUM && v->t != JVal::STR) || v->s.empty()) return false;
+    uint64_t x = 0;
+    for (char c : v->s) { if (c < '0' || c > '9') return false; x = x * 10 + (uint64_t)(c - '0'); }
+    *out = x; return true;
+}
+
+// src/reader.rs:194-218: constraints are BTreeMap<String,String> => terms ordered by the string key
+bool parse_r1cs_json(const uint8_t *data, size_t len, R1cs *out) {
+    JVal root;
+    if (!json_parse(data, len, &root) || root.t != JVal::OBJ) { set_error("unable to read: malformed circuit json"); return false; }
+    uint64_t n_pub, n_out, n_vars;
+    if (!json_u64(root.get("nPubInputs"), &n_pub) || !json_u64(root.get("nOutputs"), &n_out) || !json_u64(root.get("nVars"), &n_vars)) {
+        set_error("unable to read: nPubInputs/nOutputs/nVars missing"); return false; }
+    const JVal *cons = root.get("constraints");
+    if (!cons || cons->t != JVal::ARR) { set_error("unable to read: constraints missing"); return false; }
+    out->num_inputs = n_pub + n_out + 1;
+    if (n_vars < out->num_inputs) { set_error("unable to read: nVars < number of inputs"); return false; }
+    out->num_aux = n_vars - out->num_inputs;
+    out->num_variables = n_vars;
+    out->constraints.clear();
+    out->constraints.resize(cons->a.size());
+    for (size_t i = 0; i < cons->a.size(); i++) {
+        const JVal &c = cons->a[i];
+        if (c.t != JVal::ARR || c.a.size() < 3) { set_error("unable to read: constraint is not [A,B,C]"); return false; }
+        Lc *abc[3] = {&out->constraints[i].a, &out->constraints[i].b, &out->constraints[i].c};
+        for (int k = 0; k < 3; k++) {
+            if (c.a[k].t != JVal::OBJ) { set_error("unable to read: linear combination is not an object"); return false; }
+            std::vector<std::pair<std::string, std::string>> terms;
+            for (auto &kv : c.a[k].o) terms.emplace_back(kv.first, kv.second.s);
+            std::sort(terms.begin(), terms.end(), [](const std::pair<std::string, std::string> &x, const std::pair<std::string, std::string> &y) { return x.first < y.first; });
+            for (auto &t : terms) {
+                uint64_t w = 0; HFr cf;
+                JVal kv; kv.t = JVal::STR; kv.s = t.first;
+                if (!json_u64(&kv, &w) || !fr_from_decimal(t.second, &cf)) { set_error("unable to read: bad term in linear combination"); return false; }
+                abc[k]->push_back({(uint32_t)w, cf});
+            }
+        }
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------ witness
+bool parse_wtns_bin(const uint8_t *data, size_t len, std::vector<HFr> *out) {
+    Rd r(data, len);
+    if (len < 4 || memcmp(data, "wtns", 4) != 0) { set_error("invalid file header"); return false; }
+    r.off = 4;
+    uint32_t version = r.u32();
+    if (!r.ok || version > 2) { set_error("unsupported file version"); return false; }
+    if (r.u32() != 2 || !r.ok) { set_error("invalid num sections"); return false; }
+    if (r.u32() != 1 || !r.ok) { set_error("invalid section type"); return false; }
+    if (r.u64() != 4 + 32 + 4 || !r.ok) { set_error("invalid section len"); return false; }
+    if (r.u32() != 32 || !r.ok) { set_error("invalid field byte size"); return false; }
+    if (!r.need(32) || memcmp(data + r.off, BN254_R_LE, 32) != 0) { set_error("invalid curve prime"); return false; }
+    r.off += 32;
+    uint32_t wl = r.u32();
+    if (r.u32() != 2 || !r.ok) { set_error("invalid section type"); return false; }
+    uint64_t sz = r.u64();
+    if (!r.ok || sz != (uint64_t)wl * 32) { set_error("invalid witness section size"); return false; }
+    if (!r.need(sz)) { set_error("read witness failed: truncated"); return false; }
+    out->resize(wl);
+    for (uint32_t i = 0; i < wl; i++) {
+        if (!fr_from_le32(data + r.off, &(*out)[i])) { set_error("read witness failed: not in field"); return false; }
+        r.off += 32;
+    }
+    return true;
+}
+
+bool parse_witness_json(const uint8_t *data, size_t len, std::vector<HFr> *out) {
+    JVal root;
+    if (!json_parse(data, len, &root) || root.t != JVal::ARR) { set_error("unable to read: witness json is not an array"); return false; }
+    out->resize(root.a.size());
+    for (size_t i = 0; i < root.a.size(); i++)
+        if (!fr_from_decimal(root.a[i].s, &(*out)[i])) { set_error("unable to read: bad witness entry"); return false; }
+    return true;
+}
+
+// --------------------------------------------------------------------------- transpiler
+namespace {
+
+struct Term { uint32_t var; HFr coeff; };
+
+struct Builder {
+    Transpiled *t;
+    bool have_values;
+    const HFr zero = HFr::zero(), one = HFr::one(), minus_one = -HFr::one();
+
+    uint32_t alloc(const HFr &v) {
+        uint32_t id = (uint32_t)t->num_vars++;
+        if (have_values) t->values.push_back(v);
+        return id;
+    }
+    HFr val(uint32_t v) const { return have_values ? t->values[v] : HFr::zero(); }
+    void gate(const uint32_t v[4], const HFr q[7]) {
+        Gate g; memcpy(g.v, v, sizeof g.v); for (int i = 0; i < 7; i++) g.q[i] = q[i];
+        t->gates.push_back(g);
+    }
+
+    // stable de-duplication; wire 0 (the constant ONE) is folded into the constant term
+    static void split(const Lc &lc, HFr *constant, std::vector<Term> *terms) {
+        *constant = HFr::zero(); terms->clear();
+        for (const LcTerm &x : lc) {
+            if (x.wire == 0) { *constant = *constant + x.coeff; continue; }
+            bool found = false;
+            for (Term &y : *terms) if (y.var == x.wire) { y.coeff = y.coeff + x.coeff; found = true; break; }
+            if (!found) terms->push_back({x.wire, x.coeff});
+        }
+        terms->erase(std::remove_if(terms->begin(), terms->end(), [](const Term &y) { return y.coeff.is_zero(); }), terms->end());
+    }
+
+    HFr eval(const std::vector<Term> &lc, const HFr &free) const {
+        HFr s = free;
+        if (have_values) for (const Term &x : lc) s = s + x.coeff * val(x.var);
+        return s;
+    }
+
+    // bellman adaptor::enforce_lc_as_gates [recollection]; single gate pinned by SURVEY.md A.3 row 2
+    void lc_as_gates(std::vector<Term> lc, HFr free, bool collapse, uint32_t *var_out, HFr *coeff_out) {
+        if (lc.size() == 1 && free.is_zero() && collapse) { *var_out = lc[0].var; *coeff_out = lc[0].coeff; return; }
+        uint32_t fin = 0;
+        if (collapse) { fin = alloc(eval(lc, free)); lc.push_back({fin, minus_one}); }
+        if (lc.size() <= 4) {
+            uint32_t v[4] = {0, 0, 0, 0}; HFr q[7];
+            for (int i = 0; i < 7; i++) q[i] = zero;
+            for (size_t i = 0; i < lc.size(); i++) { v[i] = lc[i].var; q[i] = lc[i].coeff; }
+            q[5] = free;
+            gate(v, q);
+        } else {                                             // UNPINNED: chain through d / d_next
+            size_t pos = 0;
+            uint32_t v[4]; HFr q[7];
+            for (int i = 0; i < 7; i++) q[i] = zero;
+            HFr s = free;
+            for (int i = 0; i < 4; i++, pos++) { v[i] = lc[pos].var; q[i] = lc[pos].coeff; if (have_values) s = s + q[i] * val(v[i]); }
+            q[5] = free; q[6] = minus_one;
+            uint32_t nxt = alloc(s);
+            gate(v, q);
+            while (lc.size() - pos > 3) {
+                for (int i = 0; i < 7; i++) q[i] = zero;
+                s = val(nxt);
+                for (int i = 0; i < 3; i++, pos++) { v[i] = lc[pos].var; q[i] = lc[pos].coeff; if (have_values) s = s + q[i] * val(v[i]); }
+                v[3] = nxt; q[3] = one; q[6] = minus_one;
+                uint32_t nn = alloc(s);
+                gate(v, q);
+                nxt = nn;
+            }
+            for (int i = 0; i < 7; i++) q[i] = zero;
+            v[0] = v[1] = v[2] = 0;
+            for (int i = 0; pos < lc.size(); i++, pos++) { v[i] = lc[pos].var; q[i] = lc[pos].coeff; }
+            v[3] = nxt; q[3] = one;
+            gate(v, q);
+        }
+        *var_out = fin; *coeff_out = one;
+    }
+};
+
+}  // namespace
+
+bool transpile(const R1cs &r, const std::vector<HFr> *witness, Transpiled *out) {
+    out->gates.clear(); out->values.clear(); out->stats.clear(); out->num_hints = 0;
+    out->num_vars = r.num_variables;
+    Builder B{out, witness != nullptr};
+    if (witness) {
+        if (witness->size() < r.num_variables) { set_error("witness shorter than the number of variables"); return false; }
+        out->values.assign(witness->begin(), witness->begin() + r.num_variables);
+        out->values[0] = HFr::zero();                        // id 0 is the dummy variable, not circom's ONE
+    }
+    std::vector<Term> al, bl, cl;
+    HFr ac, bc, cc;
+    out->gates.reserve(r.constraints.size() * 2);
+    for (size_t idx = 0; idx < r.constraints.size(); idx++) {
+        const Constraint &k = r.constraints[idx];
+        if ((k.a.empty() || k.b.empty()) && k.c.empty()) continue;          // src/circom_circuit.rs:121-122
+        size_t g0 = out->gates.size();
+        Builder::split(k.a, &ac, &al); Builder::split(k.b, &bc, &bl); Builder::split(k.c, &cc, &cl);
+        bool a_k = al.empty(), b_k = bl.empty(), c_k = cl.empty();
+        uint32_t dv; HFr dc;
+        if (a_k && b_k) {
+            HFr free = cc - ac * bc;
+            if (c_k) { if (!free.is_zero()) { set_error("unsatisfiable constant constraint"); return false; } }
+            else B.lc_as_gates(cl, free, false, &dv, &dc);
+        } else if (a_k || b_k) {                                              // UNPINNED: constant * LC = LC
+            const HFr &kk = a_k ? ac : bc; const std::vector<Term> &lin = a_k ? bl : al; const HFr &lin_c = a_k ? bc : ac;
+            Lc merged;
+            for (const Term &x : lin) merged.push_back({x.var, x.coeff * kk});
+            for (const Term &x : cl) merged.push_back({x.var, -x.coeff});
+            HFr free = kk * lin_c - cc, dummy;
+            std::vector<Term> m2;
+            Builder::split(merged, &dummy, &m2);
+            if (!m2.empty()) B.lc_as_gates(m2, free, false, &dv, &dc);
+            else if (!free.is_zero()) { set_error("unsatisfiable constant constraint"); return false; }
+        } else {
+            bool same = al.size() == 1 && bl.size() == 1 && al[0].var == bl[0].var && (c_k || (cl.size() == 1 && cl[0].var == al[0].var));
+            if (same) {                                                       // UNPINNED: quadratic gate
+                HFr a1 = al[0].coeff, b1 = bl[0].coeff, c1 = c_k ? HFr::zero() : cl[0].coeff;
+                uint32_t v[4] = {al[0].var, al[0].var, 0, 0}; HFr q[7];
+                for (int i = 0; i < 7; i++) q[i] = HFr::zero();
+                q[0] = ac * b1 + a1 * bc - c1; q[4] = a1 * b1; q[5] = ac * bc - cc;
+                B.gate(v, q);
+            } else {
+                uint32_t av, bv, cv; HFr acoef, bcoef, ccoef;
+                B.lc_as_gates(al, ac, true, &av, &acoef);
+                B.lc_as_gates(bl, bc, true, &bv, &bcoef);
+                HFr q[7];
+                for (int i = 0; i < 7; i++) q[i] = HFr::zero();
+                q[4] = acoef * bcoef;
+                if (c_k) { uint32_t v[4] = {av, bv, 0, 0}; q[5] = -cc; B.gate(v, q); }
+                else { B.lc_as_gates(cl, cc, true, &cv, &ccoef); uint32_t v[4] = {av, bv, cv, 0}; q[2] = -ccoef; B.gate(v, q); }
+            }
+        }
+        out->stats.push_back({std::to_string(idx), (uint64_t)(out->gates.size() - g0)});
+        out->num_hints++;
+    }
+    return true;
+}
+
+std::string analyse_json(const R1cs &r, const Transpiled &t) {
+    std::string s = "{\"num_inputs\":" + std::to_string(r.num_inputs) + ",\"num_aux\":" + std::to_string(r.num_aux) +
+                    ",\"num_variables\":" + std::to_string(r.num_variables) + ",\"num_constraints\":" + std::to_string(r.constraints.size()) +
+                    ",\"num_nontrivial_constraints\":" + std::to_string(t.stats.size()) + ",\"num_gates\":" + std::to_string(t.gates.size()) +
+                    ",\"num_hints\":" + std::to_string(t.num_hints);
+    if (!t.stats.empty()) {
+        s += ",\"constraint_stats\":[";
+        for (size_t i = 0; i < t.stats.size(); i++) {
+            if (i) s += ",";
+            s += "{\"name\":\"" + t.stats[i].name + "\",\"num_gates\":" + std::to_string(t.stats[i].num_gates) + "}";
+        }
+        s += "]";
+    }
+    return s + "}";
+}
+
+}  // namespace plk
+
+// ------------------------------------------------------------------------------ C ABI
+using namespace plk;
+
+extern "C" int32_t plk_circuit_load(const uint8_t *r1cs, uint64_t r1cs_len, int32_t r1cs_is_json,
+                                    const uint8_t *witness, uint64_t witness_len, int32_t witness_is_json, plk_circuit **out) {
+    if (!r1cs || !out) { set_error("plk_circuit_load: bad argument"); return PLK_ERR_ARG; }
+    *out = nullptr;
+    plk_circuit *c = new plk_circuit();
+    bool ok = r1cs_is_json ? parse_r1cs_json(r1cs, r1cs_len, &c->r1cs) : parse_r1cs_bin(r1cs, r1cs_len, &c->r1cs);
+    if (ok && witness) {
+        ok = witness_is_json ? parse_witness_json(witness, witness_len, &c->witness) : parse_wtns_bin(witness, witness_len, &c->witness);
+        c->has_witness = ok;
+        if (ok && c->witness.size() < c->r1cs.num_variables) { set_error("witness shorter than the number of variables"); ok = false; }
+    }
+    if (!ok) { delete c; return PLK_ERR_FORMAT; }
+    *out = c;
+    return PLK_OK;
+}
+
+extern "C" void plk_circuit_free(plk_circuit *c) { delete c; }
+
+extern "C" int32_t plk_circuit_analyse(const plk_circuit *c, char *out_json, uint64_t cap) {
+    if (!c || !out_json) { set_error("plk_circuit_analyse: bad argument"); return PLK_ERR_ARG; }
+    Transpiled t;
+    if (!transpile(c->r1cs, nullptr, &t)) return PLK_ERR_UNSAT;
+    std::string s = analyse_json(c->r1cs, t);
+    if (s.size() + 1 > cap) { set_error("plk_circuit_analyse: buffer too small"); return PLK_ERR_ARG; }
+    memcpy(out_json, s.c_str(), s.size() + 1);
+    return PLK_OK;
+}

@@ -1,0 +1,69 @@
+// Host-side circuit pipeline: circom R1CS / witness loaders, CircomCircuit::synthesize into the
+// R1CS -> width-4 PLONK gate transpiler, and the gate list the setup / prover consume.
+// Mirrors (reference file:line):
+//   R1CS, CircomCircuit            src/circom_circuit.rs:33-47
+//   synthesize                     src/circom_circuit.rs:74-133
+//   load_r1cs / json / bin         src/reader.rs:178-241 ; src/r1cs_file.rs:44-154
+//   load_witness_*                 src/reader.rs:92-175
+//   transpile (TranspilerWrapper)  src/transpile.rs:18-139 -> bellman_ce adaptor::Transpiler (absent;
+//                                  gate shapes per SURVEY.md A.3; long-LC chains from recollection)
+//   analyse                        src/plonk.rs:72-93
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "hostmath.h"
+
+namespace plk {
+
+using host::HFr;
+
+struct LcTerm { uint32_t wire; HFr coeff; };
+typedef std::vector<LcTerm> Lc;
+struct Constraint { Lc a, b, c; };
+
+struct R1cs {
+    uint64_t num_inputs = 0, num_aux = 0, num_variables = 0;
+    std::vector<Constraint> constraints;
+};
+
+// variable ids: 0 = dummy (value 0); w in [1, num_variables) = circom wire w (Input(w) for
+// w < num_inputs, Aux(w - num_inputs + AUX_OFFSET) otherwise, src/circom_circuit.rs:107-113);
+// ids >= num_variables are temporaries allocated by the transpiler.
+struct Gate {
+    uint32_t v[4];
+    HFr q[7];           // q_a q_b q_c q_d q_m q_const q_d_next
+};
+
+struct ConstraintStat { std::string name; uint64_t num_gates; };
+
+struct Transpiled {
+    std::vector<Gate> gates;            // without the public-input gates
+    std::vector<HFr> values;            // per variable id; empty when there is no witness
+    std::vector<ConstraintStat> stats;
+    uint64_t num_hints = 0;
+    uint64_t num_vars = 0;              // including temporaries
+};
+
+}  // namespace plk
+
+struct plk_circuit {
+    plk::R1cs r1cs;
+    std::vector<plk::HFr> witness;
+    bool has_witness = false;
+};
+
+namespace plk {
+
+// parsers: return false and set_error() on malformed input
+bool parse_r1cs_bin(const uint8_t *data, size_t len, R1cs *out);
+bool parse_r1cs_json(const uint8_t *data, size_t len, R1cs *out);
+bool parse_wtns_bin(const uint8_t *data, size_t len, std::vector<HFr> *out);
+bool parse_witness_json(const uint8_t *data, size_t len, std::vector<HFr> *out);
+bool fr_from_decimal(const std::string &s, HFr *out);
+
+// transpile; `witness` may be null.  Returns false (set_error) on an unsatisfiable constant constraint.
+bool transpile(const R1cs &r, const std::vector<HFr> *witness, Transpiled *out);
+std::string analyse_json(const R1cs &r, const Transpiled &t);
+
+}  // namespace plk

@@ -65,6 +65,8 @@ struct plk_ctx {
     plk::DevBuf srs_own;
     // MSM scratch
     plk::DevBuf msm_a, msm_b, msm_c, msm_d, msm_e;
+    plk::DevBuf prove_ws;                    // workspace of the prover rounds (grows only)
+    plk::DevBuf poly_tmp, poly_tmp2;         // scan block totals / evaluation partials
     plk::DevBuf stage;                       // host<->device staging for the host-pointer API
     void *pinned = nullptr;                  // small pinned host buffer for results
     size_t pinned_cap = 0;

@@ -21,6 +21,7 @@
 //   * No MFMA: this is 256-bit modular integer arithmetic, bound by v_mad_u64_u32 issue.
 #include "ctx.h"
 #include "ntt.h"
+#include "poly.h"
 
 namespace plk {
 
@@ -196,6 +197,14 @@ Fr cached_inverse(plk_ctx *ctx, const Fr &g) {
     Fr gi = inv(g);
     ctx->inv_cache[key] = gi;
     return gi;
+}
+
+int32_t fill_pow_table_into(plk_ctx *ctx, const Fr &base, Fr *buf, PowTable *out, hipStream_t s) {
+    hipLaunchKernelGGL(fill_pow_table, dim3(2 * POW_TAB / 256), dim3(256), 0, s, buf, buf + POW_TAB, base);
+    PLK_HIP(hipGetLastError());
+    out->lo = buf;
+    out->hi = buf + POW_TAB;
+    return PLK_OK;
 }
 
 int32_t ntt_init_tables(plk_ctx *ctx) {

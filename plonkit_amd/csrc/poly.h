@@ -1,0 +1,53 @@
+#pragma once
+#include "ctx.h"
+namespace plk {
+
+struct PermArgs {
+    Fr *num, *den;
+    const Fr *w[4], *sigma[4];
+    Fr beta, gamma, beta_k[4];          // beta_k[j] = beta * k_j
+    uint32_t n, log_n;
+    PowTable tw;
+};
+
+struct QuotientArgs {
+    Fr *out;
+    const Fr *w[4], *z, *q[7], *sigma[4], *pi, *l0;
+    Fr beta, gamma, alpha, alpha2, coset, beta_k[4], zh_inv[4];
+    uint32_t m, log_m;                  // m = 4N
+    PowTable tw;
+};
+
+constexpr uint32_t LINCOMB_MAX = 14;
+struct LinCombArgs {
+    Fr *out;
+    const Fr *p[LINCOMB_MAX];
+    Fr s[LINCOMB_MAX];
+    uint32_t unit[LINCOMB_MAX];         // 1: coefficient is one (skip the multiply)
+    uint32_t count, n;
+};
+
+constexpr uint32_t EVAL_MAX = 12;
+struct EvalArgs {
+    const Fr *poly[EVAL_MAX];
+    uint32_t len[EVAL_MAX];
+    PowTable pt[EVAL_MAX];              // power table of the evaluation point
+    uint32_t count, max_blocks;
+    Fr *partials;
+};
+
+int32_t gather(Fr *out, const Fr *values, const uint32_t *vars, uint32_t n, hipStream_t s);
+int32_t sigma_from_index(Fr *out, const uint32_t *packed, uint32_t n, uint32_t log_n, const PowTable &tw, const Fr k[4], hipStream_t s);
+int32_t perm_terms(const PermArgs &a, hipStream_t s);
+int32_t mul3(Fr *out, const Fr *a, const Fr *b, const Fr &sc, uint32_t n, hipStream_t s);
+// out may alias in.  mult: product scan, else sum; reverse: suffix; exclusive: shifted by one
+int32_t scan(plk_ctx *ctx, Fr *out, const Fr *in, uint32_t n, bool mult, bool reverse, bool exclusive, hipStream_t s);
+int32_t quotient(const QuotientArgs &a, hipStream_t s);
+int32_t lincomb(const LinCombArgs &a, hipStream_t s);
+int32_t mul_powers(Fr *out, const Fr *in, const PowTable &t, uint32_t shift, uint32_t n, hipStream_t s);
+int32_t div_finish(Fr *q, const Fr *suffix, const PowTable &zinv, uint32_t n, hipStream_t s);
+int32_t eval_batch(plk_ctx *ctx, EvalArgs a, Fr *results_dev, hipStream_t s);
+// fills a caller-provided 2*POW_TAB table with powers of `base`
+int32_t fill_pow_table_into(plk_ctx *ctx, const Fr &base, Fr *buf, PowTable *out, hipStream_t s);
+
+}  // namespace plk

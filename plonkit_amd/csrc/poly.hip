@@ -1,0 +1,300 @@
+// Element-wise / scan / reduction kernels over Fr vectors for the device-resident prover rounds.
+// They replace the Polynomial<Fr, _> helpers bellman_ce's prover calls between FFTs and multiexps
+// (grand product, batch inversion, quotient assembly, Horner evaluation, linear combinations,
+// division by (x - z)); reference call site: prove_by_steps, src/plonk.rs:152-159.  Formulas are
+// those of SURVEY.md Appendix A.4.  All of them are HBM-streaming passes (32 B per operand per
+// point) with a handful of modular multiplies per point.
+#include "ctx.h"
+#include "poly.h"
+
+namespace plk {
+
+constexpr int PT = 256;                 // threads per block
+constexpr int EPT = 8;                  // elements per thread in scans / reductions
+constexpr int BLOCK_ELEMS = PT * EPT;
+
+__device__ __forceinline__ Fr pow2l_(const PowTable &t, uint32_t e) {
+    return mul(load_fp(t.lo + (e & (POW_TAB - 1))), load_fp(t.hi + (e >> POW_SPLIT)));
+}
+
+// ------------------------------------------------------------------ gather / permutation
+__global__ void __launch_bounds__(PT) k_gather(Fr *out, const Fr *values, const uint32_t *vars, uint32_t n) {
+    uint32_t i = blockIdx.x * PT + threadIdx.x;
+    if (i < n) store_fp(out + i, load_fp(values + vars[i]));
+}
+
+// sigma_j(omega^i) = k_col * omega^row with (col,row) packed as col<<30 | row
+__global__ void __launch_bounds__(PT) k_sigma_from_index(Fr *out, const uint32_t *packed, uint32_t n, uint32_t log_n, PowTable tw, Fr k0, Fr k1, Fr k2, Fr k3) {
+    uint32_t i = blockIdx.x * PT + threadIdx.x;
+    if (i >= n) return;
+    uint32_t p = packed[i], col = p >> 30, row = p & 0x3fffffffu;
+    Fr w = pow2l_(tw, row << (MAX_LOG_N - log_n));
+    Fr k = col == 0 ? k0 : (col == 1 ? k1 : (col == 2 ? k2 : k3));
+    store_fp(out + i, col == 0 ? w : mul(w, k));
+}
+
+// num_i = prod_j (w_j + beta*k_j*omega^i + gamma) ; den_i = prod_j (w_j + beta*sigma_j + gamma)
+__global__ void __launch_bounds__(PT) k_perm_terms(PermArgs a) {
+    uint32_t i = blockIdx.x * PT + threadIdx.x;
+    if (i >= a.n) return;
+    Fr wi = pow2l_(a.tw, i << (MAX_LOG_N - a.log_n));
+    Fr num = Fr::one(), den = Fr::one();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        Fr w = add(load_fp(a.w[j] + i), a.gamma);
+        num = mul(num, add(w, mul(wi, a.beta_k[j])));
+        den = mul(den, add(w, mul(load_fp(a.sigma[j] + i), a.beta)));
+    }
+    store_fp(a.num + i, num);
+    store_fp(a.den + i, den);
+}
+
+// z_i = A_i * C_i * inv_total
+__global__ void __launch_bounds__(PT) k_mul3(Fr *out, const Fr *a, const Fr *b, Fr s, uint32_t n) {
+    uint32_t i = blockIdx.x * PT + threadIdx.x;
+    if (i < n) store_fp(out + i, mul(mul(load_fp(a + i), load_fp(b + i)), s));
+}
+
+// -------------------------------------------------------------------------------- scans
+template <bool MULT> __device__ __forceinline__ Fr op(const Fr &a, const Fr &b) { return MULT ? mul(a, b) : add(a, b); }
+template <bool MULT> __device__ __forceinline__ Fr ident() { return MULT ? Fr::one() : Fr::zero(); }
+
+// phase 1: per-block scan of BLOCK_ELEMS elements; writes the block-local (inclusive or exclusive)
+// result and the block total.  reverse: logical index i maps to memory n-1-i (suffix scans).
+template <bool MULT>
+__global__ void __launch_bounds__(PT) k_scan_local(Fr *out, const Fr *in, Fr *block_tot, uint32_t n, int reverse, int exclusive) {
+    __shared__ __attribute__((aligned(16))) Fr sh[PT];
+    const uint32_t tid = threadIdx.x, base = blockIdx.x * BLOCK_ELEMS + tid * EPT;
+    Fr v[EPT];
+    Fr run = ident<MULT>();
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        uint32_t i = base + k;
+        Fr x = i < n ? load_fp(in + (reverse ? n - 1 - i : i)) : ident<MULT>();
+        if (exclusive) { v[k] = run; run = op<MULT>(run, x); }
+        else { run = op<MULT>(run, x); v[k] = run; }
+    }
+    sh[tid] = run;
+    __syncthreads();
+    Fr incl = run;
+    for (int off = 1; off < PT; off <<= 1) {
+        Fr o = (int)tid >= off ? sh[tid - off] : ident<MULT>();
+        __syncthreads();
+        if ((int)tid >= off) { incl = op<MULT>(o, incl); sh[tid] = incl; }
+        __syncthreads();
+    }
+    Fr excl = tid ? sh[tid - 1] : ident<MULT>();
+    if (tid == PT - 1) store_fp(block_tot + blockIdx.x, incl);
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        uint32_t i = base + k;
+        if (i < n) store_fp(out + (reverse ? n - 1 - i : i), op<MULT>(excl, v[k]));
+    }
+}
+
+// phase 2: exclusive scan of the block totals by one workgroup (in place)
+template <bool MULT>
+__global__ void __launch_bounds__(1024) k_scan_totals(Fr *tot, uint32_t nb) {
+    __shared__ __attribute__((aligned(16))) Fr sh[1024];
+    const uint32_t tid = threadIdx.x, per = (nb + 1023) / 1024;
+    uint32_t lo = tid * per, hi = lo + per < nb ? lo + per : nb;
+    if (lo > nb) lo = nb;
+    Fr run = ident<MULT>();
+    for (uint32_t i = lo; i < hi; i++) run = op<MULT>(run, load_fp(tot + i));
+    sh[tid] = run;
+    __syncthreads();
+    Fr incl = run;
+    for (int off = 1; off < 1024; off <<= 1) {
+        Fr o = (int)tid >= off ? sh[tid - off] : ident<MULT>();
+        __syncthreads();
+        if ((int)tid >= off) { incl = op<MULT>(o, incl); sh[tid] = incl; }
+        __syncthreads();
+    }
+    Fr acc = tid ? sh[tid - 1] : ident<MULT>();
+    for (uint32_t i = lo; i < hi; i++) { Fr x = load_fp(tot + i); store_fp(tot + i, acc); acc = op<MULT>(acc, x); }
+}
+
+// phase 3: fold the block prefix in
+template <bool MULT>
+__global__ void __launch_bounds__(PT) k_scan_apply(Fr *out, const Fr *tot, uint32_t n, int reverse) {
+    if (blockIdx.x == 0) return;
+    Fr pre = load_fp(tot + blockIdx.x);
+    const uint32_t base = blockIdx.x * BLOCK_ELEMS + threadIdx.x * EPT;
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        uint32_t i = base + k;
+        if (i < n) { Fr *p = out + (reverse ? n - 1 - i : i); store_fp(p, op<MULT>(pre, load_fp(p))); }
+    }
+}
+
+int32_t scan(plk_ctx *ctx, Fr *out, const Fr *in, uint32_t n, bool mult, bool reverse, bool exclusive, hipStream_t s) {
+    uint32_t nb = (n + BLOCK_ELEMS - 1) / BLOCK_ELEMS;
+    PLK_TRY(ctx->poly_tmp.reserve((size_t)nb * sizeof(Fr)));
+    Fr *tot = ctx->poly_tmp.as<Fr>();
+    if (mult) {
+        hipLaunchKernelGGL(k_scan_local<true>, dim3(nb), dim3(PT), 0, s, out, in, tot, n, reverse ? 1 : 0, exclusive ? 1 : 0);
+        if (nb > 1) {
+            hipLaunchKernelGGL(k_scan_totals<true>, dim3(1), dim3(1024), 0, s, tot, nb);
+            hipLaunchKernelGGL(k_scan_apply<true>, dim3(nb), dim3(PT), 0, s, out, (const Fr *)tot, n, reverse ? 1 : 0);
+        }
+    } else {
+        hipLaunchKernelGGL(k_scan_local<false>, dim3(nb), dim3(PT), 0, s, out, in, tot, n, reverse ? 1 : 0, exclusive ? 1 : 0);
+        if (nb > 1) {
+            hipLaunchKernelGGL(k_scan_totals<false>, dim3(1), dim3(1024), 0, s, tot, nb);
+            hipLaunchKernelGGL(k_scan_apply<false>, dim3(nb), dim3(PT), 0, s, out, (const Fr *)tot, n, reverse ? 1 : 0);
+        }
+    }
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+
+// ----------------------------------------------------------------------------- quotient
+// t(x_i) = [gate + PI + alpha*(perm) + alpha^2*L0*(z-1)] / Z_H(x_i) on the coset 7*<omega_4N>
+__global__ void __launch_bounds__(PT) k_quotient(QuotientArgs a) {
+    uint32_t i = blockIdx.x * PT + threadIdx.x;
+    if (i >= a.m) return;
+    const uint32_t nxt = (i + 4) & (a.m - 1);                    // f(omega*x) on the 4N domain
+    Fr w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = load_fp(a.w[j] + i);
+    Fr g = load_fp(a.q[5] + i);
+#pragma unroll
+    for (int j = 0; j < 4; j++) g = add(g, mul(load_fp(a.q[j] + i), w[j]));
+    g = add(g, mul(load_fp(a.q[4] + i), mul(w[0], w[1])));
+    g = add(g, mul(load_fp(a.q[6] + i), load_fp(a.w[3] + nxt)));
+    g = add(g, load_fp(a.pi + i));
+    Fr x = mul(pow2l_(a.tw, i << (MAX_LOG_N - a.log_m)), a.coset);
+    Fr z = load_fp(a.z + i);
+    Fr pa = z, pb = load_fp(a.z + nxt);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        Fr wg = add(w[j], a.gamma);
+        pa = mul(pa, add(wg, mul(x, a.beta_k[j])));
+        pb = mul(pb, add(wg, mul(load_fp(a.sigma[j] + i), a.beta)));
+    }
+    Fr t = add(g, mul(a.alpha, sub(pa, pb)));
+    t = add(t, mul(a.alpha2, mul(load_fp(a.l0 + i), sub(z, Fr::one()))));
+    store_fp(a.out + i, mul(t, a.zh_inv[i & 3]));
+}
+
+// ------------------------------------------------------------------- linear combinations
+__global__ void __launch_bounds__(PT) k_lincomb(LinCombArgs a) {
+    uint32_t i = blockIdx.x * PT + threadIdx.x;
+    if (i >= a.n) return;
+    Fr acc = Fr::zero();
+    for (uint32_t k = 0; k < a.count; k++) {
+        Fr v = load_fp(a.p[k] + i);
+        acc = add(acc, a.unit[k] ? v : mul(v, a.s[k]));
+    }
+    store_fp(a.out + i, acc);
+}
+
+// out_i = in_i * base^(i + shift)     (base given by its power table)
+__global__ void __launch_bounds__(PT) k_mul_powers(Fr *out, const Fr *in, PowTable t, uint32_t shift, uint32_t n) {
+    uint32_t i = blockIdx.x * PT + threadIdx.x;
+    if (i < n) store_fp(out + i, mul(load_fp(in + i), pow2l_(t, i + shift)));
+}
+
+// q_k = S_{k+1} * zinv^(k+1), q_{n-1} = 0       (synthetic division by (x - z), see prover.hip)
+__global__ void __launch_bounds__(PT) k_div_finish(Fr *q, const Fr *suffix, PowTable zinv, uint32_t n) {
+    uint32_t k = blockIdx.x * PT + threadIdx.x;
+    if (k >= n) return;
+    if (k == n - 1) { store_fp(q + k, Fr::zero()); return; }
+    store_fp(q + k, mul(load_fp(suffix + k + 1), pow2l_(zinv, k + 1)));
+}
+
+// ------------------------------------------------------------------------- evaluation
+// partial[b] = sum over the block's BLOCK_ELEMS coefficients c_i * x^i
+__global__ void __launch_bounds__(PT) k_eval_partial(EvalArgs a) {
+    __shared__ __attribute__((aligned(16))) Fr sh[PT];
+    const uint32_t e = blockIdx.y, tid = threadIdx.x;
+    const uint32_t n = a.len[e];
+    const uint32_t start = blockIdx.x * BLOCK_ELEMS + tid * EPT;
+    Fr acc = Fr::zero();
+    if (start < n) {
+        const Fr *c = a.poly[e];
+        Fr x = load_fp(a.pt[e].lo + 1);
+        uint32_t hi = start + EPT < n ? start + EPT : n;
+        for (int i = (int)hi - 1; i >= (int)start; i--) acc = add(mul(acc, x), load_fp(c + i));
+        acc = mul(acc, pow2l_(a.pt[e], start));
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (int off = PT / 2; off > 0; off >>= 1) {
+        if ((int)tid < off) { acc = add(acc, sh[tid + off]); sh[tid] = acc; }
+        __syncthreads();
+    }
+    if (tid == 0) store_fp(a.partials + (size_t)e * a.max_blocks + blockIdx.x, acc);
+}
+
+__global__ void __launch_bounds__(PT) k_eval_finish(EvalArgs a, Fr *results) {
+    __shared__ __attribute__((aligned(16))) Fr sh[PT];
+    const uint32_t e = blockIdx.x, tid = threadIdx.x;
+    const uint32_t nb = (a.len[e] + BLOCK_ELEMS - 1) / BLOCK_ELEMS;
+    Fr acc = Fr::zero();
+    for (uint32_t b = tid; b < nb; b += PT) acc = add(acc, load_fp(a.partials + (size_t)e * a.max_blocks + b));
+    sh[tid] = acc;
+    __syncthreads();
+    for (int off = PT / 2; off > 0; off >>= 1) {
+        if ((int)tid < off) { acc = add(acc, sh[tid + off]); sh[tid] = acc; }
+        __syncthreads();
+    }
+    if (tid == 0) store_fp(results + e, acc);
+}
+
+// ------------------------------------------------------------------------- launchers
+static inline dim3 grid1(uint32_t n) { return dim3((n + PT - 1) / PT); }
+
+int32_t gather(Fr *out, const Fr *values, const uint32_t *vars, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather, grid1(n), dim3(PT), 0, s, out, values, vars, n);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+int32_t sigma_from_index(Fr *out, const uint32_t *packed, uint32_t n, uint32_t log_n, const PowTable &tw, const Fr k[4], hipStream_t s) {
+    hipLaunchKernelGGL(k_sigma_from_index, grid1(n), dim3(PT), 0, s, out, packed, n, log_n, tw, k[0], k[1], k[2], k[3]);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+int32_t perm_terms(const PermArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_perm_terms, grid1(a.n), dim3(PT), 0, s, a);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+int32_t mul3(Fr *out, const Fr *a, const Fr *b, const Fr &sc, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_mul3, grid1(n), dim3(PT), 0, s, out, a, b, sc, n);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+int32_t quotient(const QuotientArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_quotient, grid1(a.m), dim3(PT), 0, s, a);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+int32_t lincomb(const LinCombArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_lincomb, grid1(a.n), dim3(PT), 0, s, a);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+int32_t mul_powers(Fr *out, const Fr *in, const PowTable &t, uint32_t shift, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_mul_powers, grid1(n), dim3(PT), 0, s, out, in, t, shift, n);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+int32_t div_finish(Fr *q, const Fr *suffix, const PowTable &zinv, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_div_finish, grid1(n), dim3(PT), 0, s, q, suffix, zinv, n);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+int32_t eval_batch(plk_ctx *ctx, EvalArgs a, Fr *results_dev, hipStream_t s) {
+    uint32_t maxlen = 0;
+    for (uint32_t e = 0; e < a.count; e++) if (a.len[e] > maxlen) maxlen = a.len[e];
+    a.max_blocks = (maxlen + BLOCK_ELEMS - 1) / BLOCK_ELEMS;
+    PLK_TRY(ctx->poly_tmp2.reserve((size_t)a.max_blocks * a.count * sizeof(Fr)));
+    a.partials = ctx->poly_tmp2.as<Fr>();
+    hipLaunchKernelGGL(k_eval_partial, dim3(a.max_blocks, a.count), dim3(PT), 0, s, a);
+    hipLaunchKernelGGL(k_eval_finish, dim3(a.count), dim3(PT), 0, s, a, results_dev);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+
+}  // namespace plk

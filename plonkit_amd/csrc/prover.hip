@@ -1,0 +1,413 @@
+// Setup polynomials, verification key and the five prover rounds — device resident.
+//
+// Mirrors (reference file:line):
+//   SetupForProver::prepare_setup_for_prover  src/plonk.rs:97-119   -> plk_setup_prepare
+//   make_verification_key + vk.write          src/plonk.rs:122-124 ; src/bin/main.rs:501-502 -> plk_setup_write_vk
+//   SetupForProver::prove("keccak"), monomial key = prove_by_steps  src/plonk.rs:132-159 -> plk_prove
+//   Proof::write                              src/bin/main.rs:407-408 (layout SURVEY.md A.1)
+// The protocol (bellman_ce better_cs prover, source absent) is the one recovered in SURVEY.md
+// Appendix A.3/A.4 and pinned byte-for-byte by test/circuits/simple/{vk,proof}.bin.
+// Everything O(N) runs on the GPU (ntt.hip, msm.hip, poly.hip); the host keeps the transcript,
+// a few dozen scalars per round and the circuit synthesis.
+#include "ctx.h"
+#include "ntt.h"
+#include "msm.h"
+#include "poly.h"
+#include "circuit.h"
+#include "keccak.h"
+#include <chrono>
+#include <cstring>
+
+namespace plk {
+using namespace host;
+
+static const uint64_t NON_RESIDUES[4] = {1, 5, 7, 10};     // k_j (vk.bin stores 5, 7, 10)
+
+static inline Fr to_dev(const HFr &h) { Fr f; memcpy(f.l, h.l, 32); return f; }
+static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static HFr host_omega(uint32_t log_n) {
+    Fr w = ntt_omega(log_n);
+    HFr h; memcpy(h.l, w.l, 32); return h;
+}
+
+// KZG commitment of N coefficients resident on the device
+static int32_t commit(plk_ctx *ctx, const Fr *coef, uint64_t n, HAffine *out) {
+    PLK_TRY(msm_enqueue(ctx, coef, n, 0, ctx->stream));
+    HJac j;
+    PLK_TRY(msm_finish(ctx, ctx->stream, &j));
+    *out = jac_to_affine(j);
+    return PLK_OK;
+}
+
+struct Arena {
+    DevBuf *buf; size_t off = 0;
+    template <class T> T *take(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        T *p = reinterpret_cast<T *>((char *)buf->p + off);
+        off += bytes;
+        return p;
+    }
+};
+
+}  // namespace plk
+
+struct plk_setup {
+    uint64_t n = 0, N = 0, num_inputs = 0, n_real = 0, num_vars = 0, num_gates = 0;
+    uint32_t log_n = 0;
+    plk::DevBuf store;                     // one allocation holding everything below
+    plk::Fr *sel_coef[7] = {nullptr}, *sig_coef[4] = {nullptr}, *sig_vals[4] = {nullptr};
+    uint32_t *gate_vars[4] = {nullptr};
+    std::vector<plk::Gate> gates_host;     // input gates + transpiled gates (satisfiability check)
+};
+
+using namespace plk;
+
+extern "C" {
+
+uint64_t plk_setup_domain_size(const plk_setup *s) { return s ? s->N : 0; }
+void plk_setup_free(plk_setup *s) { if (s) { s->store.release(); delete s; } }
+
+int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
+    if (!ctx || !c || !out) { set_error("plk_setup_prepare: bad argument"); return PLK_ERR_ARG; }
+    *out = nullptr;
+    PLK_HIP(hipSetDevice(ctx->device));
+    Transpiled T;
+    if (!transpile(c->r1cs, nullptr, &T)) return PLK_ERR_UNSAT;
+    plk_setup *S = new plk_setup();
+    S->num_inputs = c->r1cs.num_inputs - 1;
+    S->num_gates = T.gates.size();
+    S->n_real = S->num_inputs + T.gates.size();
+    S->num_vars = T.num_vars;
+    uint64_t N = 1; uint32_t log_n = 0;
+    while (N < S->n_real + 1) { N <<= 1; log_n++; }
+    if (log_n + 2 > MAX_LOG_N) { delete S; set_error("setup power of two is not in the correct range"); return PLK_ERR_SIZE; }   // src/plonk.rs:109-112
+    S->N = N; S->n = N - 1; S->log_n = log_n;
+    S->gates_host.reserve(S->n_real);
+    for (uint64_t i = 1; i <= S->num_inputs; i++) {                 // one gate per public input, first rows, q_a = -1
+        Gate g; g.v[0] = (uint32_t)i; g.v[1] = g.v[2] = g.v[3] = 0;
+        for (int k = 0; k < 7; k++) g.q[k] = HFr::zero();
+        g.q[0] = -HFr::one();
+        S->gates_host.push_back(g);
+    }
+    S->gates_host.insert(S->gates_host.end(), T.gates.begin(), T.gates.end());
+    const std::vector<Gate> &rows = S->gates_host;
+
+    Arena A{&S->store};
+    size_t total = 15 * ((N * sizeof(Fr) + 255) & ~(size_t)255) + 4 * ((N * 4 + 255) & ~(size_t)255);
+    int32_t rc = S->store.reserve(total);
+    if (rc != PLK_OK) { delete S; return rc; }
+    for (int k = 0; k < 7; k++) S->sel_coef[k] = A.take<Fr>(N);
+    for (int j = 0; j < 4; j++) S->sig_coef[j] = A.take<Fr>(N);
+    for (int j = 0; j < 4; j++) S->sig_vals[j] = A.take<Fr>(N);
+    for (int j = 0; j < 4; j++) S->gate_vars[j] = A.take<uint32_t>(N);
+
+    hipStream_t st = ctx->stream;
+    auto fail = [&](int32_t code) { plk_setup_free(S); return code; };
+    // selectors: values on rows 0..n_real-1, zero elsewhere -> iNTT(N)
+    {
+        std::vector<HFr> col(N);
+        for (int k = 0; k < 7; k++) {
+            for (uint64_t r = 0; r < N; r++) col[r] = r < rows.size() ? rows[r].q[k] : HFr::zero();
+            if (hipMemcpyAsync(S->sel_coef[k], col.data(), N * sizeof(Fr), hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D selector", __FILE__, __LINE__));
+            if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
+            if ((rc = ntt_dev(ctx, S->sel_coef[k], log_n, true, nullptr, st)) != PLK_OK) return fail(rc);
+        }
+    }
+    // wire -> variable index table and the permutation (rotate-left over each variable's occurrences)
+    {
+        std::vector<uint32_t> vars(N);
+        for (int j = 0; j < 4; j++) {
+            for (uint64_t r = 0; r < N; r++) vars[r] = r < rows.size() ? rows[r].v[j] : 0;
+            if (hipMemcpyAsync(S->gate_vars[j], vars.data(), N * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D vars", __FILE__, __LINE__));
+            if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
+        }
+        std::vector<uint32_t> cnt(T.num_vars + 1, 0);
+        for (const Gate &g : rows) for (int j = 0; j < 4; j++) if (g.v[j]) cnt[g.v[j] + 1]++;
+        for (size_t v = 1; v < cnt.size(); v++) cnt[v] += cnt[v - 1];              // cnt[v] = start of v's list
+        std::vector<uint32_t> pos(cnt.back()), fill(cnt.begin(), cnt.end() - 1);
+        for (uint64_t r = 0; r < rows.size(); r++)
+            for (int j = 0; j < 4; j++) { uint32_t v = rows[r].v[j]; if (v) pos[fill[v]++] = ((uint32_t)j << 30) | (uint32_t)r; }
+        std::vector<uint32_t> sig((size_t)4 * N);
+        for (int j = 0; j < 4; j++) for (uint64_t r = 0; r < N; r++) sig[(size_t)j * N + r] = ((uint32_t)j << 30) | (uint32_t)r;
+        for (size_t v = 1; v < T.num_vars; v++) {
+            uint32_t b = cnt[v], e = cnt[v + 1];
+            if (e - b < 2) continue;
+            for (uint32_t k = b; k < e; k++) {
+                uint32_t here = pos[k], next = pos[k + 1 < e ? k + 1 : b];
+                sig[(size_t)(here >> 30) * N + (here & 0x3fffffffu)] = next;
+            }
+        }
+        Fr kk[4];
+        for (int j = 0; j < 4; j++) kk[j] = from_u64<FrParams>(NON_RESIDUES[j]);
+        // reuse sig_coef[j] as the upload buffer for the packed indices (N u32 <= N Fr)
+        for (int j = 0; j < 4; j++) {
+            uint32_t *tmp = reinterpret_cast<uint32_t *>(S->sig_coef[j]);
+            if (hipMemcpyAsync(tmp, sig.data() + (size_t)j * N, N * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D sigma", __FILE__, __LINE__));
+            if ((rc = sigma_from_index(S->sig_vals[j], tmp, (uint32_t)N, log_n, ctx->tw_fwd, kk, st)) != PLK_OK) return fail(rc);
+            if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
+            if (hipMemcpyAsync(S->sig_coef[j], S->sig_vals[j], N * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "D2D sigma", __FILE__, __LINE__));
+            if ((rc = ntt_dev(ctx, S->sig_coef[j], log_n, true, nullptr, st)) != PLK_OK) return fail(rc);
+        }
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
+    *out = S;
+    return PLK_OK;
+}
+
+static void put_u64(std::vector<uint8_t> &b, uint64_t v) { for (int i = 7; i >= 0; i--) b.push_back((uint8_t)(v >> (8 * i))); }
+static void put_g1(std::vector<uint8_t> &b, const HAffine &p) { uint8_t t[64]; g1_to_bytes(p, t); b.insert(b.end(), t, t + 64); }
+static void put_fr(std::vector<uint8_t> &b, const HFr &v) { uint8_t t[32]; v.to_be_bytes(t); b.insert(b.end(), t, t + 32); }
+
+int32_t plk_setup_write_vk(plk_ctx *ctx, const plk_setup *s, const uint8_t g2_bytes[256], uint8_t *out, uint64_t cap, uint64_t *len) {
+    if (!ctx || !s || !g2_bytes || !out || !len) { set_error("plk_setup_write_vk: bad argument"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    std::vector<uint8_t> b;
+    put_u64(b, s->n); put_u64(b, s->num_inputs);
+    HAffine p;
+    put_u64(b, 6);
+    for (int k = 0; k < 6; k++) { PLK_TRY(commit(ctx, s->sel_coef[k], s->N, &p)); put_g1(b, p); }
+    put_u64(b, 1);
+    PLK_TRY(commit(ctx, s->sel_coef[6], s->N, &p)); put_g1(b, p);
+    put_u64(b, 4);
+    for (int j = 0; j < 4; j++) { PLK_TRY(commit(ctx, s->sig_coef[j], s->N, &p)); put_g1(b, p); }
+    put_u64(b, 3);
+    for (int j = 1; j < 4; j++) put_fr(b, HFr::from_u64(NON_RESIDUES[j]));
+    b.insert(b.end(), g2_bytes, g2_bytes + 256);
+    *len = b.size();
+    if (b.size() > cap) { set_error("plk_setup_write_vk: buffer too small"); return PLK_ERR_ARG; }
+    memcpy(out, b.data(), b.size());
+    return PLK_OK;
+}
+
+int32_t plk_prove_timings(const plk_ctx *ctx, double *out_ms, uint32_t cap, uint32_t *count) {
+    if (!ctx || !count) { set_error("plk_prove_timings: bad argument"); return PLK_ERR_ARG; }
+    *count = (uint32_t)ctx->timings.size();
+    for (uint32_t i = 0; i < *count && i < cap && out_ms; i++) out_ms[i] = ctx->timings[i];
+    return PLK_OK;
+}
+
+// is_satisfied_using_one_shot_check (src/plonk.rs:128,137): every gate equation holds on the witness
+static bool gates_satisfied(const plk_setup *S, const std::vector<HFr> &val, const std::vector<Gate> &rows) {
+    for (size_t r = 0; r < rows.size(); r++) {
+        const Gate &g = rows[r];
+        const HFr &a = val[g.v[0]], &b = val[g.v[1]], &c = val[g.v[2]], &d = val[g.v[3]];
+        HFr acc = g.q[0] * a + g.q[1] * b + g.q[2] * c + g.q[3] * d + g.q[4] * a * b + g.q[5];
+        if (!g.q[6].is_zero()) acc = acc + g.q[6] * (r + 1 < rows.size() ? val[rows[r + 1].v[3]] : HFr::zero());
+        if (r < S->num_inputs) acc = acc + a;
+        if (!acc.is_zero()) return false;
+    }
+    return true;
+}
+
+int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_t *proof_out, uint64_t cap, uint64_t *len) {
+    if (!ctx || !S || !c || !proof_out || !len) { set_error("plk_prove: bad argument"); return PLK_ERR_ARG; }
+    if (!c->has_witness) { set_error("plk_prove: circuit has no witness"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    if (!ctx->srs || ctx->srs_n < S->N) { set_error("SRS too small for this circuit"); return PLK_ERR_SRS; }
+    ctx->timings.clear();
+    double t_prev = now_ms();
+    auto lap = [&]() { double t = now_ms(); ctx->timings.push_back(t - t_prev); t_prev = t; };
+    hipStream_t st = ctx->stream;
+
+    // ---- synthesis with the witness (host)
+    Transpiled T;
+    if (!transpile(c->r1cs, &c->witness, &T)) return PLK_ERR_UNSAT;
+    if (T.gates.size() != S->num_gates || T.num_vars != S->num_vars) { set_error("plk_prove: circuit does not match the prepared setup"); return PLK_ERR_ARG; }
+    if (!gates_satisfied(S, T.values, S->gates_host)) { set_error("must satisfy: witness does not satisfy the circuit"); return PLK_ERR_UNSAT; }
+    lap();                                                                    // [0] synthesis + check
+
+    const uint64_t N = S->N, M = 4 * N;
+    const uint32_t log_n = S->log_n, log_m = log_n + 2;
+    const size_t NB = (N * sizeof(Fr) + 255) & ~(size_t)255, MB = (M * sizeof(Fr) + 255) & ~(size_t)255;
+    const size_t TB = ((size_t)2 * POW_TAB * sizeof(Fr) + 255) & ~(size_t)255;
+    const size_t VB = (T.num_vars * sizeof(Fr) + 255) & ~(size_t)255;
+    PLK_TRY(ctx->prove_ws.reserve(VB + 16 * NB + 20 * MB + 4 * TB + 4096));
+    Arena A{&ctx->prove_ws};
+    Fr *d_values = A.take<Fr>(T.num_vars);
+    Fr *w_vals[4], *w_coef[4];
+    for (int j = 0; j < 4; j++) { w_vals[j] = A.take<Fr>(N); w_coef[j] = A.take<Fr>(N); }
+    Fr *z_coef = A.take<Fr>(N), *t1 = A.take<Fr>(N), *t2 = A.take<Fr>(N), *t3 = A.take<Fr>(N);
+    Fr *r_poly = A.take<Fr>(N), *agg = A.take<Fr>(N), *pi_coef = A.take<Fr>(N), *l0_coef = A.take<Fr>(N);
+    Fr *ext[18];
+    for (int k = 0; k < 18; k++) ext[k] = A.take<Fr>(M);
+    Fr *t_ext = A.take<Fr>(M);
+    Fr *tab[4];
+    for (int k = 0; k < 4; k++) tab[k] = A.take<Fr>(2 * POW_TAB);
+    Fr *d_results = A.take<Fr>(16);
+
+    PLK_HIP(hipMemcpyAsync(d_values, T.values.data(), T.num_vars * sizeof(Fr), hipMemcpyHostToDevice, st));
+    std::vector<HFr> inputs(T.values.begin() + 1, T.values.begin() + 1 + S->num_inputs);
+
+    // ---- round 1: wire polynomials, 4 x iNTT(N), 4 x MSM(N)
+    for (int j = 0; j < 4; j++) {
+        PLK_TRY(gather(w_vals[j], d_values, S->gate_vars[j], (uint32_t)N, st));
+        PLK_HIP(hipMemcpyAsync(w_coef[j], w_vals[j], N * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        PLK_TRY(ntt_dev(ctx, w_coef[j], log_n, true, nullptr, st));
+    }
+    HAffine wire_c[4];
+    for (int j = 0; j < 4; j++) PLK_TRY(commit(ctx, w_coef[j], N, &wire_c[j]));
+    RollingKeccak tr;
+    for (const HFr &x : inputs) tr.absorb_fr(x);
+    for (int j = 0; j < 4; j++) tr.absorb_g1(wire_c[j]);
+    const HFr beta = tr.challenge(), gamma = tr.challenge();
+    lap();                                                                    // [1] round 1
+
+    // ---- round 2: grand product z  (z_i = prod_{k<i} num_k / den_k, no per-element inversion:
+    //      z_i = A_i * C_i / C_0 with A = exclusive prefix product of num, C = inclusive suffix product of den)
+    HFr kk[4];
+    for (int j = 0; j < 4; j++) kk[j] = HFr::from_u64(NON_RESIDUES[j]);
+    {
+        PermArgs pa;
+        pa.num = t1; pa.den = t2;
+        for (int j = 0; j < 4; j++) { pa.w[j] = w_vals[j]; pa.sigma[j] = S->sig_vals[j]; pa.beta_k[j] = to_dev(beta * kk[j]); }
+        pa.beta = to_dev(beta); pa.gamma = to_dev(gamma); pa.n = (uint32_t)N; pa.log_n = log_n; pa.tw = ctx->tw_fwd;
+        PLK_TRY(perm_terms(pa, st));
+        PLK_TRY(scan(ctx, t1, t1, (uint32_t)N, true, false, true, st));
+        PLK_TRY(scan(ctx, t2, t2, (uint32_t)N, true, true, false, st));
+        HFr total;
+        PLK_HIP(hipMemcpyAsync(total.l, t2, sizeof(Fr), hipMemcpyDeviceToHost, st));
+        PLK_HIP(hipStreamSynchronize(st));
+        if (total.is_zero()) { set_error("grand product denominator vanished (probability ~2^-230)"); return PLK_ERR_UNSAT; }
+        PLK_TRY(mul3(z_coef, t1, t2, to_dev(total.inv()), (uint32_t)N, st));
+        PLK_TRY(ntt_dev(ctx, z_coef, log_n, true, nullptr, st));
+    }
+    HAffine z_c;
+    PLK_TRY(commit(ctx, z_coef, N, &z_c));
+    tr.absorb_g1(z_c);
+    const HFr alpha = tr.challenge();
+    lap();                                                                    // [2] round 2
+
+    // ---- round 3: quotient on the coset 7*<omega_4N>: 18 x LDE, fused point-wise kernel, coset iNTT(4N)
+    const HFr coset = HFr::from_u64(7);
+    {
+        for (int j = 0; j < 4; j++) PLK_TRY(lde4_dev(ctx, w_coef[j], log_n, ext[j], st));
+        PLK_TRY(lde4_dev(ctx, z_coef, log_n, ext[4], st));
+        for (int k = 0; k < 7; k++) PLK_TRY(lde4_dev(ctx, S->sel_coef[k], log_n, ext[5 + k], st));
+        for (int j = 0; j < 4; j++) PLK_TRY(lde4_dev(ctx, S->sig_coef[j], log_n, ext[12 + j], st));
+        PLK_HIP(hipMemsetAsync(pi_coef, 0, N * sizeof(Fr), st));
+        if (!inputs.empty()) PLK_HIP(hipMemcpyAsync(pi_coef, inputs.data(), inputs.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
+        PLK_TRY(ntt_dev(ctx, pi_coef, log_n, true, nullptr, st));
+        PLK_TRY(lde4_dev(ctx, pi_coef, log_n, ext[16], st));
+        HFr one = HFr::one();
+        PLK_HIP(hipMemsetAsync(l0_coef, 0, N * sizeof(Fr), st));
+        PLK_HIP(hipMemcpyAsync(l0_coef, one.l, sizeof(Fr), hipMemcpyHostToDevice, st));
+        PLK_TRY(ntt_dev(ctx, l0_coef, log_n, true, nullptr, st));
+        PLK_TRY(lde4_dev(ctx, l0_coef, log_n, ext[17], st));
+
+        QuotientArgs qa;
+        qa.out = t_ext;
+        for (int j = 0; j < 4; j++) { qa.w[j] = ext[j]; qa.sigma[j] = ext[12 + j]; qa.beta_k[j] = to_dev(beta * kk[j]); }
+        qa.z = ext[4];
+        for (int k = 0; k < 7; k++) qa.q[k] = ext[5 + k];
+        qa.pi = ext[16]; qa.l0 = ext[17];
+        qa.beta = to_dev(beta); qa.gamma = to_dev(gamma); qa.alpha = to_dev(alpha); qa.alpha2 = to_dev(alpha * alpha);
+        qa.coset = to_dev(coset);
+        HFr gN = coset.pow_u64(N), iota = host_omega(log_m).pow_u64(N), ip = HFr::one();
+        for (int k = 0; k < 4; k++) { qa.zh_inv[k] = to_dev((gN * ip - HFr::one()).inv()); ip = ip * iota; }
+        qa.m = (uint32_t)M; qa.log_m = log_m; qa.tw = ctx->tw_fwd;
+        PLK_TRY(quotient(qa, st));
+        Fr g = to_dev(coset);
+        PLK_TRY(ntt_dev(ctx, t_ext, log_m, true, &g, st));
+    }
+    HAffine t_c[4];
+    for (int k = 0; k < 4; k++) PLK_TRY(commit(ctx, t_ext + (size_t)k * N, N, &t_c[k]));
+    for (int k = 0; k < 4; k++) tr.absorb_g1(t_c[k]);
+    const HFr z = tr.challenge();
+    lap();                                                                    // [3] round 3
+
+    // ---- round 4: evaluations at z and z*omega, linearisation
+    const HFr omega = host_omega(log_n), zw = z * omega, zN = z.pow_u64(N);
+    if (z.is_zero()) { set_error("challenge z = 0"); return PLK_ERR_UNSAT; }
+    PowTable pt_z, pt_zinv, pt_zw, pt_zwinv;
+    PLK_TRY(fill_pow_table_into(ctx, to_dev(z), tab[0], &pt_z, st));
+    PLK_TRY(fill_pow_table_into(ctx, to_dev(z.inv()), tab[1], &pt_zinv, st));
+    PLK_TRY(fill_pow_table_into(ctx, to_dev(zw), tab[2], &pt_zw, st));
+    PLK_TRY(fill_pow_table_into(ctx, to_dev(zw.inv()), tab[3], &pt_zwinv, st));
+    HFr ev[11];
+    {
+        EvalArgs ea{};
+        const Fr *polys[10] = {w_coef[0], w_coef[1], w_coef[2], w_coef[3], w_coef[3], S->sig_coef[0], S->sig_coef[1], S->sig_coef[2], t_ext, z_coef};
+        for (int e = 0; e < 10; e++) { ea.poly[e] = polys[e]; ea.len[e] = (uint32_t)(e == 8 ? M : N); ea.pt[e] = (e == 4 || e == 9) ? pt_zw : pt_z; }
+        ea.count = 10;
+        PLK_TRY(eval_batch(ctx, ea, d_results, st));
+        PLK_HIP(hipMemcpyAsync(ev, d_results, 10 * sizeof(Fr), hipMemcpyDeviceToHost, st));
+        PLK_HIP(hipStreamSynchronize(st));
+    }
+    const HFr *wz = ev, w3zw = ev[4], *sz = ev + 5, tz = ev[8], zzw = ev[9];
+    HFr l0z = (zN - HFr::one()) * (HFr::from_u64(N) * (z - HFr::one())).inv();
+    HFr fz = alpha;
+    for (int j = 0; j < 4; j++) fz = fz * (wz[j] + beta * kk[j] * z + gamma);
+    fz = fz + alpha * alpha * l0z;
+    HFr fs = alpha * beta * zzw;
+    for (int j = 0; j < 3; j++) fs = fs * (wz[j] + beta * sz[j] + gamma);
+    {
+        LinCombArgs la{};
+        la.out = r_poly; la.n = (uint32_t)N; la.count = 9;
+        const Fr *ps[9] = {S->sel_coef[5], S->sel_coef[0], S->sel_coef[1], S->sel_coef[2], S->sel_coef[3], S->sel_coef[4], S->sel_coef[6], z_coef, S->sig_coef[3]};
+        HFr sc[9] = {HFr::one(), wz[0], wz[1], wz[2], wz[3], wz[0] * wz[1], w3zw, fz, -fs};
+        for (int k = 0; k < 9; k++) { la.p[k] = ps[k]; la.s[k] = to_dev(sc[k]); la.unit[k] = (k == 0); }
+        PLK_TRY(lincomb(la, st));
+        EvalArgs ea{};
+        ea.poly[0] = r_poly; ea.len[0] = (uint32_t)N; ea.pt[0] = pt_z; ea.count = 1;
+        PLK_TRY(eval_batch(ctx, ea, d_results, st));
+        PLK_HIP(hipMemcpyAsync(&ev[10], d_results, sizeof(Fr), hipMemcpyDeviceToHost, st));
+        PLK_HIP(hipStreamSynchronize(st));
+    }
+    const HFr rz = ev[10];
+    for (int j = 0; j < 4; j++) tr.absorb_fr(wz[j]);
+    tr.absorb_fr(w3zw);
+    for (int j = 0; j < 3; j++) tr.absorb_fr(sz[j]);
+    tr.absorb_fr(tz); tr.absorb_fr(rz); tr.absorb_fr(zzw);
+    const HFr v = tr.challenge();
+    lap();                                                                    // [4] round 4
+
+    // ---- round 5: opening proofs W_z, W_zw by synthetic division (suffix sums of p_j z^j, times z^-(k+1))
+    HAffine Wz, Wzw;
+    {
+        LinCombArgs la{};
+        la.out = agg; la.n = (uint32_t)N; la.count = 12;
+        HFr vp[11]; vp[0] = HFr::one();
+        for (int k = 1; k <= 10; k++) vp[k] = vp[k - 1] * v;
+        const Fr *ps[12] = {t_ext, t_ext + N, t_ext + 2 * N, t_ext + 3 * N, r_poly, w_coef[0], w_coef[1], w_coef[2], w_coef[3],
+                            S->sig_coef[0], S->sig_coef[1], S->sig_coef[2]};
+        HFr sc[12] = {HFr::one(), zN, zN * zN, zN * zN * zN, vp[1], vp[2], vp[3], vp[4], vp[5], vp[6], vp[7], vp[8]};
+        for (int k = 0; k < 12; k++) { la.p[k] = ps[k]; la.s[k] = to_dev(sc[k]); la.unit[k] = (k == 0); }
+        PLK_TRY(lincomb(la, st));
+        PLK_TRY(mul_powers(t1, agg, pt_z, 0, (uint32_t)N, st));
+        PLK_TRY(scan(ctx, t1, t1, (uint32_t)N, false, true, false, st));
+        PLK_TRY(div_finish(t2, t1, pt_zinv, (uint32_t)N, st));
+        PLK_TRY(commit(ctx, t2, N, &Wz));
+
+        LinCombArgs lb{};
+        lb.out = agg; lb.n = (uint32_t)N; lb.count = 2;
+        lb.p[0] = z_coef; lb.s[0] = to_dev(vp[9]); lb.p[1] = w_coef[3]; lb.s[1] = to_dev(vp[10]);
+        PLK_TRY(lincomb(lb, st));
+        PLK_TRY(mul_powers(t1, agg, pt_zw, 0, (uint32_t)N, st));
+        PLK_TRY(scan(ctx, t1, t1, (uint32_t)N, false, true, false, st));
+        PLK_TRY(div_finish(t3, t1, pt_zwinv, (uint32_t)N, st));
+        PLK_TRY(commit(ctx, t3, N, &Wzw));
+    }
+    lap();                                                                    // [5] round 5
+
+    // ---- Proof::write
+    std::vector<uint8_t> b;
+    put_u64(b, S->n);
+    put_u64(b, inputs.size());
+    for (const HFr &x : inputs) put_fr(b, x);
+    put_u64(b, 4); for (int j = 0; j < 4; j++) put_g1(b, wire_c[j]);
+    put_g1(b, z_c);
+    put_u64(b, 4); for (int k = 0; k < 4; k++) put_g1(b, t_c[k]);
+    put_u64(b, 4); for (int j = 0; j < 4; j++) put_fr(b, wz[j]);
+    put_u64(b, 1); put_fr(b, w3zw);
+    put_fr(b, zzw); put_fr(b, tz); put_fr(b, rz);
+    put_u64(b, 3); for (int j = 0; j < 3; j++) put_fr(b, sz[j]);
+    put_g1(b, Wz); put_g1(b, Wzw);
+    *len = b.size();
+    if (b.size() > cap) { set_error("plk_prove: proof buffer too small"); return PLK_ERR_ARG; }
+    memcpy(proof_out, b.data(), b.size());
+    lap();                                                                    // [6] serialise
+    return PLK_OK;
+}
+
+}  // extern "C"

@@ -95,7 +95,7 @@ void plk_destroy(plk_ctx *ctx) {
     for (void *p : ctx->coset_allocs) (void)hipFree(p);
     ctx->tables.release(); ctx->ntt_scratch.release(); ctx->srs_own.release();
     ctx->msm_a.release(); ctx->msm_b.release(); ctx->msm_c.release(); ctx->msm_d.release(); ctx->msm_e.release();
-    ctx->stage.release();
+    ctx->stage.release(); ctx->poly_tmp.release(); ctx->poly_tmp2.release(); ctx->prove_ws.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ev[0]) { (void)hipEventDestroy(ctx->ev[0]); (void)hipEventDestroy(ctx->ev[1]); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -1,0 +1,134 @@
+"""CPU-only checks of the product's C ABI library: it loads, exports every symbol the header declares,
+and its host half (loaders, transpiler/analyse, transcript, serialisation) agrees with the reference's
+golden data and with the oracle.  No compute entry point is called (there is no GPU here)."""
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import plonkit_amd as pa
+from oracle import oracle_lib as ol, plonk_oracle as po
+from oracle.oracle_lib import R_MOD
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "plonkit_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(plk_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 40
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pa.lib_path()]).decode()
+    exported = set(re.findall(r" T (plk_[a-z0-9_]+)", out))
+    missing = [s for s in declared if s not in exported]
+    assert not missing, missing
+    L = pa.lib()
+    for s in declared:
+        getattr(L, s)
+    assert b"gfx950" in L.plk_version()
+
+
+def test_no_cpu_fallback_without_gpu():
+    if pa.have_gpu():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(pa.PlkError) as e:
+        pa.Context(0)
+    assert e.value.code == 4 and "no CPU fallback" in str(e.value)
+
+
+def test_keccak_and_transcript_match_oracle():
+    for msg in (b"", b"abc", b"x" * 135, b"y" * 136, b"z" * 1000):
+        assert pa.keccak256(msg) == ol.keccak256(msg)
+    t, o = pa.Transcript(), po.Transcript()
+    G = ol.g1_generator()
+    for v in (35, 0, R_MOD - 1):
+        t.absorb_fr(ol.fr_mont(v)); o.absorb_fr(v)
+    t.absorb_g1(G); o.absorb_g1(G)
+    t.absorb_g1(np.zeros(8, dtype=np.uint64)); o.absorb_g1(np.zeros(8, dtype=np.uint64))
+    for _ in range(3):
+        assert ol.fr_ints(t.challenge())[0] == o.challenge()
+
+
+def test_point_and_scalar_encoding(golden_dir, golden_crs):
+    raw = open(os.path.join(golden_dir, "setup_2pow10.key"), "rb").read()
+    for i in (0, 1, 777, 1023):
+        b = raw[8 + 64 * i: 8 + 64 * i + 64]
+        p = pa.g1_from_bytes(b)
+        assert np.array_equal(p, golden_crs.g1[i]) and pa.g1_to_bytes(p) == b
+    inf = b"\x40" + b"\x00" * 63
+    assert not pa.g1_from_bytes(inf).any() and pa.g1_to_bytes(np.zeros(8, dtype=np.uint64)) == inf
+    with pytest.raises(pa.PlkError):
+        pa.g1_from_bytes((1).to_bytes(32, "big") + (3).to_bytes(32, "big"))     # not on the curve
+    with pytest.raises(pa.PlkError):
+        pa.fr_from_bytes(R_MOD.to_bytes(32, "big"))
+    assert pa.fr_to_bytes(pa.fr_from_bytes((R_MOD - 5).to_bytes(32, "big"))) == (R_MOD - 5).to_bytes(32, "big")
+    # partial sums: (P) + (P) + (-2P) = O through the host combiner used by the multi-GPU path
+    P = golden_crs.g1[5]
+    jac = lambda a: np.concatenate([a, ol.fq_mont(1)]) if a.any() else np.concatenate([ol.fq_mont(1), ol.fq_mont(1), np.zeros(4, dtype=np.uint64)])
+    parts = np.stack([jac(P), jac(P), jac(ol.g1_neg(ol.g1_mul(P, 2)))])
+    assert not pa.g1_sum_jacobian(parts).any()
+    assert np.array_equal(pa.g1_sum_jacobian(parts[:2]), ol.g1_mul(P, 2))
+
+
+def test_analyse_golden_string(golden_dir):
+    c = pa.Circuit.from_files(os.path.join(golden_dir, "circuit.r1cs.json"))
+    assert c.analyse() == open(os.path.join(golden_dir, "analyse.json")).read()
+    c2 = pa.Circuit.from_files(os.path.join(golden_dir, "circuit.r1cs.json"), os.path.join(golden_dir, "witness.json"))
+    assert c2.analyse() == c.analyse()
+
+
+def test_r1cs_bin_loader_matches_oracle_and_rejects_bad_input(golden_dir):
+    data = open(os.path.join(golden_dir, "r1cs_sample.bin"), "rb").read()
+    c = pa.Circuit(data, False)
+    assert c.analyse() == po.analyse(po.load_r1cs_bin(data))
+    for bad in (b"r2cs" + data[4:], data[:100], data[:4] + struct.pack("<I", 2) + data[8:]):
+        with pytest.raises(pa.PlkError) as e:
+            pa.Circuit(bad, False)
+        assert e.value.code == 6
+    hdr_bad = bytearray(data)
+    hdr_bad[28] ^= 1                                    # prime byte
+    with pytest.raises(pa.PlkError):
+        pa.Circuit(bytes(hdr_bad), False)
+
+
+def test_witness_loaders(golden_dir):
+    r = open(os.path.join(golden_dir, "circuit.r1cs.json"), "rb").read()
+    w = [1, 35, 3, 9]
+    wt = (b"wtns" + struct.pack("<II", 2, 2) + struct.pack("<IQ", 1, 40) + struct.pack("<I", 32) + po.BN254_PRIME_LE
+          + struct.pack("<I", len(w)) + struct.pack("<IQ", 2, 32 * len(w)) + b"".join(v.to_bytes(32, "little") for v in w))
+    pa.Circuit(r, True, wt, False)
+    pa.Circuit(r, True, b'["1","35","3","9"]', True)
+    with pytest.raises(pa.PlkError):
+        pa.Circuit(r, True, wt[:-1], False)
+    with pytest.raises(pa.PlkError):
+        pa.Circuit(r, True, b'["1","35"]', True)        # shorter than nVars
+    with pytest.raises(pa.PlkError):
+        pa.Circuit(r, True, b"wtnx" + wt[4:], False)
+
+
+def test_transpiler_matches_oracle_on_synthetic_shapes():
+    """same gate counts per constraint as the oracle transpiler, incl. the unpinned shapes"""
+    import json
+    rng = po.Xoshiro256ss(3)
+    cons = []
+    nvars = 24
+    for k in range(40):
+        def lc(nterms, with_const):
+            d = {}
+            for _ in range(nterms):
+                d[str(1 + rng.next() % (nvars - 1))] = str(rng.fr())
+            if with_const:
+                d["0"] = str(rng.fr())
+            return d
+        shape = k % 8
+        a = lc([1, 1, 3, 6, 0, 1, 1, 9][shape], shape in (2, 6))
+        b = lc([1, 1, 1, 2, 2, 0, 1, 5][shape], shape == 3)
+        c = lc([1, 3, 2, 7, 3, 5, 0, 1][shape], shape in (1, 4))
+        if shape == 6:
+            b = {list(a.keys())[0]: "5"} if list(a.keys())[0] != "0" else b
+        cons.append([a, b, c])
+    obj = {"nPubInputs": 2, "nOutputs": 1, "nVars": nvars, "constraints": cons}
+    c = pa.Circuit(json.dumps(obj).encode(), True)
+    assert c.analyse() == po.analyse(po.load_r1cs_json(obj))
