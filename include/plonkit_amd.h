@@ -117,6 +117,12 @@ typedef struct plk_circuit plk_circuit;
 int32_t plk_circuit_load(const uint8_t *r1cs, uint64_t r1cs_len, int32_t r1cs_is_json,
                          const uint8_t *witness, uint64_t witness_len, int32_t witness_is_json,
                          plk_circuit **out);                            /* witness may be NULL    */
+/* synthetic chain circuit of exactly `target_gates` PLONK gates + 1 public input, with witness
+ * (xoshiro256** seed, pinned constraint shapes); bench / test input.    */
+int32_t plk_circuit_synthetic(uint64_t target_gates, uint64_t seed, plk_circuit **out);
+/* what = 0: iden3 .r1cs v1 bytes, 1: .wtns v2 bytes (the reference's own input formats,
+ * src/r1cs_file.rs:100-154, src/reader.rs:124-175); out == NULL only reports the length.            */
+int32_t plk_circuit_export(const plk_circuit *c, int32_t what, uint8_t *out, uint64_t cap, uint64_t *len);
 void plk_circuit_free(plk_circuit *c);
 /* plonk::analyse (src/plonk.rs:72-93): JSON as serde_json::to_string prints it (src/tests.rs:14) */
 int32_t plk_circuit_analyse(const plk_circuit *c, char *out_json, uint64_t cap);

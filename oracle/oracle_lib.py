@@ -49,7 +49,8 @@ def _p(a):
 
 
 def ncpu():
-    return os.cpu_count() or 1
+    """default thread count of the checker (tests); the cpu_baseline leg passes its own (all cores)"""
+    return min(os.cpu_count() or 1, 16)
 
 
 # ----------------------------------------------------------------- int <-> limb conversions

@@ -202,6 +202,23 @@ class Circuit:
                                       ctypes.c_int32(1 if witness_is_json else 0), ctypes.byref(self._h)))
 
     @classmethod
+    def synthetic(cls, target_gates, seed=0x706c6f6e6b6974):
+        """seeded chain circuit with exactly `target_gates` gates and one public input (bench input)"""
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        _check(lib().plk_circuit_synthetic(ctypes.c_uint64(target_gates), ctypes.c_uint64(seed), ctypes.byref(self._h)))
+        return self
+
+    def export(self, what):
+        """what = "r1cs" | "wtns": bytes in the reference's binary formats"""
+        code = {"r1cs": 0, "wtns": 1}[what]
+        n = ctypes.c_uint64(0)
+        _check(lib().plk_circuit_export(self._h, ctypes.c_int32(code), None, ctypes.c_uint64(0), ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(n.value)
+        _check(lib().plk_circuit_export(self._h, ctypes.c_int32(code), buf, ctypes.c_uint64(n.value), ctypes.byref(n)))
+        return buf.raw
+
+    @classmethod
     def from_files(cls, r1cs_path, witness_path=None):
         w = open(witness_path, "rb").read() if witness_path else None
         return cls(open(r1cs_path, "rb").read(), r1cs_path.endswith("json"), w, bool(witness_path) and witness_path.endswith("json"))

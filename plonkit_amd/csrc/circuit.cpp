@@ -422,3 +422,117 @@ extern "C" int32_t plk_circuit_analyse(const plk_circuit *c, char *out_json, uin
     memcpy(out_json, s.c_str(), s.size() + 1);
     return PLK_OK;
 }
+
+// ------------------------------------------------------------------ synthetic R1CS (bench input)
+// a seeded multiplication chain over Fr, witness included, using only
+// constraint shapes whose transpilation is pinned by the golden circuit:
+//   type 1 (1 gate):  (ca*u) * (cb*v) = cc*w                      -> new wire w
+//   type 2 (2 gates): (ca*u) * (cb*v) = k + c1*v + c2*q           -> new wire q
+// plus a final  1*pub = last  linear constraint (1 gate) tying the single public input to the chain.
+// `target_gates` transpiled gates are produced exactly, so that 1 (public input) + target_gates + 1
+// is the domain size: 2^20 - 2 gates give the 2^20 domain of BASELINE.json configs[1].
+namespace plk {
+namespace {
+struct Xoshiro256ss {
+    uint64_t s[4];
+    explicit Xoshiro256ss(uint64_t seed) {
+        for (int i = 0; i < 4; i++) {                                   // splitmix64 seeding
+            seed += 0x9E3779B97F4A7C15ULL;
+            uint64_t z = seed;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            s[i] = z ^ (z >> 31);
+        }
+    }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() {
+        uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    HFr fr() {                                                          // uniform by rejection from 254 bits
+        for (;;) {
+            uint64_t c[4] = {next(), next(), next(), next()};
+            c[3] &= (1ULL << 62) - 1;
+            if (!HFr::geq_p(c)) return HFr::from_canonical(c);
+        }
+    }
+    HFr fr_nonzero() { HFr v = fr(); return v.is_zero() ? HFr::one() : v; }
+};
+}  // namespace
+}  // namespace plk
+
+extern "C" int32_t plk_circuit_synthetic(uint64_t target_gates, uint64_t seed, plk_circuit **out) {
+    if (!out || target_gates < 4) { set_error("plk_circuit_synthetic: bad argument"); return PLK_ERR_ARG; }
+    plk_circuit *c = new plk_circuit();
+    Xoshiro256ss rng(seed);
+    std::vector<HFr> &w = c->witness;
+    w.reserve(target_gates + 8);
+    w.push_back(HFr::one()); w.push_back(HFr::zero()); w.push_back(rng.fr()); w.push_back(rng.fr());
+    std::vector<Constraint> &cons = c->r1cs.constraints;
+    cons.reserve(target_gates);
+    uint64_t gates = 0;
+    const uint64_t body = target_gates - 1;                             // the last gate is the public-input tie
+    while (gates < body) {
+        uint32_t u = (uint32_t)w.size() - 1, v = (uint32_t)w.size() - 2;
+        HFr ca = rng.fr_nonzero(), cb = rng.fr_nonzero();
+        HFr prod = ca * w[u] * cb * w[v];
+        Constraint k;
+        k.a.push_back({u, ca}); k.b.push_back({v, cb});
+        bool two = (cons.size() & 1) && (gates + 2 <= body);
+        if (!two) {
+            HFr cc = rng.fr_nonzero();
+            w.push_back(prod * cc.inv());
+            k.c.push_back({(uint32_t)w.size() - 1, cc});
+            gates += 1;
+        } else {
+            HFr kk = rng.fr(), c1 = rng.fr_nonzero(), c2 = rng.fr_nonzero();
+            w.push_back((prod - kk - c1 * w[v]) * c2.inv());
+            k.c.push_back({0, kk}); k.c.push_back({v, c1}); k.c.push_back({(uint32_t)w.size() - 1, c2});
+            gates += 2;
+        }
+        cons.push_back(std::move(k));
+    }
+    w[1] = w.back();
+    Constraint tie;
+    tie.a.push_back({1, HFr::one()}); tie.b.push_back({0, HFr::one()}); tie.c.push_back({(uint32_t)w.size() - 1, HFr::one()});
+    cons.push_back(std::move(tie));
+    c->r1cs.num_inputs = 2;
+    c->r1cs.num_variables = w.size();
+    c->r1cs.num_aux = w.size() - 2;
+    c->has_witness = true;
+    *out = c;
+    return PLK_OK;
+}
+
+// exports the circuit in the reference's own file formats (iden3 .r1cs v1 / .wtns v2), so that the
+// same synthetic input can be fed to a real `plonkit` binary (PLONKIT_REF_BIN)
+extern "C" int32_t plk_circuit_export(const plk_circuit *c, int32_t what, uint8_t *out, uint64_t cap, uint64_t *len) {
+    if (!c || !len) { set_error("plk_circuit_export: bad argument"); return PLK_ERR_ARG; }
+    std::vector<uint8_t> b;
+    auto u32 = [&](uint32_t v) { for (int i = 0; i < 4; i++) b.push_back((uint8_t)(v >> (8 * i))); };
+    auto u64 = [&](uint64_t v) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(v >> (8 * i))); };
+    auto fr = [&](const HFr &v) { uint64_t cc[4]; v.to_canonical(cc); for (int i = 0; i < 4; i++) u64(cc[i]); };
+    if (what == 0) {                                                    // .r1cs
+        b.insert(b.end(), {'r', '1', 'c', 's'}); u32(1); u32(3);
+        u32(1); u64(64); u32(32); b.insert(b.end(), BN254_R_LE, BN254_R_LE + 32);
+        u32((uint32_t)c->r1cs.num_variables); u32(0); u32((uint32_t)c->r1cs.num_inputs - 1); u32((uint32_t)c->r1cs.num_aux);
+        u64(c->r1cs.num_variables); u32((uint32_t)c->r1cs.constraints.size());
+        uint64_t sz = 0;
+        for (const Constraint &k : c->r1cs.constraints) sz += 12 + 36 * (k.a.size() + k.b.size() + k.c.size());
+        u32(2); u64(sz);
+        for (const Constraint &k : c->r1cs.constraints)
+            for (const Lc *lc : {&k.a, &k.b, &k.c}) { u32((uint32_t)lc->size()); for (const LcTerm &t : *lc) { u32(t.wire); fr(t.coeff); } }
+        u32(3); u64(8 * c->r1cs.num_variables);
+        for (uint64_t i = 0; i < c->r1cs.num_variables; i++) u64(i);
+    } else {                                                            // .wtns
+        if (!c->has_witness) { set_error("plk_circuit_export: no witness"); return PLK_ERR_ARG; }
+        b.insert(b.end(), {'w', 't', 'n', 's'}); u32(2); u32(2);
+        u32(1); u64(40); u32(32); b.insert(b.end(), BN254_R_LE, BN254_R_LE + 32); u32((uint32_t)c->witness.size());
+        u32(2); u64(32 * c->witness.size());
+        for (const HFr &v : c->witness) fr(v);
+    }
+    *len = b.size();
+    if (out) { if (b.size() > cap) { set_error("plk_circuit_export: buffer too small"); return PLK_ERR_ARG; } memcpy(out, b.data(), b.size()); }
+    return PLK_OK;
+}

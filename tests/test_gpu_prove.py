@@ -105,3 +105,19 @@ def test_crs42_generation_matches_golden_key(ctx, golden_crs):
     assert np.array_equal(ctx.srs_download(0, 1024), golden_crs.g1)
     ctx.srs_generate(100, 1000, 42)
     assert np.array_equal(ctx.srs_download(0, 24), golden_crs.g1[1000:1024])
+
+
+def test_native_synthetic_circuit_prove_matches_oracle(ctx):
+    """the bench's native circuit generator, exported in the reference's own .r1cs/.wtns formats,
+    proves to the same bytes as the oracle run on those files"""
+    import plonkit_amd as pa
+    circ = pa.Circuit.synthetic((1 << 12) - 2)
+    r1cs, wit = po.load_r1cs_bin(circ.export("r1cs")), po.parse_wtns(circ.export("wtns"))
+    srs = ol.crs42(1 << 12)
+    ctx.srs_upload(srs)
+    setup = pa.SetupForProver(ctx, circ)
+    assert setup.domain_size == 1 << 12
+    S = po.setup(r1cs)
+    crs = po.Crs(srs, b"\x01" * 256)
+    assert setup.verification_key_bytes(b"\x01" * 256) == po.write_vk(po.make_verification_key(S, crs))
+    assert setup.prove(circ) == po.write_proof(po.prove(r1cs, wit, crs, S))
