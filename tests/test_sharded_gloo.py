@@ -1,0 +1,62 @@
+"""world_size-2 `gloo` test (CPU) of the multi-GPU commitment's exchange step: each rank holds the
+Jacobian partial sum of its SRS shard (here computed by the oracle, standing in for the rank's GPU),
+ranks all_gather the 96-byte partials and add them on the host with the product's plk_g1_sum_jacobian.
+The result must equal the single-process MSM over the whole SRS.  (On the GPU box the same
+combine_partials runs over RCCL; the driver launches it through bench.py --gpus N.)"""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle_lib as ol
+from oracle.oracle_lib import R_MOD
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_per_rank, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from plonkit_amd.sharded import combine_partials
+        srs = ol.crs42(world * n_per_rank, threads=2)
+        rng = np.random.default_rng(99)                       # same scalars on every rank
+        s = rng.integers(0, 1 << 62, size=(world * n_per_rank, 4), dtype=np.uint64)
+        s[:, 3] &= np.uint64((1 << 60) - 1)
+        lo, hi = rank * n_per_rank, (rank + 1) * n_per_rank
+        partial = ol.msm_jacobian(srs[lo:hi], s[lo:hi], threads=2)    # this rank's shard
+        total = combine_partials(partial, dist, None)
+        full = ol.msm(srs, s, threads=2)
+        q.put((rank, bool(np.array_equal(total, full))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_commit_combination_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 300, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_combine_single_process_is_affine_conversion():
+    from plonkit_amd.sharded import combine_partials
+    srs = ol.crs42(64, threads=1)
+    s = ol.fr_vec([(i * 7919 + 13) % R_MOD for i in range(64)])
+    assert np.array_equal(combine_partials(ol.msm_jacobian(srs, s, threads=1)), ol.msm(srs, s, threads=1))
