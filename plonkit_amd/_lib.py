@@ -272,7 +272,7 @@ class SetupForProver:
         arr = (ctypes.c_double * 16)()
         cnt = ctypes.c_uint32(0)
         _check(lib().plk_prove_timings(self.ctx._h, arr, ctypes.c_uint32(16), ctypes.byref(cnt)))
-        names = ["synthesis+check", "round1", "round2", "round3", "round4", "round5", "serialise"]
+        names = ["witness", "round1", "round2", "round3", "round4", "round5", "serialise"]
         return {names[i] if i < len(names) else str(i): arr[i] for i in range(cnt.value)}
 
     def close(self):

@@ -246,9 +246,14 @@ struct Builder {
     bool have_values;
     const HFr zero = HFr::zero(), one = HFr::one(), minus_one = -HFr::one();
 
-    uint32_t alloc(const HFr &v) {
+    // a temporary is always a linear form over earlier variables: record it, so that a later proof
+    // can recompute the temporaries from a fresh witness without re-running the transpiler
+    uint32_t alloc(const HFr &v, const Term *terms, size_t n_terms, const HFr &constant) {
         uint32_t id = (uint32_t)t->num_vars++;
         if (have_values) t->values.push_back(v);
+        WitnessOp op; op.first = (uint32_t)t->op_terms.size(); op.count = (uint32_t)n_terms; op.constant = constant;
+        for (size_t i = 0; i < n_terms; i++) t->op_terms.push_back({terms[i].var, terms[i].coeff});
+        t->ops.push_back(op);
         return id;
     }
     HFr val(uint32_t v) const { return have_values ? t->values[v] : HFr::zero(); }
@@ -279,7 +284,7 @@ struct Builder {
     void lc_as_gates(std::vector<Term> lc, HFr free, bool collapse, uint32_t *var_out, HFr *coeff_out) {
         if (lc.size() == 1 && free.is_zero() && collapse) { *var_out = lc[0].var; *coeff_out = lc[0].coeff; return; }
         uint32_t fin = 0;
-        if (collapse) { fin = alloc(eval(lc, free)); lc.push_back({fin, minus_one}); }
+        if (collapse) { fin = alloc(eval(lc, free), lc.data(), lc.size(), free); lc.push_back({fin, minus_one}); }
         if (lc.size() <= 4) {
             uint32_t v[4] = {0, 0, 0, 0}; HFr q[7];
             for (int i = 0; i < 7; i++) q[i] = zero;
@@ -293,14 +298,15 @@ struct Builder {
             HFr s = free;
             for (int i = 0; i < 4; i++, pos++) { v[i] = lc[pos].var; q[i] = lc[pos].coeff; if (have_values) s = s + q[i] * val(v[i]); }
             q[5] = free; q[6] = minus_one;
-            uint32_t nxt = alloc(s);
+            uint32_t nxt = alloc(s, lc.data(), 4, free);
             gate(v, q);
             while (lc.size() - pos > 3) {
                 for (int i = 0; i < 7; i++) q[i] = zero;
                 s = val(nxt);
                 for (int i = 0; i < 3; i++, pos++) { v[i] = lc[pos].var; q[i] = lc[pos].coeff; if (have_values) s = s + q[i] * val(v[i]); }
                 v[3] = nxt; q[3] = one; q[6] = minus_one;
-                uint32_t nn = alloc(s);
+                Term chain[4] = {lc[pos - 3], lc[pos - 2], lc[pos - 1], {nxt, one}};
+                uint32_t nn = alloc(s, chain, 4, zero);
                 gate(v, q);
                 nxt = nn;
             }
@@ -318,6 +324,7 @@ struct Builder {
 
 bool transpile(const R1cs &r, const std::vector<HFr> *witness, Transpiled *out) {
     out->gates.clear(); out->values.clear(); out->stats.clear(); out->num_hints = 0;
+    out->ops.clear(); out->op_terms.clear();
     out->num_vars = r.num_variables;
     Builder B{out, witness != nullptr};
     if (witness) {

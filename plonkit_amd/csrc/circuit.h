@@ -37,12 +37,18 @@ struct Gate {
 
 struct ConstraintStat { std::string name; uint64_t num_gates; };
 
+// temporary variable id (num_variables + index) = constant + sum coeff * value[var]
+struct WitnessTerm { uint32_t var; HFr coeff; };
+struct WitnessOp { uint32_t first, count; HFr constant; };
+
 struct Transpiled {
     std::vector<Gate> gates;            // without the public-input gates
     std::vector<HFr> values;            // per variable id; empty when there is no witness
     std::vector<ConstraintStat> stats;
     uint64_t num_hints = 0;
     uint64_t num_vars = 0;              // including temporaries
+    std::vector<WitnessOp> ops;         // one per temporary, in allocation order
+    std::vector<WitnessTerm> op_terms;
 };
 
 }  // namespace plk

@@ -30,11 +30,10 @@ namespace plk {
 constexpr int MSM_THREADS = 256;
 constexpr uint32_t FINE_BITS = 7;                 // 128 buckets per accumulate workgroup
 constexpr uint32_t FINE = 1u << FINE_BITS;
-constexpr uint32_t CHUNK = 4096;                  // entries sorted in LDS at a time
+constexpr uint32_t CHUNK = 8192;                  // entries per accumulate workgroup (sorted in LDS)
 constexpr uint32_t SCALARS_PER_BLOCK = 4096;      // partition kernels
-constexpr uint32_t TASK_MAX = 2 * CHUNK;             // entries per accumulate workgroup
-constexpr uint32_t HEAVY = 96;                    // per-chunk bucket population handled cooperatively
-constexpr uint32_t REDUCE_GROUP = 16;             // buckets per thread in the running-sum kernel
+constexpr uint32_t TASK_MAX = CHUNK;
+constexpr uint32_t HEAVY = 320;                   // per-chunk bucket population handled cooperatively
 
 struct MsmParams {
     uint32_t n;
@@ -159,6 +158,17 @@ __device__ __forceinline__ G1Xyzz shfl_xor_xyzz(const G1Xyzz &v, int mask) {
     }
     return r;
 }
+__device__ __forceinline__ G1Xyzz shfl_down_xyzz(const G1Xyzz &v, int delta) {
+    G1Xyzz r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.x.l[i] = __shfl_down(v.x.l[i], delta);
+        r.y.l[i] = __shfl_down(v.y.l[i], delta);
+        r.zz.l[i] = __shfl_down(v.zz.l[i], delta);
+        r.zzz.l[i] = __shfl_down(v.zzz.l[i], delta);
+    }
+    return r;
+}
 
 __device__ __noinline__ void xyzz_add_noinline(G1Xyzz &a, const G1Xyzz &b) { xyzz_add(a, b); }
 
@@ -174,140 +184,140 @@ __device__ __forceinline__ void accumulate_run(G1Xyzz &acc, const G1Affine *base
     }
 }
 
-// one workgroup per task = (window, coarse bin, slice of <= TASK_MAX entries): 128 buckets, two lanes per bucket
+// One workgroup per task = one slice (<= CHUNK entries) of a (window, coarse bin): 128 buckets.
+//  1. counting sort of the slice by fine bucket inside LDS
+//  2. buckets ranked by population; lane pair p takes the p-th most populated bucket, half a run per
+//     lane, so the lanes of a wave walk runs of (nearly) equal length and short waves retire early
+//  3. buckets hotter than HEAVY are reduced by the whole workgroup with wave64 shuffle trees
+//  4. epilogue on one wave: T = sum_f B_f and S = sum_f (f+1) B_f of the 128 bucket sums by a
+//     shuffle suffix scan — the task leaves only these two points behind
 __global__ void __launch_bounds__(MSM_THREADS) msm_accumulate(const G1Affine *bases, const uint32_t *entries,
                                                                const uint32_t *bin_start, const uint32_t *task_start,
-                                                               G1Xyzz *bucket_parts, MsmParams p) {
+                                                               G1Xyzz *task_out, uint32_t *task_bin, MsmParams p) {
     __shared__ uint32_t sorted[CHUNK];
-    __shared__ uint32_t cnt[FINE], start[FINE + 1], cursor[FINE];
+    __shared__ uint32_t cnt[FINE], start[FINE + 1], cursor[FINE], order[FINE], rank_of[FINE];
+    __shared__ __attribute__((aligned(16))) G1Xyzz B[FINE];
     __shared__ __attribute__((aligned(16))) G1Xyzz wave_part[MSM_THREADS / 64];
     __shared__ uint32_t heavy_list[FINE], heavy_n;
     const uint32_t tid = threadIdx.x, task = blockIdx.x;
     const uint32_t total_bins = p.windows * p.nbins;
     if (task >= task_start[total_bins]) return;
-    // bin = last index with task_start[bin] <= task  (binary search, uniform across the workgroup)
-    uint32_t blo = 0, bhi = total_bins;
+    uint32_t blo = 0, bhi = total_bins;                       // bin = last index with task_start[bin] <= task
     while (bhi - blo > 1) { uint32_t mid = (blo + bhi) >> 1; if (task_start[mid] <= task) blo = mid; else bhi = mid; }
     const uint32_t bin = blo, slice = task - task_start[bin];
     const uint32_t bs = bin_start[bin], be = bin_start[bin + 1];
-    const uint32_t s = bs + slice * TASK_MAX, e = (s + TASK_MAX < be) ? s + TASK_MAX : be;
-    const uint32_t my_bucket = tid >> 1, half = tid & 1;
+    const uint32_t s = bs + slice * CHUNK, e = (s + CHUNK < be) ? s + CHUNK : be, nc = e - s;
+
+    if (tid < FINE) { cnt[tid] = 0; cursor[tid] = 0; }
+    if (tid == 0) heavy_n = 0;
+    __syncthreads();
+    for (uint32_t idx = tid; idx < nc; idx += MSM_THREADS) atomicAdd(&cnt[entries[s + idx] & (FINE - 1)], 1u);
+    __syncthreads();
+    if (tid < 64) {                                           // exclusive scan of 128 counts by one wave
+        uint32_t a = cnt[2 * tid], b = cnt[2 * tid + 1], v = a + b;
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off); if ((int)tid >= off) v += t; }
+        uint32_t ex = v - (a + b);
+        start[2 * tid] = ex; start[2 * tid + 1] = ex + a;
+        if (tid == 63) start[FINE] = v;
+    }
+    if (tid >= 64 && tid < 64 + FINE) {                       // rank by population (descending, ties by index)
+        uint32_t b = tid - 64, c = cnt[b], r = 0;
+        for (uint32_t o = 0; o < FINE; o++) { uint32_t co = cnt[o]; r += (co > c) || (co == c && o < b); }
+        order[r] = b; rank_of[b] = r;
+        if (c > HEAVY) heavy_list[atomicAdd(&heavy_n, 1u)] = b;
+    }
+    __syncthreads();
+    for (uint32_t idx = tid; idx < nc; idx += MSM_THREADS) {
+        uint32_t en = entries[s + idx], f = en & (FINE - 1);
+        sorted[start[f] + atomicAdd(&cursor[f], 1u)] = en;
+    }
+    __syncthreads();
+    const uint32_t pair = tid >> 1, half = tid & 1, my_bucket = order[pair];
     G1Xyzz acc = xyzz_identity();
-
-    for (uint32_t cs = s; cs < e; cs += CHUNK) {
-        const uint32_t nc = (e - cs) < CHUNK ? (e - cs) : CHUNK;
-        if (tid < FINE) { cnt[tid] = 0; cursor[tid] = 0; }
-        if (tid == 0) heavy_n = 0;
-        __syncthreads();
-        uint32_t mine[CHUNK / MSM_THREADS];
-#pragma unroll
-        for (uint32_t q = 0; q < CHUNK / MSM_THREADS; q++) {
-            uint32_t idx = tid + q * MSM_THREADS;
-            mine[q] = idx < nc ? entries[cs + idx] : 0xffffffffu;
-            if (idx < nc) atomicAdd(&cnt[mine[q] & (FINE - 1)], 1u);
+    {
+        uint32_t b0 = start[my_bucket], n_b = cnt[my_bucket];
+        if (n_b <= HEAVY) {
+            uint32_t mid = b0 + (n_b + 1) / 2;
+            accumulate_run(acc, bases, sorted, half ? mid : b0, half ? b0 + n_b : mid);
         }
+    }
+    const uint32_t hn = heavy_n;
+    for (uint32_t hI = 0; hI < hn; hI++) {
+        uint32_t hb = heavy_list[hI], b0 = start[hb], n_b = cnt[hb];
+        uint32_t per = (n_b + MSM_THREADS - 1) / MSM_THREADS;
+        uint32_t lo = b0 + tid * per, hi = lo + per;
+        if (lo > b0 + n_b) lo = b0 + n_b;
+        if (hi > b0 + n_b) hi = b0 + n_b;
+        G1Xyzz part = xyzz_identity();
+        accumulate_run(part, bases, sorted, lo, hi);
+        for (int m = 1; m < 64; m <<= 1) { G1Xyzz o = shfl_xor_xyzz(part, m); xyzz_add_noinline(part, o); }
+        if ((tid & 63) == 0) wave_part[tid >> 6] = part;
         __syncthreads();
-        if (tid < 64) {            // exclusive scan of 128 counts by one wave (2 per lane)
-            uint32_t a = cnt[2 * tid], b = cnt[2 * tid + 1], v = a + b;
-            for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off); if ((int)tid >= off) v += t; }
-            uint32_t ex = v - (a + b);
-            start[2 * tid] = ex; start[2 * tid + 1] = ex + a;
-            if (tid == 63) start[FINE] = v;
-            if (a > HEAVY) heavy_list[atomicAdd(&heavy_n, 1u)] = 2 * tid;
-            if (b > HEAVY) heavy_list[atomicAdd(&heavy_n, 1u)] = 2 * tid + 1;
-        }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t q = 0; q < CHUNK / MSM_THREADS; q++) {
-            if (mine[q] != 0xffffffffu) {
-                uint32_t f = mine[q] & (FINE - 1);
-                sorted[start[f] + atomicAdd(&cursor[f], 1u)] = mine[q];
-            }
-        }
-        __syncthreads();
-        // regular buckets: each lane of the pair takes half of the bucket's run
-        {
-            uint32_t b0 = start[my_bucket], n_b = cnt[my_bucket];
-            if (n_b <= HEAVY) {
-                uint32_t mid = b0 + (n_b + 1) / 2;
-                uint32_t lo = half ? mid : b0, hi = half ? b0 + n_b : mid;
-                accumulate_run(acc, bases, sorted, lo, hi);
-            }
-        }
-        // hot buckets: the whole workgroup slices the run, wave64 xor-tree, then 4 wave partials
-        const uint32_t hn = heavy_n;
-        for (uint32_t hI = 0; hI < hn; hI++) {
-            uint32_t hb = heavy_list[hI], b0 = start[hb], n_b = cnt[hb];
-            uint32_t per = (n_b + MSM_THREADS - 1) / MSM_THREADS;
-            uint32_t lo = b0 + tid * per, hi = lo + per;
-            if (lo > b0 + n_b) lo = b0 + n_b;
-            if (hi > b0 + n_b) hi = b0 + n_b;
-            G1Xyzz part = xyzz_identity();
-            accumulate_run(part, bases, sorted, lo, hi);
-            for (int m = 1; m < 64; m <<= 1) { G1Xyzz o = shfl_xor_xyzz(part, m); xyzz_add_noinline(part, o); }
-            if ((tid & 63) == 0) wave_part[tid >> 6] = part;
-            __syncthreads();
-            if (tid == 2 * hb) {
-                for (int wv = 0; wv < MSM_THREADS / 64; wv++) { G1Xyzz o = wave_part[wv]; xyzz_add_noinline(acc, o); }
-            }
-            __syncthreads();
+        if (tid == 2 * rank_of[hb]) {
+            for (int wv = 0; wv < MSM_THREADS / 64; wv++) { G1Xyzz o = wave_part[wv]; xyzz_add_noinline(acc, o); }
         }
         __syncthreads();
     }
-    G1Xyzz other = shfl_xor_xyzz(acc, 1);
-    if (half == 0) {
-        xyzz_add_noinline(acc, other);
-        store_xyzz(bucket_parts + (size_t)task * FINE + my_bucket, acc);
+    {
+        G1Xyzz other = shfl_xor_xyzz(acc, 1);
+        if (half == 0) { xyzz_add_noinline(acc, other); B[my_bucket] = acc; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        G1Xyzz r1 = B[2 * tid + 1], P = B[2 * tid];
+        xyzz_add_noinline(P, r1);                             // pair total
+        for (int off = 1; off < 64; off <<= 1) {              // inclusive suffix scan of the pair totals
+            G1Xyzz o = shfl_down_xyzz(P, off);
+            if ((int)tid + off < 64) xyzz_add_noinline(P, o);
+        }
+        G1Xyzz nxt = shfl_down_xyzz(P, 1);                    // suffix sum starting at bucket 2*tid + 2
+        if (tid == 63) nxt = xyzz_identity();
+        xyzz_add_noinline(r1, nxt);                           // suffix sum starting at bucket 2*tid + 1
+        G1Xyzz V = P;
+        xyzz_add_noinline(V, r1);
+        for (int m = 1; m < 64; m <<= 1) { G1Xyzz o = shfl_xor_xyzz(V, m); xyzz_add_noinline(V, o); }
+        if (tid == 0) {
+            store_xyzz(task_out + 2 * (size_t)task, V);       // S = sum_f (f+1) B_f
+            store_xyzz(task_out + 2 * (size_t)task + 1, P);   // T = sum_f B_f
+            task_bin[task] = bin;
+        }
     }
 }
 
-// ------------------------------------------------------------------------ bucket reduction
-// thread: 16 consecutive buckets [g0, g0+16) of one window -> sum_b (b+1) * B_b over its group
-__global__ void __launch_bounds__(MSM_THREADS) msm_reduce_groups(const G1Xyzz *bucket_parts, const uint32_t *task_start, G1Xyzz *group_out,
-                                                                  uint32_t buckets_per_window, uint32_t nbins, uint32_t total_groups) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total_groups) return;
-    uint32_t groups_per_window = buckets_per_window / REDUCE_GROUP;
-    uint32_t w = g / groups_per_window, gi = g % groups_per_window;
-    uint32_t bin = w * nbins + ((gi * REDUCE_GROUP) >> FINE_BITS), f0 = (gi * REDUCE_GROUP) & (FINE - 1);
-    uint32_t t0 = task_start[bin], t1 = task_start[bin + 1];
-    G1Xyzz run = xyzz_identity(), sum = xyzz_identity();
-    for (int i = REDUCE_GROUP - 1; i >= 0; i--) {
-        for (uint32_t t = t0; t < t1; t++) {          // usually one part per bucket
-            G1Xyzz v = load_xyzz(bucket_parts + (size_t)t * FINE + f0 + i);
-            xyzz_add_noinline(run, v);
-        }
-        xyzz_add_noinline(sum, run);
-    }
-    // sum = sum_i (i+1) B[g0+i];  add g0 * run
-    uint32_t g0 = gi * REDUCE_GROUP;
-    if (g0 && !is_inf(run)) {
-        G1Xyzz acc = xyzz_identity();
-        for (int i = 31 - __clz(g0); i >= 0; i--) {
-            acc = xyzz_double(acc);
-            if ((g0 >> i) & 1) xyzz_add_noinline(acc, run);
-        }
-        xyzz_add_noinline(sum, acc);
-    }
-    store_xyzz(group_out + g, sum);
-}
-
-// one workgroup per window: plain sum of its group results
-__global__ void __launch_bounds__(MSM_THREADS) msm_sum_window(const G1Xyzz *group_out, G1Xyzz *window_out, uint32_t groups_per_window) {
+// ------------------------------------------------------------------------ window reduction
+// one workgroup per window: W_w = sum_t S_t + 2^FINE_BITS * sum_c c * D_c,  D_c = sum of T_t over bin c
+__global__ void __launch_bounds__(MSM_THREADS) msm_window_sums(const G1Xyzz *task_out, const uint32_t *task_start, G1Xyzz *window_out, uint32_t nbins) {
     __shared__ __attribute__((aligned(16))) G1Xyzz sh[MSM_THREADS];
     const uint32_t tid = threadIdx.x, w = blockIdx.x;
-    G1Xyzz acc = xyzz_identity();
-    for (uint32_t i = tid; i < groups_per_window; i += MSM_THREADS) {
-        G1Xyzz v = load_xyzz(group_out + (size_t)w * groups_per_window + i);
-        xyzz_add_noinline(acc, v);
+    G1Xyzz ssum = xyzz_identity(), d = xyzz_identity();
+    if (tid < nbins) {
+        uint32_t bin = w * nbins + tid;
+        for (uint32_t t = task_start[bin]; t < task_start[bin + 1]; t++) {
+            G1Xyzz sv = load_xyzz(task_out + 2 * (size_t)t), tv = load_xyzz(task_out + 2 * (size_t)t + 1);
+            xyzz_add_noinline(ssum, sv);
+            xyzz_add_noinline(d, tv);
+        }
     }
-    sh[tid] = acc;
+    // inclusive suffix scan of D over the bins
+    sh[tid] = d;
     __syncthreads();
-    for (uint32_t off = MSM_THREADS / 2; off > 0; off >>= 1) {
-        if (tid < off) { G1Xyzz o = sh[tid + off]; xyzz_add_noinline(acc, o); sh[tid] = acc; }
+    for (uint32_t off = 1; off < MSM_THREADS; off <<= 1) {
+        G1Xyzz o = (tid + off < MSM_THREADS) ? sh[tid + off] : xyzz_identity();
+        __syncthreads();
+        if (tid + off < MSM_THREADS) { xyzz_add_noinline(d, o); sh[tid] = d; }
         __syncthreads();
     }
-    if (tid == 0) store_xyzz(window_out + w, acc);
+    // sum_c c*D_c = sum_{k>=1} suffix_k ; times 2^FINE_BITS ; plus the S terms
+    G1Xyzz v = tid >= 1 ? d : xyzz_identity();
+    for (uint32_t i = 0; i < FINE_BITS; i++) v = xyzz_double(v);
+    xyzz_add_noinline(v, ssum);
+    sh[tid] = v;
+    __syncthreads();
+    for (uint32_t off = MSM_THREADS / 2; off > 0; off >>= 1) {
+        if (tid < off) { G1Xyzz o = sh[tid + off]; xyzz_add_noinline(v, o); sh[tid] = v; }
+        __syncthreads();
+    }
+    if (tid == 0) store_xyzz(window_out + w, v);
 }
 
 // ------------------------------------------------------------------- tiny inputs: no buckets
@@ -369,19 +379,15 @@ int32_t msm_enqueue(plk_ctx *ctx, const Fr *scalars_dev, uint64_t n, uint64_t ba
     p.coarse_bits = p.c - 1 - FINE_BITS;
     p.nbins = 1u << p.coarse_bits;
     const uint32_t total_bins = p.windows * p.nbins;
-    const uint32_t buckets_per_window = 1u << (p.c - 1);
-    const uint32_t groups_per_window = buckets_per_window / REDUCE_GROUP;
-    const uint32_t total_groups = groups_per_window * p.windows;
-
     const uint32_t max_tasks = total_bins + (uint32_t)(((uint64_t)p.windows * n) / TASK_MAX) + 1;
-    PLK_TRY(ctx->msm_a.reserve((size_t)(3 * total_bins + 4) * sizeof(uint32_t)));             // hist/cursor + bin_start + task_start
-    PLK_TRY(ctx->msm_b.reserve((size_t)p.windows * n * sizeof(uint32_t)));                     // entries
-    PLK_TRY(ctx->msm_c.reserve((size_t)max_tasks * FINE * sizeof(G1Xyzz)));                    // per-task bucket sums
-    PLK_TRY(ctx->msm_d.reserve((size_t)(total_groups + p.windows) * sizeof(G1Xyzz)));          // group sums + window sums
+    PLK_TRY(ctx->msm_a.reserve((size_t)(3 * total_bins + 4 + max_tasks) * sizeof(uint32_t)));   // hist/cursor, bin_start, task_start, task_bin
+    PLK_TRY(ctx->msm_b.reserve((size_t)p.windows * n * sizeof(uint32_t)));                       // entries
+    PLK_TRY(ctx->msm_c.reserve((size_t)max_tasks * 2 * sizeof(G1Xyzz)));                         // per-task (S, T)
+    PLK_TRY(ctx->msm_d.reserve((size_t)p.windows * sizeof(G1Xyzz)));                             // window sums
     uint32_t *hist = ctx->msm_a.as<uint32_t>(), *bin_start = hist + total_bins, *task_start = bin_start + total_bins + 1;
+    uint32_t *task_bin = task_start + total_bins + 1;
     uint32_t *entries = ctx->msm_b.as<uint32_t>();
-    G1Xyzz *buckets = ctx->msm_c.as<G1Xyzz>();
-    G1Xyzz *groups = ctx->msm_d.as<G1Xyzz>(), *window_out = groups + total_groups;
+    G1Xyzz *task_out = ctx->msm_c.as<G1Xyzz>(), *window_out = ctx->msm_d.as<G1Xyzz>();
 
     PLK_HIP(hipMemsetAsync(hist, 0, total_bins * sizeof(uint32_t), stream));
     const uint32_t pblocks = (uint32_t)((n + SCALARS_PER_BLOCK - 1) / SCALARS_PER_BLOCK);
@@ -391,11 +397,9 @@ int32_t msm_enqueue(plk_ctx *ctx, const Fr *scalars_dev, uint64_t n, uint64_t ba
     hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks), dim3(MSM_THREADS), plds, stream, scalars_dev, p, hist, (const uint32_t *)bin_start, entries);
     if (ctx->ev_on) PLK_HIP(hipEventRecord(ctx->ev[0], stream));
     hipLaunchKernelGGL(msm_accumulate, dim3(max_tasks), dim3(MSM_THREADS), 0, stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
-                       (const uint32_t *)task_start, buckets, p);
+                       (const uint32_t *)task_start, task_out, task_bin, p);
     if (ctx->ev_on) PLK_HIP(hipEventRecord(ctx->ev[1], stream));
-    hipLaunchKernelGGL(msm_reduce_groups, dim3((total_groups + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
-                       (const G1Xyzz *)buckets, (const uint32_t *)task_start, groups, buckets_per_window, p.nbins, total_groups);
-    hipLaunchKernelGGL(msm_sum_window, dim3(p.windows), dim3(MSM_THREADS), 0, stream, (const G1Xyzz *)groups, window_out, groups_per_window);
+    hipLaunchKernelGGL(msm_window_sums, dim3(p.windows), dim3(MSM_THREADS), 0, stream, (const G1Xyzz *)task_out, (const uint32_t *)task_start, window_out, p.nbins);
     PLK_HIP(hipGetLastError());
     PLK_TRY(ensure_pinned(ctx, p.windows * sizeof(G1Xyzz)));
     PLK_HIP(hipMemcpyAsync(ctx->pinned, window_out, p.windows * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));

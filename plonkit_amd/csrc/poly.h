@@ -10,6 +10,13 @@ struct PermArgs {
     PowTable tw;
 };
 
+struct CheckArgs {
+    const Fr *values, *q[7];
+    const uint32_t *vars[4];
+    uint32_t n, num_inputs;
+    uint32_t *flag;
+};
+
 struct QuotientArgs {
     Fr *out;
     const Fr *w[4], *z, *q[7], *sigma[4], *pi, *l0;
@@ -38,6 +45,7 @@ struct EvalArgs {
 
 int32_t gather(Fr *out, const Fr *values, const uint32_t *vars, uint32_t n, hipStream_t s);
 int32_t sigma_from_index(Fr *out, const uint32_t *packed, uint32_t n, uint32_t log_n, const PowTable &tw, const Fr k[4], hipStream_t s);
+int32_t check_gates(const CheckArgs &a, hipStream_t s);
 int32_t perm_terms(const PermArgs &a, hipStream_t s);
 int32_t mul3(Fr *out, const Fr *a, const Fr *b, const Fr &sc, uint32_t n, hipStream_t s);
 // out may alias in.  mult: product scan, else sum; reverse: suffix; exclusive: shifted by one

@@ -242,6 +242,28 @@ __global__ void __launch_bounds__(PT) k_eval_finish(EvalArgs a, Fr *results) {
     if (tid == 0) store_fp(results + e, acc);
 }
 
+// ------------------------------------------------------------------- gate satisfiability
+// is_satisfied_using_one_shot_check (src/plonk.rs:128,137) on the device: every row's gate equation
+// q_a a + q_b b + q_c c + q_d d + q_m ab + q_const + q_dnext d_next + PI == 0; flag <- 1 otherwise
+__global__ void __launch_bounds__(PT) k_check_gates(CheckArgs a) {
+    uint32_t r = blockIdx.x * PT + threadIdx.x;
+    if (r >= a.n) return;
+    Fr w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = load_fp(a.values + a.vars[j][r]);
+    Fr acc = load_fp(a.q[5] + r);
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc = add(acc, mul(load_fp(a.q[j] + r), w[j]));
+    acc = add(acc, mul(load_fp(a.q[4] + r), mul(w[0], w[1])));
+    Fr qn = load_fp(a.q[6] + r);
+    if (!qn.is_zero()) {
+        Fr dn = (r + 1 < a.n) ? load_fp(a.values + a.vars[3][r + 1]) : Fr::zero();
+        acc = add(acc, mul(qn, dn));
+    }
+    if (r < a.num_inputs) acc = add(acc, w[0]);
+    if (!acc.is_zero()) atomicOr(a.flag, 1u);
+}
+
 // ------------------------------------------------------------------------- launchers
 static inline dim3 grid1(uint32_t n) { return dim3((n + PT - 1) / PT); }
 
@@ -252,6 +274,11 @@ int32_t gather(Fr *out, const Fr *values, const uint32_t *vars, uint32_t n, hipS
 }
 int32_t sigma_from_index(Fr *out, const uint32_t *packed, uint32_t n, uint32_t log_n, const PowTable &tw, const Fr k[4], hipStream_t s) {
     hipLaunchKernelGGL(k_sigma_from_index, grid1(n), dim3(PT), 0, s, out, packed, n, log_n, tw, k[0], k[1], k[2], k[3]);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+int32_t check_gates(const CheckArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_check_gates, grid1(a.n), dim3(PT), 0, s, a);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
 }

@@ -56,9 +56,11 @@ struct plk_setup {
     uint64_t n = 0, N = 0, num_inputs = 0, n_real = 0, num_vars = 0, num_gates = 0;
     uint32_t log_n = 0;
     plk::DevBuf store;                     // one allocation holding everything below
-    plk::Fr *sel_coef[7] = {nullptr}, *sig_coef[4] = {nullptr}, *sig_vals[4] = {nullptr};
+    plk::Fr *sel_coef[7] = {nullptr}, *sel_vals[7] = {nullptr}, *sig_coef[4] = {nullptr}, *sig_vals[4] = {nullptr};
     uint32_t *gate_vars[4] = {nullptr};
-    std::vector<plk::Gate> gates_host;     // input gates + transpiled gates (satisfiability check)
+    uint64_t num_circuit_vars = 0;         // circom wires; temporaries follow
+    std::vector<plk::WitnessOp> ops;       // linear forms defining the transpiler's temporaries
+    std::vector<plk::WitnessTerm> op_terms;
 };
 
 using namespace plk;
@@ -83,21 +85,25 @@ int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
     while (N < S->n_real + 1) { N <<= 1; log_n++; }
     if (log_n + 2 > MAX_LOG_N) { delete S; set_error("setup power of two is not in the correct range"); return PLK_ERR_SIZE; }   // src/plonk.rs:109-112
     S->N = N; S->n = N - 1; S->log_n = log_n;
-    S->gates_host.reserve(S->n_real);
+    S->num_circuit_vars = c->r1cs.num_variables;
+    S->ops.swap(T.ops); S->op_terms.swap(T.op_terms);
+    std::vector<Gate> rows;
+    rows.reserve(S->n_real);
     for (uint64_t i = 1; i <= S->num_inputs; i++) {                 // one gate per public input, first rows, q_a = -1
         Gate g; g.v[0] = (uint32_t)i; g.v[1] = g.v[2] = g.v[3] = 0;
         for (int k = 0; k < 7; k++) g.q[k] = HFr::zero();
         g.q[0] = -HFr::one();
-        S->gates_host.push_back(g);
+        rows.push_back(g);
     }
-    S->gates_host.insert(S->gates_host.end(), T.gates.begin(), T.gates.end());
-    const std::vector<Gate> &rows = S->gates_host;
+    rows.insert(rows.end(), T.gates.begin(), T.gates.end());
+    std::vector<Gate>().swap(T.gates);
 
     Arena A{&S->store};
-    size_t total = 15 * ((N * sizeof(Fr) + 255) & ~(size_t)255) + 4 * ((N * 4 + 255) & ~(size_t)255);
+    size_t total = 22 * ((N * sizeof(Fr) + 255) & ~(size_t)255) + 4 * ((N * 4 + 255) & ~(size_t)255);
     int32_t rc = S->store.reserve(total);
     if (rc != PLK_OK) { delete S; return rc; }
     for (int k = 0; k < 7; k++) S->sel_coef[k] = A.take<Fr>(N);
+    for (int k = 0; k < 7; k++) S->sel_vals[k] = A.take<Fr>(N);
     for (int j = 0; j < 4; j++) S->sig_coef[j] = A.take<Fr>(N);
     for (int j = 0; j < 4; j++) S->sig_vals[j] = A.take<Fr>(N);
     for (int j = 0; j < 4; j++) S->gate_vars[j] = A.take<uint32_t>(N);
@@ -109,7 +115,8 @@ int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
         std::vector<HFr> col(N);
         for (int k = 0; k < 7; k++) {
             for (uint64_t r = 0; r < N; r++) col[r] = r < rows.size() ? rows[r].q[k] : HFr::zero();
-            if (hipMemcpyAsync(S->sel_coef[k], col.data(), N * sizeof(Fr), hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D selector", __FILE__, __LINE__));
+            if (hipMemcpyAsync(S->sel_vals[k], col.data(), N * sizeof(Fr), hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D selector", __FILE__, __LINE__));
+            if (hipMemcpyAsync(S->sel_coef[k], S->sel_vals[k], N * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "D2D selector", __FILE__, __LINE__));
             if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
             if ((rc = ntt_dev(ctx, S->sel_coef[k], log_n, true, nullptr, st)) != PLK_OK) return fail(rc);
         }
@@ -187,19 +194,6 @@ int32_t plk_prove_timings(const plk_ctx *ctx, double *out_ms, uint32_t cap, uint
     return PLK_OK;
 }
 
-// is_satisfied_using_one_shot_check (src/plonk.rs:128,137): every gate equation holds on the witness
-static bool gates_satisfied(const plk_setup *S, const std::vector<HFr> &val, const std::vector<Gate> &rows) {
-    for (size_t r = 0; r < rows.size(); r++) {
-        const Gate &g = rows[r];
-        const HFr &a = val[g.v[0]], &b = val[g.v[1]], &c = val[g.v[2]], &d = val[g.v[3]];
-        HFr acc = g.q[0] * a + g.q[1] * b + g.q[2] * c + g.q[3] * d + g.q[4] * a * b + g.q[5];
-        if (!g.q[6].is_zero()) acc = acc + g.q[6] * (r + 1 < rows.size() ? val[rows[r + 1].v[3]] : HFr::zero());
-        if (r < S->num_inputs) acc = acc + a;
-        if (!acc.is_zero()) return false;
-    }
-    return true;
-}
-
 int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_t *proof_out, uint64_t cap, uint64_t *len) {
     if (!ctx || !S || !c || !proof_out || !len) { set_error("plk_prove: bad argument"); return PLK_ERR_ARG; }
     if (!c->has_witness) { set_error("plk_prove: circuit has no witness"); return PLK_ERR_ARG; }
@@ -210,19 +204,29 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     auto lap = [&]() { double t = now_ms(); ctx->timings.push_back(t - t_prev); t_prev = t; };
     hipStream_t st = ctx->stream;
 
-    // ---- synthesis with the witness (host)
-    Transpiled T;
-    if (!transpile(c->r1cs, &c->witness, &T)) return PLK_ERR_UNSAT;
-    if (T.gates.size() != S->num_gates || T.num_vars != S->num_vars) { set_error("plk_prove: circuit does not match the prepared setup"); return PLK_ERR_ARG; }
-    if (!gates_satisfied(S, T.values, S->gates_host)) { set_error("must satisfy: witness does not satisfy the circuit"); return PLK_ERR_UNSAT; }
-    lap();                                                                    // [0] synthesis + check
+    // ---- witness synthesis (host): circom wires, then the transpiler's temporaries from their recorded
+    //      linear forms (the gate structure itself lives in plk_setup; the reference re-synthesises here)
+    if (c->r1cs.num_variables != S->num_circuit_vars || c->witness.size() < S->num_circuit_vars) {
+        set_error("plk_prove: circuit does not match the prepared setup"); return PLK_ERR_ARG; }
+    struct { std::vector<HFr> values; uint64_t num_vars; } T;
+    T.num_vars = S->num_vars;
+    T.values.resize(S->num_vars);
+    memcpy(T.values.data(), c->witness.data(), S->num_circuit_vars * sizeof(HFr));
+    T.values[0] = HFr::zero();                                               // id 0 = dummy variable
+    for (size_t i = 0; i < S->ops.size(); i++) {
+        const WitnessOp &op = S->ops[i];
+        HFr acc = op.constant;
+        for (uint32_t k = 0; k < op.count; k++) { const WitnessTerm &t = S->op_terms[op.first + k]; acc = acc + t.coeff * T.values[t.var]; }
+        T.values[S->num_circuit_vars + i] = acc;
+    }
+    lap();                                                                    // [0] witness synthesis
 
     const uint64_t N = S->N, M = 4 * N;
     const uint32_t log_n = S->log_n, log_m = log_n + 2;
     const size_t NB = (N * sizeof(Fr) + 255) & ~(size_t)255, MB = (M * sizeof(Fr) + 255) & ~(size_t)255;
     const size_t TB = ((size_t)2 * POW_TAB * sizeof(Fr) + 255) & ~(size_t)255;
     const size_t VB = (T.num_vars * sizeof(Fr) + 255) & ~(size_t)255;
-    PLK_TRY(ctx->prove_ws.reserve(VB + 16 * NB + 20 * MB + 4 * TB + 4096));
+    PLK_TRY(ctx->prove_ws.reserve(VB + 16 * NB + 20 * MB + 4 * TB + 8192));
     Arena A{&ctx->prove_ws};
     Fr *d_values = A.take<Fr>(T.num_vars);
     Fr *w_vals[4], *w_coef[4];
@@ -236,8 +240,21 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     for (int k = 0; k < 4; k++) tab[k] = A.take<Fr>(2 * POW_TAB);
     Fr *d_results = A.take<Fr>(16);
 
+    uint32_t *d_flag = A.take<uint32_t>(64);
     PLK_HIP(hipMemcpyAsync(d_values, T.values.data(), T.num_vars * sizeof(Fr), hipMemcpyHostToDevice, st));
     std::vector<HFr> inputs(T.values.begin() + 1, T.values.begin() + 1 + S->num_inputs);
+    {   // is_satisfied_using_one_shot_check (src/plonk.rs:137) on the device
+        CheckArgs ca;
+        ca.values = d_values; ca.n = (uint32_t)N; ca.num_inputs = (uint32_t)S->num_inputs; ca.flag = d_flag;
+        for (int k = 0; k < 7; k++) ca.q[k] = S->sel_vals[k];
+        for (int j = 0; j < 4; j++) ca.vars[j] = S->gate_vars[j];
+        PLK_HIP(hipMemsetAsync(d_flag, 0, 4, st));
+        PLK_TRY(check_gates(ca, st));
+        uint32_t bad = 0;
+        PLK_HIP(hipMemcpyAsync(&bad, d_flag, 4, hipMemcpyDeviceToHost, st));
+        PLK_HIP(hipStreamSynchronize(st));
+        if (bad) { set_error("must satisfy: witness does not satisfy the circuit"); return PLK_ERR_UNSAT; }
+    }
 
     // ---- round 1: wire polynomials, 4 x iNTT(N), 4 x MSM(N)
     for (int j = 0; j < 4; j++) {
