@@ -63,6 +63,8 @@ struct plk_ctx {
     const void *srs = nullptr;               // device, Montgomery affine, 64 B per point
     uint64_t srs_n = 0;
     plk::DevBuf srs_own;
+    plk::DevBuf srs_w;                       // the same points in the 2^261 Montgomery domain of field29.cuh (MSM gathers)
+    bool srs_w_valid = false;
     // MSM scratch
     plk::DevBuf msm_a, msm_b, msm_c, msm_d, msm_e;
     plk::DevBuf prove_ws;                    // workspace of the prover rounds (grows only)

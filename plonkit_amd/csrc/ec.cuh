@@ -11,6 +11,18 @@
 
 namespace plk {
 
+// The EC formulas below call the Montgomery product through ONE out-of-line copy on the device:
+// fully inlined, a mixed addition is ~45 KB of straight-line code (10 products x ~560 instructions)
+// and the accumulate loop thrashes the 64 KB instruction cache shared by two CUs.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __noinline__ Fq fq_mul_call(Fq a, Fq b) { return plk::mul<FqParams>(a, b); }
+#define ECM(a, b) fq_mul_call((a), (b))
+#define ECS(a) fq_mul_call((a), (a))
+#else
+#define ECM(a, b) plk::mul((a), (b))
+#define ECS(a) plk::mul((a), (a))
+#endif
+
 struct alignas(16) G1Affine { Fq x, y; };
 struct alignas(16) G1Xyzz { Fq x, y, zz, zzz; };
 struct alignas(16) G1Jac { Fq x, y, z; };
@@ -25,11 +37,11 @@ PLK_HD G1Xyzz xyzz_from_affine(const G1Affine &p) {
 
 // 2 * affine  (mdbl-2008-s-1)
 PLK_HD G1Xyzz xyzz_double_affine(const G1Affine &p) {
-    Fq u = dbl(p.y), v = sqr(u), w = mul(u, v), s = mul(p.x, v);
-    Fq xx = sqr(p.x), m = add(dbl(xx), xx);
+    Fq u = dbl(p.y), v = ECS(u), w = ECM(u, v), s = ECM(p.x, v);
+    Fq xx = ECS(p.x), m = add(dbl(xx), xx);
     G1Xyzz r;
-    r.x = sub(sqr(m), dbl(s));
-    r.y = sub(mul(m, sub(s, r.x)), mul(w, p.y));
+    r.x = sub(ECS(m), dbl(s));
+    r.y = sub(ECM(m, sub(s, r.x)), ECM(w, p.y));
     r.zz = v; r.zzz = w;
     return r;
 }
@@ -37,12 +49,12 @@ PLK_HD G1Xyzz xyzz_double_affine(const G1Affine &p) {
 // 2 * xyzz  (dbl-2008-s-1)
 PLK_HD G1Xyzz xyzz_double(const G1Xyzz &p) {
     if (is_inf(p)) return p;
-    Fq u = dbl(p.y), v = sqr(u), w = mul(u, v), s = mul(p.x, v);
-    Fq xx = sqr(p.x), m = add(dbl(xx), xx);
+    Fq u = dbl(p.y), v = ECS(u), w = ECM(u, v), s = ECM(p.x, v);
+    Fq xx = ECS(p.x), m = add(dbl(xx), xx);
     G1Xyzz r;
-    r.x = sub(sqr(m), dbl(s));
-    r.y = sub(mul(m, sub(s, r.x)), mul(w, p.y));
-    r.zz = mul(v, p.zz); r.zzz = mul(w, p.zzz);
+    r.x = sub(ECS(m), dbl(s));
+    r.y = sub(ECM(m, sub(s, r.x)), ECM(w, p.y));
+    r.zz = ECM(v, p.zz); r.zzz = ECM(w, p.zzz);
     return r;
 }
 
@@ -52,38 +64,38 @@ PLK_HD void xyzz_add_mixed(G1Xyzz &acc, const G1Affine &q_in, bool neg_q) {
     G1Affine q = q_in;
     if (neg_q) q.y = neg(q.y);
     if (is_inf(acc)) { acc.x = q.x; acc.y = q.y; acc.zz = Fq::one(); acc.zzz = Fq::one(); return; }
-    Fq u2 = mul(q.x, acc.zz), s2 = mul(q.y, acc.zzz);
+    Fq u2 = ECM(q.x, acc.zz), s2 = ECM(q.y, acc.zzz);
     Fq p = sub(u2, acc.x), r = sub(s2, acc.y);
     if (p.is_zero()) {
         if (r.is_zero()) acc = xyzz_double_affine(q);
         else acc = xyzz_identity();
         return;
     }
-    Fq pp = sqr(p), ppp = mul(p, pp), qq = mul(acc.x, pp);
-    Fq x3 = sub(sub(sqr(r), ppp), dbl(qq));
-    acc.y = sub(mul(r, sub(qq, x3)), mul(acc.y, ppp));
+    Fq pp = ECS(p), ppp = ECM(p, pp), qq = ECM(acc.x, pp);
+    Fq x3 = sub(sub(ECS(r), ppp), dbl(qq));
+    acc.y = sub(ECM(r, sub(qq, x3)), ECM(acc.y, ppp));
     acc.x = x3;
-    acc.zz = mul(acc.zz, pp);
-    acc.zzz = mul(acc.zzz, ppp);
+    acc.zz = ECM(acc.zz, pp);
+    acc.zzz = ECM(acc.zzz, ppp);
 }
 
 // a += b   (add-2008-s)
 PLK_HD void xyzz_add(G1Xyzz &a, const G1Xyzz &b) {
     if (is_inf(b)) return;
     if (is_inf(a)) { a = b; return; }
-    Fq u1 = mul(a.x, b.zz), u2 = mul(b.x, a.zz), s1 = mul(a.y, b.zzz), s2 = mul(b.y, a.zzz);
+    Fq u1 = ECM(a.x, b.zz), u2 = ECM(b.x, a.zz), s1 = ECM(a.y, b.zzz), s2 = ECM(b.y, a.zzz);
     Fq p = sub(u2, u1), r = sub(s2, s1);
     if (p.is_zero()) {
         if (r.is_zero()) a = xyzz_double(a);
         else a = xyzz_identity();
         return;
     }
-    Fq pp = sqr(p), ppp = mul(p, pp), qq = mul(u1, pp);
-    Fq x3 = sub(sub(sqr(r), ppp), dbl(qq));
-    a.y = sub(mul(r, sub(qq, x3)), mul(s1, ppp));
+    Fq pp = ECS(p), ppp = ECM(p, pp), qq = ECM(u1, pp);
+    Fq x3 = sub(sub(ECS(r), ppp), dbl(qq));
+    a.y = sub(ECM(r, sub(qq, x3)), ECM(s1, ppp));
     a.x = x3;
-    a.zz = mul(mul(a.zz, b.zz), pp);
-    a.zzz = mul(mul(a.zzz, b.zzz), ppp);
+    a.zz = ECM(ECM(a.zz, b.zz), pp);
+    a.zzz = ECM(ECM(a.zzz, b.zzz), ppp);
 }
 
 PLK_HD G1Xyzz xyzz_neg(const G1Xyzz &p) { G1Xyzz r = p; r.y = neg(p.y); return r; }
@@ -102,10 +114,10 @@ PLK_HD G1Xyzz xyzz_mul_small(const G1Xyzz &p, uint32_t k) {
 PLK_HD G1Jac xyzz_to_jacobian(const G1Xyzz &p) {
     G1Jac r;
     if (is_inf(p)) { r.x = Fq::one(); r.y = Fq::one(); r.z = Fq::zero(); return r; }
-    Fq t2 = sqr(p.zzz), zz2 = sqr(p.zz);
-    r.x = mul(mul(p.x, p.zz), t2);
-    r.y = mul(mul(mul(p.y, zz2), p.zz), t2);
-    r.z = mul(p.zz, p.zzz);
+    Fq t2 = ECS(p.zzz), zz2 = ECS(p.zz);
+    r.x = ECM(ECM(p.x, p.zz), t2);
+    r.y = ECM(ECM(ECM(p.y, zz2), p.zz), t2);
+    r.z = ECM(p.zz, p.zzz);
     return r;
 }
 

@@ -21,6 +21,7 @@
 // algorithmic 96 B/term plus 8 B/term/window of index lists.
 #include "ctx.h"
 #include "ec.cuh"
+#include "ec29.cuh"
 #include "msm.h"
 #include "hostmath.h"
 #include <cstring>
@@ -147,10 +148,12 @@ __global__ void __launch_bounds__(1024) msm_scan_bins(uint32_t *hist, uint32_t *
 }
 
 // --------------------------------------------------------------------- bucket accumulation
-__device__ __forceinline__ G1Xyzz shfl_xor_xyzz(const G1Xyzz &v, int mask) {
-    G1Xyzz r;
+// All group arithmetic below runs on the 9 x 29-bit lazy field layer (ec29.cuh); the resident SRS
+// copy it gathers from is kept in that layer's 2^261 Montgomery domain (srs_to_w_kernel).
+__device__ __forceinline__ XyzzW shfl_xor_w(const XyzzW &v, int mask) {
+    XyzzW r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 9; i++) {
         r.x.l[i] = __shfl_xor(v.x.l[i], mask);
         r.y.l[i] = __shfl_xor(v.y.l[i], mask);
         r.zz.l[i] = __shfl_xor(v.zz.l[i], mask);
@@ -158,10 +161,10 @@ __device__ __forceinline__ G1Xyzz shfl_xor_xyzz(const G1Xyzz &v, int mask) {
     }
     return r;
 }
-__device__ __forceinline__ G1Xyzz shfl_down_xyzz(const G1Xyzz &v, int delta) {
-    G1Xyzz r;
+__device__ __forceinline__ XyzzW shfl_down_w(const XyzzW &v, int delta) {
+    XyzzW r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 9; i++) {
         r.x.l[i] = __shfl_down(v.x.l[i], delta);
         r.y.l[i] = __shfl_down(v.y.l[i], delta);
         r.zz.l[i] = __shfl_down(v.zz.l[i], delta);
@@ -170,35 +173,46 @@ __device__ __forceinline__ G1Xyzz shfl_down_xyzz(const G1Xyzz &v, int delta) {
     return r;
 }
 
-__device__ __noinline__ void xyzz_add_noinline(G1Xyzz &a, const G1Xyzz &b) { xyzz_add(a, b); }
+// full additions are off the hot path (pair combine, hot buckets, epilogue): one out-of-line copy
+__device__ __noinline__ void xyzzw_add_call(XyzzW *a, const XyzzW *b) { XyzzW t = *a; xyzzw_add(t, *b); *a = t; }
+__device__ __forceinline__ void xyzzw_add_nl(XyzzW &a, const XyzzW &b) { xyzzw_add_call(&a, &b); }
 
-__device__ __forceinline__ void accumulate_run(G1Xyzz &acc, const G1Affine *bases, const uint32_t *sorted, uint32_t lo, uint32_t hi) {
+__global__ void __launch_bounds__(256) srs_to_w_kernel(G1Affine *out, const G1Affine *in, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Affine p = load_affine(in + i);
+    G1Affine o;
+    o.x = pack<FqParams>(csub_p(w_from_s(unpack<FqW>(p.x))));
+    o.y = pack<FqParams>(csub_p(w_from_s(unpack<FqW>(p.y))));
+    store_fp(&out[i].x, o.x);
+    store_fp(&out[i].y, o.y);
+}
+
+__device__ __forceinline__ void accumulate_run(XyzzW &acc, const G1Affine *bases, const uint32_t *sorted, uint32_t lo, uint32_t hi) {
     if (lo >= hi) return;
     uint32_t e = sorted[lo];
     G1Affine pt = load_affine(bases + (e >> 8));
     for (uint32_t i = lo; i < hi; i++) {
         uint32_t e_cur = e;
-        G1Affine cur = pt;
+        AffW cur; cur.x = unpack<FqW>(pt.x); cur.y = unpack<FqW>(pt.y);
         if (i + 1 < hi) { e = sorted[i + 1]; pt = load_affine(bases + (e >> 8)); }   // prefetch the next gather
-        xyzz_add_mixed(acc, cur, (e_cur & 0x80u) != 0);
+        xyzzw_add_mixed(acc, cur, (e_cur & 0x80u) != 0);
     }
 }
 
-// One workgroup per task = one slice (<= CHUNK entries) of a (window, coarse bin): 128 buckets.
+// Kernel A — one workgroup per task = one slice (<= CHUNK entries) of a (window, coarse bin): 128 buckets.
 //  1. counting sort of the slice by fine bucket inside LDS
 //  2. buckets ranked by population; lane pair p takes the p-th most populated bucket, half a run per
 //     lane, so the lanes of a wave walk runs of (nearly) equal length and short waves retire early
-//  3. buckets hotter than HEAVY are reduced by the whole workgroup with wave64 shuffle trees
-//  4. epilogue on one wave: T = sum_f B_f and S = sum_f (f+1) B_f of the 128 bucket sums by a
-//     shuffle suffix scan — the task leaves only these two points behind
-__global__ void __launch_bounds__(MSM_THREADS) msm_accumulate(const G1Affine *bases, const uint32_t *entries,
-                                                               const uint32_t *bin_start, const uint32_t *task_start,
-                                                               G1Xyzz *task_out, uint32_t *task_bin, MsmParams p) {
+//  3. the most populated bucket, when hotter than HEAVY (repeated scalars), is instead sliced over all
+//     256 lanes into an overflow row
+// Only mixed additions happen here (10 products each, ~25 KB of code, <= 128 VGPRs); every lane leaves
+// its partial sum in `partials[task][2*bucket + half]` and kernel B folds them.
+__global__ void __launch_bounds__(MSM_THREADS, 4) msm_accumulate(const G1Affine *bases, const uint32_t *entries,
+                                                                  const uint32_t *bin_start, const uint32_t *task_start,
+                                                                  XyzzW *partials, XyzzW *overflow, uint32_t *task_heavy, MsmParams p) {
     __shared__ uint32_t sorted[CHUNK];
-    __shared__ uint32_t cnt[FINE], start[FINE + 1], cursor[FINE], order[FINE], rank_of[FINE];
-    __shared__ __attribute__((aligned(16))) G1Xyzz B[FINE];
-    __shared__ __attribute__((aligned(16))) G1Xyzz wave_part[MSM_THREADS / 64];
-    __shared__ uint32_t heavy_list[FINE], heavy_n;
+    __shared__ uint32_t cnt[FINE], start[FINE + 1], cursor[FINE], order[FINE];
     const uint32_t tid = threadIdx.x, task = blockIdx.x;
     const uint32_t total_bins = p.windows * p.nbins;
     if (task >= task_start[total_bins]) return;
@@ -209,7 +223,6 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_accumulate(const G1Affine *ba
     const uint32_t s = bs + slice * CHUNK, e = (s + CHUNK < be) ? s + CHUNK : be, nc = e - s;
 
     if (tid < FINE) { cnt[tid] = 0; cursor[tid] = 0; }
-    if (tid == 0) heavy_n = 0;
     __syncthreads();
     for (uint32_t idx = tid; idx < nc; idx += MSM_THREADS) atomicAdd(&cnt[entries[s + idx] & (FINE - 1)], 1u);
     __syncthreads();
@@ -223,8 +236,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_accumulate(const G1Affine *ba
     if (tid >= 64 && tid < 64 + FINE) {                       // rank by population (descending, ties by index)
         uint32_t b = tid - 64, c = cnt[b], r = 0;
         for (uint32_t o = 0; o < FINE; o++) { uint32_t co = cnt[o]; r += (co > c) || (co == c && o < b); }
-        order[r] = b; rank_of[b] = r;
-        if (c > HEAVY) heavy_list[atomicAdd(&heavy_n, 1u)] = b;
+        order[r] = b;
     }
     __syncthreads();
     for (uint32_t idx = tid; idx < nc; idx += MSM_THREADS) {
@@ -232,122 +244,148 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_accumulate(const G1Affine *ba
         sorted[start[f] + atomicAdd(&cursor[f], 1u)] = en;
     }
     __syncthreads();
+    const uint32_t hot = order[0];
+    const bool has_hot = cnt[hot] > HEAVY;
     const uint32_t pair = tid >> 1, half = tid & 1, my_bucket = order[pair];
-    G1Xyzz acc = xyzz_identity();
-    {
-        uint32_t b0 = start[my_bucket], n_b = cnt[my_bucket];
-        if (n_b <= HEAVY) {
-            uint32_t mid = b0 + (n_b + 1) / 2;
-            accumulate_run(acc, bases, sorted, half ? mid : b0, half ? b0 + n_b : mid);
+    if (tid == 0) task_heavy[task] = has_hot ? hot : 0xffffffffu;
+    // phase 0: the lane's half of its bucket; phase 1 (only with a hot bucket): the lane's slice of it.
+    // One loop, one copy of the mixed-addition code.
+    for (uint32_t phase = 0; phase < (has_hot ? 2u : 1u); phase++) {
+        uint32_t lo, hi;
+        XyzzW *dst;
+        if (phase == 0) {
+            uint32_t b0 = start[my_bucket], n_b = cnt[my_bucket], mid = b0 + (n_b + 1) / 2;
+            lo = half ? mid : b0; hi = half ? b0 + n_b : mid;
+            if (has_hot && my_bucket == hot) hi = lo;
+            dst = partials + (size_t)task * (2 * FINE) + 2 * my_bucket + half;
+        } else {
+            uint32_t b0 = start[hot], n_b = cnt[hot], per = (n_b + MSM_THREADS - 1) / MSM_THREADS;
+            lo = b0 + tid * per; hi = lo + per;
+            if (lo > b0 + n_b) lo = b0 + n_b;
+            if (hi > b0 + n_b) hi = b0 + n_b;
+            dst = overflow + (size_t)task * MSM_THREADS + tid;
+        }
+        XyzzW acc = xyzzw_identity();
+        accumulate_run(acc, bases, sorted, lo, hi);
+        store_xyzzw(dst, acc);
+    }
+}
+
+// Kernel B — 16 lanes per task, 8 buckets per lane: folds the lane partials of kernel A (and the
+// overflow row of a hot bucket), then T = sum_f B_f and S = sum_f (f+1) B_f by running sums inside
+// the lane and a 16-lane shuffle suffix scan across lanes.  Leaves (S, T) per task.
+__global__ void __launch_bounds__(MSM_THREADS) msm_task_reduce(const XyzzW *partials, const XyzzW *overflow, const uint32_t *task_heavy,
+                                                                const uint32_t *task_start, XyzzW *task_out, uint32_t total_bins) {
+    const uint32_t gt = blockIdx.x * MSM_THREADS + threadIdx.x;
+    const uint32_t task = gt >> 4, sub = gt & 15;
+    const uint32_t ntasks = task_start[total_bins];
+    const bool live = task < ntasks;
+    XyzzW run = xyzzw_identity(), sum = xyzzw_identity(), hot_total = xyzzw_identity();
+    if (live) {
+        const uint32_t hot = task_heavy[task];
+        const XyzzW *P = partials + (size_t)task * (2 * FINE);
+        for (int k = 7; k >= 0; k--) {
+            const uint32_t b = 8 * sub + k;
+            XyzzW v = load_xyzzw(P + 2 * b), v1 = load_xyzzw(P + 2 * b + 1);
+            xyzzw_add_nl(v, v1);
+            if (hot != 0xffffffffu) {                        // uniform across the task's 16 lanes
+                // the hot bucket's 256 slices: 16 per lane, then a 16-lane tree; lane owning the bucket takes it
+                const XyzzW *O = overflow + (size_t)task * MSM_THREADS + 16 * sub;
+                XyzzW part = xyzzw_identity();
+                if (k == 7) {
+                    for (uint32_t i = 0; i < 16; i++) { XyzzW o = load_xyzzw(O + i); xyzzw_add_nl(part, o); }
+                    for (int m = 1; m < 16; m <<= 1) { XyzzW o = shfl_xor_w(part, m); xyzzw_add_nl(part, o); }
+                    hot_total = part;
+                }
+                if (b == hot) xyzzw_add_nl(v, hot_total);
+            }
+            xyzzw_add_nl(run, v);
+            xyzzw_add_nl(sum, run);                          // sum = sum_k (k+1) * B[8 sub + k]
         }
     }
-    const uint32_t hn = heavy_n;
-    for (uint32_t hI = 0; hI < hn; hI++) {
-        uint32_t hb = heavy_list[hI], b0 = start[hb], n_b = cnt[hb];
-        uint32_t per = (n_b + MSM_THREADS - 1) / MSM_THREADS;
-        uint32_t lo = b0 + tid * per, hi = lo + per;
-        if (lo > b0 + n_b) lo = b0 + n_b;
-        if (hi > b0 + n_b) hi = b0 + n_b;
-        G1Xyzz part = xyzz_identity();
-        accumulate_run(part, bases, sorted, lo, hi);
-        for (int m = 1; m < 64; m <<= 1) { G1Xyzz o = shfl_xor_xyzz(part, m); xyzz_add_noinline(part, o); }
-        if ((tid & 63) == 0) wave_part[tid >> 6] = part;
-        __syncthreads();
-        if (tid == 2 * rank_of[hb]) {
-            for (int wv = 0; wv < MSM_THREADS / 64; wv++) { G1Xyzz o = wave_part[wv]; xyzz_add_noinline(acc, o); }
-        }
-        __syncthreads();
+    // across the 16 lanes of the task: R_sub = sum_{s >= sub} run_s (suffix scan), then
+    // S = sum_sub sum_sub + 8 * sum_{sub >= 1} R_sub ,  T = R_0
+    XyzzW R = run;
+    for (int off = 1; off < 16; off <<= 1) {
+        XyzzW o = shfl_down_w(R, off);
+        if ((int)sub + off < 16) xyzzw_add_nl(R, o);
     }
-    {
-        G1Xyzz other = shfl_xor_xyzz(acc, 1);
-        if (half == 0) { xyzz_add_noinline(acc, other); B[my_bucket] = acc; }
-    }
-    __syncthreads();
-    if (tid < 64) {
-        G1Xyzz r1 = B[2 * tid + 1], P = B[2 * tid];
-        xyzz_add_noinline(P, r1);                             // pair total
-        for (int off = 1; off < 64; off <<= 1) {              // inclusive suffix scan of the pair totals
-            G1Xyzz o = shfl_down_xyzz(P, off);
-            if ((int)tid + off < 64) xyzz_add_noinline(P, o);
-        }
-        G1Xyzz nxt = shfl_down_xyzz(P, 1);                    // suffix sum starting at bucket 2*tid + 2
-        if (tid == 63) nxt = xyzz_identity();
-        xyzz_add_noinline(r1, nxt);                           // suffix sum starting at bucket 2*tid + 1
-        G1Xyzz V = P;
-        xyzz_add_noinline(V, r1);
-        for (int m = 1; m < 64; m <<= 1) { G1Xyzz o = shfl_xor_xyzz(V, m); xyzz_add_noinline(V, o); }
-        if (tid == 0) {
-            store_xyzz(task_out + 2 * (size_t)task, V);       // S = sum_f (f+1) B_f
-            store_xyzz(task_out + 2 * (size_t)task + 1, P);   // T = sum_f B_f
-            task_bin[task] = bin;
-        }
+    XyzzW wsum = sub >= 1 ? R : xyzzw_identity();
+    for (int i = 0; i < 3; i++) wsum = xyzzw_double(wsum);
+    xyzzw_add_nl(wsum, sum);
+    for (int m = 1; m < 16; m <<= 1) { XyzzW o = shfl_xor_w(wsum, m); xyzzw_add_nl(wsum, o); }
+    if (live && sub == 0) {
+        store_xyzzw(task_out + 2 * (size_t)task, wsum);
+        store_xyzzw(task_out + 2 * (size_t)task + 1, R);
     }
 }
 
 // ------------------------------------------------------------------------ window reduction
-// one workgroup per window: W_w = sum_t S_t + 2^FINE_BITS * sum_c c * D_c,  D_c = sum of T_t over bin c
-__global__ void __launch_bounds__(MSM_THREADS) msm_window_sums(const G1Xyzz *task_out, const uint32_t *task_start, G1Xyzz *window_out, uint32_t nbins) {
-    __shared__ __attribute__((aligned(16))) G1Xyzz sh[MSM_THREADS];
+// one workgroup per window: W_w = sum_t S_t + 2^FINE_BITS * sum_c c * D_c,  D_c = sum of T_t over bin c.
+// The result is exported in the library's external form (canonical, R = 2^256) for the host Horner.
+__global__ void __launch_bounds__(MSM_THREADS) msm_window_sums(const XyzzW *task_out, const uint32_t *task_start, G1Xyzz *window_out, uint32_t nbins) {
+    __shared__ __attribute__((aligned(16))) XyzzW sh[MSM_THREADS];
     const uint32_t tid = threadIdx.x, w = blockIdx.x;
-    G1Xyzz ssum = xyzz_identity(), d = xyzz_identity();
+    XyzzW ssum = xyzzw_identity(), d = xyzzw_identity();
     if (tid < nbins) {
         uint32_t bin = w * nbins + tid;
         for (uint32_t t = task_start[bin]; t < task_start[bin + 1]; t++) {
-            G1Xyzz sv = load_xyzz(task_out + 2 * (size_t)t), tv = load_xyzz(task_out + 2 * (size_t)t + 1);
-            xyzz_add_noinline(ssum, sv);
-            xyzz_add_noinline(d, tv);
+            XyzzW sv = load_xyzzw(task_out + 2 * (size_t)t), tv = load_xyzzw(task_out + 2 * (size_t)t + 1);
+            xyzzw_add_nl(ssum, sv);
+            xyzzw_add_nl(d, tv);
         }
     }
-    // inclusive suffix scan of D over the bins
     sh[tid] = d;
     __syncthreads();
-    for (uint32_t off = 1; off < MSM_THREADS; off <<= 1) {
-        G1Xyzz o = (tid + off < MSM_THREADS) ? sh[tid + off] : xyzz_identity();
+    for (uint32_t off = 1; off < MSM_THREADS; off <<= 1) {   // inclusive suffix scan of D over the bins
+        XyzzW o = (tid + off < MSM_THREADS) ? sh[tid + off] : xyzzw_identity();
         __syncthreads();
-        if (tid + off < MSM_THREADS) { xyzz_add_noinline(d, o); sh[tid] = d; }
+        if (tid + off < MSM_THREADS) { xyzzw_add_nl(d, o); sh[tid] = d; }
         __syncthreads();
     }
     // sum_c c*D_c = sum_{k>=1} suffix_k ; times 2^FINE_BITS ; plus the S terms
-    G1Xyzz v = tid >= 1 ? d : xyzz_identity();
-    for (uint32_t i = 0; i < FINE_BITS; i++) v = xyzz_double(v);
-    xyzz_add_noinline(v, ssum);
+    XyzzW v = tid >= 1 ? d : xyzzw_identity();
+    for (uint32_t i = 0; i < FINE_BITS; i++) v = xyzzw_double(v);
+    xyzzw_add_nl(v, ssum);
     sh[tid] = v;
     __syncthreads();
     for (uint32_t off = MSM_THREADS / 2; off > 0; off >>= 1) {
-        if (tid < off) { G1Xyzz o = sh[tid + off]; xyzz_add_noinline(v, o); sh[tid] = v; }
+        if (tid < off) { XyzzW o = sh[tid + off]; xyzzw_add_nl(v, o); sh[tid] = v; }
         __syncthreads();
     }
-    if (tid == 0) store_xyzz(window_out + w, v);
+    if (tid == 0) store_xyzz(window_out + w, xyzzw_export(v));
 }
 
 // ------------------------------------------------------------------- tiny inputs: no buckets
 __global__ void __launch_bounds__(MSM_THREADS) msm_naive(const G1Affine *bases, const Fr *scalars, uint32_t n, G1Xyzz *block_out) {
-    __shared__ __attribute__((aligned(16))) G1Xyzz sh[MSM_THREADS];
+    __shared__ __attribute__((aligned(16))) XyzzW sh[MSM_THREADS];
     const uint32_t tid = threadIdx.x, i = blockIdx.x * MSM_THREADS + tid;
-    G1Xyzz acc = xyzz_identity();
+    XyzzW acc = xyzzw_identity();
     if (i < n) {
         Fr k = to_canonical(load_fp(scalars + i));
         G1Affine pt = load_affine(bases + i);
         if (!k.is_zero() && !is_inf(pt)) {
+            AffW q; q.x = unpack<FqW>(pt.x); q.y = unpack<FqW>(pt.y);
             for (int bit = 253; bit >= 0; bit--) {
-                acc = xyzz_double(acc);
-                if ((k.l[bit >> 5] >> (bit & 31)) & 1) xyzz_add_mixed(acc, pt, false);
+                acc = xyzzw_double(acc);
+                if ((k.l[bit >> 5] >> (bit & 31)) & 1) xyzzw_add_mixed(acc, q, false);
             }
         }
     }
     sh[tid] = acc;
     __syncthreads();
     for (uint32_t off = MSM_THREADS / 2; off > 0; off >>= 1) {
-        if (tid < off) { G1Xyzz o = sh[tid + off]; xyzz_add_noinline(acc, o); sh[tid] = acc; }
+        if (tid < off) { XyzzW o = sh[tid + off]; xyzzw_add_nl(acc, o); sh[tid] = acc; }
         __syncthreads();
     }
-    if (tid == 0) store_xyzz(block_out + blockIdx.x, acc);
+    if (tid == 0) store_xyzz(block_out + blockIdx.x, xyzzw_export(acc));
 }
 
 // ------------------------------------------------------------------------------ host side
+// Window widths are chosen among those whose top window still has many bits (254 = 19*13 + 7 = 15*16 + 14):
+// a top window of 1-2 bits would put every term into two or three buckets of a single bin.
 static uint32_t pick_window_bits(uint64_t n) {
-    if (n < (1u << 15)) return 12;
-    if (n < (1u << 18)) return 14;
+    if (n < (1u << 17)) return 13;
     return 16;
 }
 
@@ -357,7 +395,14 @@ int32_t msm_enqueue(plk_ctx *ctx, const Fr *scalars_dev, uint64_t n, uint64_t ba
     if (!ctx->srs) { set_error("msm: no SRS uploaded (plk_srs_upload)"); return PLK_ERR_SRS; }
     if (base_offset + n > ctx->srs_n) { set_error("msm: SRS too small for this commitment"); return PLK_ERR_SRS; }
     if (n >= (1ull << 24) + 1) { set_error("msm: more than 2^24 terms per call (shard the commitment)"); return PLK_ERR_SIZE; }
-    const G1Affine *bases = reinterpret_cast<const G1Affine *>(ctx->srs) + base_offset;
+    if (!ctx->srs_w_valid) {                                     // resident copy of the SRS in the 2^261 domain of the lazy field layer
+        PLK_TRY(ctx->srs_w.reserve(ctx->srs_n * sizeof(G1Affine)));
+        hipLaunchKernelGGL(srs_to_w_kernel, dim3((uint32_t)((ctx->srs_n + 255) / 256)), dim3(256), 0, stream,
+                           ctx->srs_w.as<G1Affine>(), reinterpret_cast<const G1Affine *>(ctx->srs), ctx->srs_n);
+        PLK_HIP(hipGetLastError());
+        ctx->srs_w_valid = true;
+    }
+    const G1Affine *bases = ctx->srs_w.as<G1Affine>() + base_offset;
     ctx->msm_pending_parts = 0;
     ctx->msm_windows = 0;
     if (n == 0) return PLK_OK;
@@ -380,14 +425,17 @@ int32_t msm_enqueue(plk_ctx *ctx, const Fr *scalars_dev, uint64_t n, uint64_t ba
     p.nbins = 1u << p.coarse_bits;
     const uint32_t total_bins = p.windows * p.nbins;
     const uint32_t max_tasks = total_bins + (uint32_t)(((uint64_t)p.windows * n) / TASK_MAX) + 1;
-    PLK_TRY(ctx->msm_a.reserve((size_t)(3 * total_bins + 4 + max_tasks) * sizeof(uint32_t)));   // hist/cursor, bin_start, task_start, task_bin
+    PLK_TRY(ctx->msm_a.reserve((size_t)(3 * total_bins + 4) * sizeof(uint32_t)));               // hist/cursor, bin_start, task_start
     PLK_TRY(ctx->msm_b.reserve((size_t)p.windows * n * sizeof(uint32_t)));                       // entries
-    PLK_TRY(ctx->msm_c.reserve((size_t)max_tasks * 2 * sizeof(G1Xyzz)));                         // per-task (S, T)
+    PLK_TRY(ctx->msm_c.reserve((size_t)max_tasks * 2 * sizeof(XyzzW) + (size_t)max_tasks * 4));  // per-task (S, T) + hot-bucket id
+    PLK_TRY(ctx->msm_e.reserve((size_t)max_tasks * (2 * FINE + MSM_THREADS) * sizeof(XyzzW)));  // lane partials + overflow rows
     PLK_TRY(ctx->msm_d.reserve((size_t)p.windows * sizeof(G1Xyzz)));                             // window sums
     uint32_t *hist = ctx->msm_a.as<uint32_t>(), *bin_start = hist + total_bins, *task_start = bin_start + total_bins + 1;
-    uint32_t *task_bin = task_start + total_bins + 1;
     uint32_t *entries = ctx->msm_b.as<uint32_t>();
-    G1Xyzz *task_out = ctx->msm_c.as<G1Xyzz>(), *window_out = ctx->msm_d.as<G1Xyzz>();
+    XyzzW *task_out = ctx->msm_c.as<XyzzW>();
+    uint32_t *task_heavy = reinterpret_cast<uint32_t *>(task_out + 2 * (size_t)max_tasks);
+    XyzzW *partials = ctx->msm_e.as<XyzzW>(), *overflow = partials + (size_t)max_tasks * 2 * FINE;
+    G1Xyzz *window_out = ctx->msm_d.as<G1Xyzz>();
 
     PLK_HIP(hipMemsetAsync(hist, 0, total_bins * sizeof(uint32_t), stream));
     const uint32_t pblocks = (uint32_t)((n + SCALARS_PER_BLOCK - 1) / SCALARS_PER_BLOCK);
@@ -397,9 +445,11 @@ int32_t msm_enqueue(plk_ctx *ctx, const Fr *scalars_dev, uint64_t n, uint64_t ba
     hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks), dim3(MSM_THREADS), plds, stream, scalars_dev, p, hist, (const uint32_t *)bin_start, entries);
     if (ctx->ev_on) PLK_HIP(hipEventRecord(ctx->ev[0], stream));
     hipLaunchKernelGGL(msm_accumulate, dim3(max_tasks), dim3(MSM_THREADS), 0, stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
-                       (const uint32_t *)task_start, task_out, task_bin, p);
+                       (const uint32_t *)task_start, partials, overflow, task_heavy, p);
     if (ctx->ev_on) PLK_HIP(hipEventRecord(ctx->ev[1], stream));
-    hipLaunchKernelGGL(msm_window_sums, dim3(p.windows), dim3(MSM_THREADS), 0, stream, (const G1Xyzz *)task_out, (const uint32_t *)task_start, window_out, p.nbins);
+    hipLaunchKernelGGL(msm_task_reduce, dim3((max_tasks * 16 + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
+                       (const XyzzW *)partials, (const XyzzW *)overflow, (const uint32_t *)task_heavy, (const uint32_t *)task_start, task_out, total_bins);
+    hipLaunchKernelGGL(msm_window_sums, dim3(p.windows), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins);
     PLK_HIP(hipGetLastError());
     PLK_TRY(ensure_pinned(ctx, p.windows * sizeof(G1Xyzz)));
     PLK_HIP(hipMemcpyAsync(ctx->pinned, window_out, p.windows * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));

@@ -93,7 +93,7 @@ void plk_destroy(plk_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
     for (void *p : ctx->coset_allocs) (void)hipFree(p);
-    ctx->tables.release(); ctx->ntt_scratch.release(); ctx->srs_own.release();
+    ctx->tables.release(); ctx->ntt_scratch.release(); ctx->srs_own.release(); ctx->srs_w.release();
     ctx->msm_a.release(); ctx->msm_b.release(); ctx->msm_c.release(); ctx->msm_d.release(); ctx->msm_e.release();
     ctx->stage.release(); ctx->poly_tmp.release(); ctx->poly_tmp2.release(); ctx->prove_ws.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -117,6 +117,7 @@ int32_t plk_srs_upload(plk_ctx *ctx, const plk_g1_affine *bases, uint64_t n) {
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->srs = ctx->srs_own.p;
     ctx->srs_n = n;
+    ctx->srs_w_valid = false;
     return PLK_OK;
 }
 
@@ -124,6 +125,7 @@ int32_t plk_srs_set_dev(plk_ctx *ctx, const void *bases_dev, uint64_t n) {
     if (!ctx || !bases_dev || n == 0) { set_error("plk_srs_set_dev: bad argument"); return PLK_ERR_ARG; }
     ctx->srs = bases_dev;
     ctx->srs_n = n;
+    ctx->srs_w_valid = false;
     return PLK_OK;
 }
 

@@ -54,6 +54,7 @@ extern "C" int32_t plk_srs_generate(plk_ctx *ctx, uint64_t n, uint64_t start, ui
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->srs = ctx->srs_own.p;
     ctx->srs_n = n;
+    ctx->srs_w_valid = false;
     return PLK_OK;
 }
 
