@@ -53,11 +53,13 @@ struct plk_ctx {
     int num_cus = 0;
     // NTT tables (device): omega_{2^28} powers forward / inverse, coset generator 7 and 7^-1
     plk::DevBuf tables;
-    plk::PowTable tw_fwd, tw_inv;            // omega_{2^28}^{+-e}
+    plk::PowTable tw_fwd, tw_inv;            // omega_{2^28}^{+-e}, external Montgomery form (R = 2^256)
+    plk::PowTable tw_fwd_w, tw_inv_w;        // the same powers in the 2^261 domain of field29.cuh (NTT passes)
     std::map<std::vector<uint32_t>, plk::PowTable> coset_tabs;   // keyed by the 8 limbs of the shift
     std::vector<void *> coset_allocs;
     std::map<std::vector<uint32_t>, plk::Fr> inv_cache;
     plk::Fr n_inv[plk::MAX_LOG_N + 1];      // 2^-k
+    plk::Fr n_inv_w[plk::MAX_LOG_N + 1];    // 2^-k in the 2^261 domain
     plk::DevBuf ntt_scratch;                 // ping-pong buffer for the transposing final pass
     // SRS
     const void *srs = nullptr;               // device, Montgomery affine, 64 B per point

@@ -22,6 +22,7 @@
 #include "ctx.h"
 #include "ntt.h"
 #include "poly.h"
+#include "field29.cuh"
 
 namespace plk {
 
@@ -41,40 +42,65 @@ struct NttPassArgs {
     uint32_t has_scale;
 };
 
-__device__ __forceinline__ Fr pow2l(const PowTable &t, uint32_t e) {
-    Fr lo = load_fp(t.lo + (e & (POW_TAB - 1)));
-    Fr hi = load_fp(t.hi + (e >> POW_SPLIT));
-    return mul(lo, hi);
+// ---- all butterfly arithmetic runs on the carry-free 9 x 29-bit layer (field29.cuh): data words are
+// ---- re-sliced, never converted; the constants (twiddles, coset powers, 1/n) live in its 2^261 domain.
+__device__ __forceinline__ FrW9 ldw(const Fr *p) { return unpack<FrW>(load_fp(p)); }
+
+__device__ __forceinline__ FrW9 pow2l_w(const PowTable &t, uint32_t e) {
+    return mulw(ldw(t.lo + (e & (POW_TAB - 1))), ldw(t.hi + (e >> POW_SPLIT)));
 }
 
 __device__ __forceinline__ uint32_t brev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
+// LDS tile: 9 limbs per element as two 16-byte planes and one 4-byte plane
 struct LdsTile {
     u32x4 *p0, *p1;
-    __device__ __forceinline__ Fr get(uint32_t i) const {
+    uint32_t *p2;
+    __device__ __forceinline__ FrW9 get(uint32_t i) const {
         u32x4 a = p0[i], b = p1[i];
-        Fr r;
+        FrW9 r;
         r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-        r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+        r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = p2[i];
         return r;
     }
-    __device__ __forceinline__ void put(uint32_t i, const Fr &v) const {
+    __device__ __forceinline__ void put(uint32_t i, const FrW9 &v) const {
         p0[i] = u32x4{v.l[0], v.l[1], v.l[2], v.l[3]};
         p1[i] = u32x4{v.l[4], v.l[5], v.l[6], v.l[7]};
+        p2[i] = v.l[8];
     }
 };
 
 // omega_R^i (i < R/2) straight out of the hi table: omega_{2^28}^(i << (28 - log_r)), low part 0
-__device__ __forceinline__ Fr small_tw(const PowTable &t, uint32_t i, uint32_t log_r) {
-    return load_fp(t.hi + (i << (POW_SPLIT - log_r)));
+__device__ __forceinline__ FrW9 small_tw(const PowTable &t, uint32_t i, uint32_t log_r) {
+    return ldw(t.hi + (i << (POW_SPLIT - log_r)));
 }
 
-// Passes 1..p-1: strided columns, DIT, in place, post-multiplied by the inter-digit twiddle.
+// log2(R) radix-2 DIT stages over an LDS tile of R rows x C columns (element (i, c) at i*pitch + c),
+// input rows in bit-reversed order.  Values stay lazily reduced: each stage adds at most 2p.
+__device__ __forceinline__ void dit_stages(const LdsTile &L, const PowTable &tw, uint32_t log_r, uint32_t log_c, uint32_t pitch, uint32_t tid) {
+    const uint32_t C = 1u << log_c, half_tile = 1u << (log_r + log_c - 1);
+    for (uint32_t s = 0; s < log_r; s++) {
+        const uint32_t h = 1u << s;
+        for (uint32_t b = tid; b < half_tile; b += NTT_THREADS) {
+            uint32_t c = b & (C - 1), j = b >> log_c;
+            uint32_t jl = j & (h - 1);
+            uint32_t i0 = (((j >> s) << (s + 1)) | jl), i1 = i0 + h;
+            FrW9 u = L.get(i0 * pitch + c), v = L.get(i1 * pitch + c);
+            if (s) v = mulw(v, small_tw(tw, jl << (log_r - s - 1), log_r));
+            else v = normw(v);
+            L.put(i0 * pitch + c, addn(u, v));
+            L.put(i1 * pitch + c, sub2(u, v));               // v < 2p after the product (stage 0: inputs < 1.1p)
+        }
+        __syncthreads();
+    }
+}
+
+// Passes 1..p-1: strided columns, in place, post-multiplied by the inter-digit twiddle.
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t log_r = a.log_r, log_c = a.log_c, C = 1u << log_c;
     const uint32_t T = 1u << (log_r + log_c);
-    LdsTile L{reinterpret_cast<u32x4 *>(smem), reinterpret_cast<u32x4 *>(smem) + T};
+    LdsTile L{reinterpret_cast<u32x4 *>(smem), reinterpret_cast<u32x4 *>(smem) + T, reinterpret_cast<uint32_t *>(reinterpret_cast<u32x4 *>(smem) + 2 * T)};
     const uint32_t tid = threadIdx.x, t = blockIdx.x;
     const uint32_t tiles_log = a.log_inner - log_c;
     const uint32_t o = t >> tiles_log, c0 = (t & ((1u << tiles_log) - 1)) << log_c;
@@ -82,41 +108,28 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
 
     for (uint32_t idx = tid; idx < T; idx += NTT_THREADS) {
         uint32_t c = idx & (C - 1), p = idx >> log_c;
-        size_t g = base + ((size_t)brev(p, log_r) << a.log_inner) + c;
-        Fr v = load_fp(a.in + g);
-        if (a.pre.lo) v = mul(v, pow2l(a.pre, (uint32_t)g));
+        size_t g = base + ((size_t)brev(p, log_r) << a.log_inner) + c;     // rows fetched in bit-reversed order
+        FrW9 v = ldw(a.in + g);
+        if (a.pre.lo) v = mulw(v, pow2l_w(a.pre, (uint32_t)g));
         L.put(idx, v);
     }
     __syncthreads();
-    for (uint32_t s = 0; s < log_r; s++) {
-        const uint32_t h = 1u << s;
-        for (uint32_t b = tid; b < (T >> 1); b += NTT_THREADS) {
-            uint32_t c = b & (C - 1), j = b >> log_c;
-            uint32_t jl = j & (h - 1);
-            uint32_t i0 = (((j >> s) << (s + 1)) | jl), i1 = i0 + h;
-            Fr u = L.get((i0 << log_c) + c), v = L.get((i1 << log_c) + c);
-            if (s) v = mul(v, small_tw(a.tw, jl << (log_r - s - 1), log_r));
-            L.put((i0 << log_c) + c, add(u, v));
-            L.put((i1 << log_c) + c, sub(u, v));
-        }
-        __syncthreads();
-    }
+    dit_stages(L, a.tw, log_r, log_c, C, tid);
     const uint32_t eshift = MAX_LOG_N - (log_r + a.log_inner);
     for (uint32_t idx = tid; idx < T; idx += NTT_THREADS) {
         uint32_t c = idx & (C - 1), k = idx >> log_c;
         uint32_t e = (k * (c0 + c)) << eshift;
-        Fr v = mul(L.get(idx), pow2l(a.tw, e));
-        store_fp(a.out + base + ((size_t)k << a.log_inner) + c, v);
+        FrW9 v = mulw(L.get(idx), pow2l_w(a.tw, e));                          // < 1.1p: fits 256 bits, stays lazy
+        store_fp(a.out + base + ((size_t)k << a.log_inner) + c, pack<FrParams>(v));
     }
 }
 
-// Last pass: C contiguous rows of R elements, DIF, scattered to the digit-reversed output index.
+// Last pass: C contiguous rows of R elements, scattered to the digit-reversed output index, canonical.
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t log_r = a.log_r, log_c = a.log_c, C = 1u << log_c, R = 1u << log_r;
     const uint32_t T = 1u << (log_r + log_c);
-    const uint32_t pitch = C | 1;              // odd pitch: the transposing LDS write is conflict-free
-    LdsTile L{reinterpret_cast<u32x4 *>(smem), reinterpret_cast<u32x4 *>(smem) + R * pitch};
+    LdsTile L{reinterpret_cast<u32x4 *>(smem), reinterpret_cast<u32x4 *>(smem) + T, reinterpret_cast<uint32_t *>(reinterpret_cast<u32x4 *>(smem) + 2 * T)};
     const uint32_t tid = threadIdx.x, t = blockIdx.x;
     const uint32_t kb_log = a.log_r1 - log_c, log_m = a.log_m1 + a.log_m2;
     const uint32_t k1_0 = (t & ((1u << kb_log) - 1)) << log_c, mu = t >> kb_log;
@@ -125,35 +138,22 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
         uint32_t n = idx & (R - 1), c = idx >> log_r;
         size_t rho = ((size_t)(k1_0 + c) << log_m) + mu;
         size_t g = (rho << log_r) + n;
-        Fr v = load_fp(a.in + g);
-        if (a.pre.lo) v = mul(v, pow2l(a.pre, (uint32_t)g));
-        L.put(n * pitch + c, v);
+        FrW9 v = ldw(a.in + g);
+        if (a.pre.lo) v = mulw(v, pow2l_w(a.pre, (uint32_t)g));
+        L.put(brev(n, log_r) * C + c, v);                                    // bit reversal as an LDS scatter
     }
     __syncthreads();
-    for (int s = (int)log_r - 1; s >= 0; s--) {
-        const uint32_t h = 1u << s;
-        for (uint32_t b = tid; b < (T >> 1); b += NTT_THREADS) {
-            uint32_t c = b & (C - 1), j = b >> log_c;
-            uint32_t jl = j & (h - 1);
-            uint32_t i0 = (((j >> s) << (s + 1)) | jl), i1 = i0 + h;
-            Fr u = L.get(i0 * pitch + c), v = L.get(i1 * pitch + c);
-            Fr d = sub(u, v);
-            if (s) d = mul(d, small_tw(a.tw, jl << (log_r - s - 1), log_r));
-            L.put(i0 * pitch + c, add(u, v));
-            L.put(i1 * pitch + c, d);
-        }
-        __syncthreads();
-    }
+    dit_stages(L, a.tw, log_r, log_c, C, tid);
     const uint32_t k2 = mu >> a.log_m2, k3 = mu & ((1u << a.log_m2) - 1);
     const size_t drev = (size_t)k2 + ((size_t)k3 << a.log_m1);
-    for (uint32_t idx = tid; idx < T; idx += NTT_THREADS) {
-        uint32_t c = idx & (C - 1), p = idx >> log_c;
-        uint32_t k = brev(p, log_r);
+    const FrW9 last = a.has_scale ? unpack<FrW>(a.scale) : w_one<FrW>();     // 1/n, or the layer's "one": the final
+    for (uint32_t idx = tid; idx < T; idx += NTT_THREADS) {                  // product brings the value below 2p
+        uint32_t c = idx & (C - 1), k = idx >> log_c;
         size_t o = (size_t)(k1_0 + c) + (drev << a.log_r1) + ((size_t)k << (a.log_n - log_r));
-        Fr v = L.get(p * pitch + c);
-        if (a.post.lo) v = mul(v, pow2l(a.post, (uint32_t)o));
-        if (a.has_scale) v = mul(v, a.scale);
-        store_fp(a.out + o, v);
+        FrW9 v = L.get(k * C + c);
+        if (a.post.lo) v = mulw(v, pow2l_w(a.post, (uint32_t)o));
+        v = csub_p(mulw(v, last));
+        store_fp(a.out + o, pack<FrParams>(v));
     }
 }
 
@@ -179,13 +179,23 @@ Fr ntt_omega(uint32_t log_n) {
     return w;
 }
 
-static int32_t make_pow_table(plk_ctx *ctx, const Fr &base, PowTable *out, void **alloc_out) {
+// the same table with every entry moved into the 2^261 domain of field29.cuh (x*2^256 -> x*2^261)
+__global__ void table_to_w(Fr *out, const Fr *in, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) store_fp(out + i, pack<FrParams>(csub_p(w_from_s(unpack<FrW>(load_fp(in + i))))));
+}
+
+// allocates [lo | hi] in the external domain followed by [lo | hi] in the W domain
+static int32_t make_pow_table(plk_ctx *ctx, const Fr &base, PowTable *out, PowTable *out_w, void **alloc_out) {
     Fr *buf = nullptr;
-    PLK_HIP(hipMalloc(&buf, sizeof(Fr) * 2 * POW_TAB));
+    PLK_HIP(hipMalloc(&buf, sizeof(Fr) * 4 * POW_TAB));
     hipLaunchKernelGGL(fill_pow_table, dim3(2 * POW_TAB / 256), dim3(256), 0, ctx->stream, buf, buf + POW_TAB, base);
+    hipLaunchKernelGGL(table_to_w, dim3(2 * POW_TAB / 256), dim3(256), 0, ctx->stream, buf + 2 * POW_TAB, (const Fr *)buf, 2 * POW_TAB);
     PLK_HIP(hipGetLastError());
     out->lo = buf;
     out->hi = buf + POW_TAB;
+    out_w->lo = buf + 2 * POW_TAB;
+    out_w->hi = buf + 3 * POW_TAB;
     if (alloc_out) *alloc_out = buf;
     return PLK_OK;
 }
@@ -214,19 +224,22 @@ int32_t ntt_init_tables(plk_ctx *ctx) {
     for (uint32_t i = 1; i <= MAX_LOG_N; i++) ctx->n_inv[i] = mul(ctx->n_inv[i - 1], half);
     Fr w = root28();
     void *a = nullptr, *b = nullptr;
-    PLK_TRY(make_pow_table(ctx, w, &ctx->tw_fwd, &a));
-    PLK_TRY(make_pow_table(ctx, inv(w), &ctx->tw_inv, &b));
+    PLK_TRY(make_pow_table(ctx, w, &ctx->tw_fwd, &ctx->tw_fwd_w, &a));
+    PLK_TRY(make_pow_table(ctx, inv(w), &ctx->tw_inv, &ctx->tw_inv_w, &b));
+    for (uint32_t i = 0; i <= MAX_LOG_N; i++) ctx->n_inv_w[i] = mul(ctx->n_inv[i], from_u64<FrParams>(32));   // x*2^256 -> x*2^261
     ctx->coset_allocs.push_back(a);
     ctx->coset_allocs.push_back(b);
     return PLK_OK;
 }
 
+// returns the power table of g in the W domain (what the NTT passes consume)
 int32_t ntt_coset_table(plk_ctx *ctx, const Fr &g, PowTable *out) {
     std::vector<uint32_t> key(g.l, g.l + 8);
     auto it = ctx->coset_tabs.find(key);
     if (it != ctx->coset_tabs.end()) { *out = it->second; return PLK_OK; }
     void *a = nullptr;
-    PLK_TRY(make_pow_table(ctx, g, out, &a));
+    PowTable ext;
+    PLK_TRY(make_pow_table(ctx, g, &ext, out, &a));
     ctx->coset_allocs.push_back(a);
     ctx->coset_tabs[key] = *out;
     return PLK_OK;
@@ -264,7 +277,7 @@ int32_t ntt_dev(plk_ctx *ctx, Fr *data, uint32_t log_n, bool inverse, const Fr *
 
     NttPassArgs a{};
     a.log_n = log_n;
-    a.tw = inverse ? ctx->tw_inv : ctx->tw_fwd;
+    a.tw = inverse ? ctx->tw_inv_w : ctx->tw_fwd_w;
     // ping-pong: pass 1 data -> scratch, middle passes in place in scratch, last pass scratch -> data
     uint32_t rem = log_n;
     for (uint32_t i = 0; i + 1 < p; i++) {
@@ -275,7 +288,7 @@ int32_t ntt_dev(plk_ctx *ctx, Fr *data, uint32_t log_n, bool inverse, const Fr *
         a.pre = (i == 0) ? pre : PowTable{};
         a.post = PowTable{}; a.has_scale = 0;
         uint32_t tiles = (uint32_t)(n >> (a.log_r + a.log_c));
-        size_t lds = (size_t)2 * 16 << (a.log_r + a.log_c);
+        size_t lds = (size_t)36 << (a.log_r + a.log_c);
         hipLaunchKernelGGL(ntt_pass_cols, dim3(tiles), dim3(NTT_THREADS), lds, stream, a);
     }
     {
@@ -291,9 +304,9 @@ int32_t ntt_dev(plk_ctx *ctx, Fr *data, uint32_t log_n, bool inverse, const Fr *
         a.pre = (p == 1) ? pre : PowTable{};
         a.post = post;
         a.has_scale = inverse ? 1 : 0;
-        if (inverse) a.scale = ctx->n_inv[log_n];
+        if (inverse) a.scale = ctx->n_inv_w[log_n];
         uint32_t tiles = (uint32_t)(n >> (a.log_r + a.log_c));
-        size_t lds = (size_t)2 * 16 * (((size_t)1 << a.log_r) * ((1u << a.log_c) | 1));
+        size_t lds = (size_t)36 << (a.log_r + a.log_c);
         hipLaunchKernelGGL(ntt_pass_rows, dim3(tiles), dim3(NTT_THREADS), lds, stream, a);
     }
     PLK_HIP(hipGetLastError());
