@@ -77,6 +77,9 @@ int32_t plk_lde4_dev(plk_ctx *ctx, const void *coeffs_dev, uint32_t log_n, void 
  *      the 11 commitments of prove): sum_i scalars[i] * srs[base_offset + i], scalars Montgomery Fr. */
 int32_t plk_msm_g1(plk_ctx *ctx, const plk_fr *scalars_host, uint64_t n, uint64_t base_offset, plk_g1_affine *out);
 int32_t plk_msm_g1_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, plk_g1_affine *out, void *stream);
+/* `count` commitments of equal length against the same bases in one pass of the kernels (the 4 wire /
+ * 4 quotient / 2 opening commitments of a proof, the 11 of a verification key)                       */
+int32_t plk_msm_g1_batch_dev(plk_ctx *ctx, const void *const *scalars_dev, uint32_t count, uint64_t n, uint64_t base_offset, plk_g1_affine *out, void *stream);
 /* the same sum left in Jacobian form, for cross-rank combination (multi-GPU shards) */
 int32_t plk_msm_g1_partial_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, plk_g1_jacobian *out, void *stream);
 /* enqueue only (no host sync): window sums land in an internal device buffer; finish with _finish */

@@ -164,6 +164,13 @@ class Context:
         _check(lib().plk_msm_g1_dev(self._h, _devptr(ptr), ctypes.c_uint64(n), ctypes.c_uint64(base_offset), _np(out), _stream(stream)))
         return out
 
+    def msm_batch_dev(self, ptrs, n, base_offset=0, stream=None):
+        """several commitments (same length, same bases) in one pass; returns [count, 8] affine points"""
+        arr = (ctypes.c_void_p * len(ptrs))(*[_devptr(p) for p in ptrs])
+        out = np.zeros((len(ptrs), 8), dtype=np.uint64)
+        _check(lib().plk_msm_g1_batch_dev(self._h, arr, ctypes.c_uint32(len(ptrs)), ctypes.c_uint64(n), ctypes.c_uint64(base_offset), _np(out), _stream(stream)))
+        return out
+
     def msm_partial_dev(self, ptr, n, base_offset=0, stream=None):
         out = np.zeros(12, dtype=np.uint64)
         _check(lib().plk_msm_g1_partial_dev(self._h, _devptr(ptr), ctypes.c_uint64(n), ctypes.c_uint64(base_offset), _np(out), _stream(stream)))

@@ -74,7 +74,7 @@ struct plk_ctx {
     plk::DevBuf stage;                       // host<->device staging for the host-pointer API
     void *pinned = nullptr;                  // small pinned host buffer for results
     size_t pinned_cap = 0;
-    uint32_t msm_windows = 0, msm_c_bits = 0, msm_pending_parts = 0;
+    uint32_t msm_windows = 0, msm_c_bits = 0, msm_pending_parts = 0, msm_batch = 1;
     hipStream_t msm_stream = nullptr;
     std::vector<double> timings;
     // optional HIP-event bracket around the dominant kernel of the last MSM (bench roofline)

@@ -36,13 +36,18 @@ constexpr uint32_t SCALARS_PER_BLOCK = 4096;      // partition kernels
 constexpr uint32_t TASK_MAX = CHUNK;
 constexpr uint32_t HEAVY = 320;                   // per-chunk bucket population handled cooperatively
 
+constexpr uint32_t MSM_MAX_BATCH = 8;              // commitments sharing one pass over the same bases
+
 struct MsmParams {
     uint32_t n;
     uint32_t c;               // window bits
-    uint32_t windows;         // W
+    uint32_t windows;         // W per commitment
     uint32_t coarse_bits;     // c - 1 - FINE_BITS
     uint32_t nbins;           // 1 << coarse_bits
+    uint32_t batch;           // number of scalar vectors (same n, same bases); "global window" = m * W + w
 };
+
+struct ScalarSet { const Fr *v[MSM_MAX_BATCH]; };
 
 // -------------------------------------------------------------------------- scalar recoding
 struct Digits {
@@ -76,12 +81,15 @@ __device__ __forceinline__ Digits load_scalar(const Fr *scalars, uint32_t i) {
 
 // ------------------------------------------------------------------- coarse partition kernels
 template <bool SCATTER>
-__global__ void __launch_bounds__(MSM_THREADS) msm_partition(const Fr *scalars, MsmParams p, uint32_t *hist_or_cursor,
+__global__ void __launch_bounds__(MSM_THREADS) msm_partition(ScalarSet set, MsmParams p, uint32_t *hist_or_cursor,
                                                               const uint32_t *bin_start, uint32_t *entries) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *lh = reinterpret_cast<uint32_t *>(smem);                 // [W * nbins] counts
     uint32_t *lbase = lh + p.windows * p.nbins;                        // [W * nbins] reserved bases (SCATTER)
-    const uint32_t total_bins = p.windows * p.nbins;
+    const uint32_t total_bins = p.windows * p.nbins;                   // per commitment
+    const Fr *scalars = set.v[blockIdx.y];
+    hist_or_cursor += blockIdx.y * total_bins;
+    if (SCATTER) bin_start += blockIdx.y * total_bins;
     const uint32_t tid = threadIdx.x;
     const uint32_t first = blockIdx.x * SCALARS_PER_BLOCK;
     for (uint32_t b = tid; b < total_bins; b += MSM_THREADS) lh[b] = 0;
@@ -206,15 +214,17 @@ __device__ __forceinline__ void accumulate_run(XyzzW &acc, const G1Affine *bases
 //     lane, so the lanes of a wave walk runs of (nearly) equal length and short waves retire early
 //  3. the most populated bucket, when hotter than HEAVY (repeated scalars), is instead sliced over all
 //     256 lanes into an overflow row
-// Only mixed additions happen here (10 products each, ~25 KB of code, <= 128 VGPRs); every lane leaves
+// Only mixed additions happen here (10 products each, ~25 KB of code).  One wave per SIMD already saturates the
+// VALU (tools/ubench_w: 14.6 G mixed-adds/s at any occupancy, 25 % less when squeezed into 128 VGPRs with
+// spills), so the register budget is the full 256 and nothing is spilled.  Every lane leaves
 // its partial sum in `partials[task][2*bucket + half]` and kernel B folds them.
-__global__ void __launch_bounds__(MSM_THREADS, 4) msm_accumulate(const G1Affine *bases, const uint32_t *entries,
+__global__ void __launch_bounds__(MSM_THREADS, 2) msm_accumulate(const G1Affine *bases, const uint32_t *entries,
                                                                   const uint32_t *bin_start, const uint32_t *task_start,
                                                                   XyzzW *partials, XyzzW *overflow, uint32_t *task_heavy, MsmParams p) {
     __shared__ uint32_t sorted[CHUNK];
     __shared__ uint32_t cnt[FINE], start[FINE + 1], cursor[FINE], order[FINE];
     const uint32_t tid = threadIdx.x, task = blockIdx.x;
-    const uint32_t total_bins = p.windows * p.nbins;
+    const uint32_t total_bins = p.batch * p.windows * p.nbins;
     if (task >= task_start[total_bins]) return;
     uint32_t blo = 0, bhi = total_bins;                       // bin = last index with task_start[bin] <= task
     while (bhi - blo > 1) { uint32_t mid = (blo + bhi) >> 1; if (task_start[mid] <= task) blo = mid; else bhi = mid; }
@@ -391,10 +401,11 @@ static uint32_t pick_window_bits(uint64_t n) {
 
 int32_t ensure_pinned(plk_ctx *ctx, size_t bytes);
 
-int32_t msm_enqueue(plk_ctx *ctx, const Fr *scalars_dev, uint64_t n, uint64_t base_offset, hipStream_t stream) {
+int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t batch, uint64_t n, uint64_t base_offset, hipStream_t stream) {
     if (!ctx->srs) { set_error("msm: no SRS uploaded (plk_srs_upload)"); return PLK_ERR_SRS; }
     if (base_offset + n > ctx->srs_n) { set_error("msm: SRS too small for this commitment"); return PLK_ERR_SRS; }
     if (n >= (1ull << 24) + 1) { set_error("msm: more than 2^24 terms per call (shard the commitment)"); return PLK_ERR_SIZE; }
+    if (batch < 1 || batch > MSM_MAX_BATCH) { set_error("msm: batch must be 1..8"); return PLK_ERR_ARG; }
     if (!ctx->srs_w_valid) {                                     // resident copy of the SRS in the 2^261 domain of the lazy field layer
         PLK_TRY(ctx->srs_w.reserve(ctx->srs_n * sizeof(G1Affine)));
         hipLaunchKernelGGL(srs_to_w_kernel, dim3((uint32_t)((ctx->srs_n + 255) / 256)), dim3(256), 0, stream,
@@ -405,16 +416,18 @@ int32_t msm_enqueue(plk_ctx *ctx, const Fr *scalars_dev, uint64_t n, uint64_t ba
     const G1Affine *bases = ctx->srs_w.as<G1Affine>() + base_offset;
     ctx->msm_pending_parts = 0;
     ctx->msm_windows = 0;
+    ctx->msm_batch = batch;
     if (n == 0) return PLK_OK;
     if (n < 4096) {
         uint32_t blocks = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
-        PLK_TRY(ctx->msm_d.reserve(blocks * sizeof(G1Xyzz)));
-        hipLaunchKernelGGL(msm_naive, dim3(blocks), dim3(MSM_THREADS), 0, stream, bases, scalars_dev, (uint32_t)n, ctx->msm_d.as<G1Xyzz>());
+        PLK_TRY(ctx->msm_d.reserve((size_t)batch * blocks * sizeof(G1Xyzz)));
+        for (uint32_t m = 0; m < batch; m++)
+            hipLaunchKernelGGL(msm_naive, dim3(blocks), dim3(MSM_THREADS), 0, stream, bases, scalars_dev[m], (uint32_t)n, ctx->msm_d.as<G1Xyzz>() + (size_t)m * blocks);
         PLK_HIP(hipGetLastError());
         ctx->msm_pending_parts = blocks;
         ctx->msm_c_bits = 0;
-        PLK_TRY(ensure_pinned(ctx, blocks * sizeof(G1Xyzz)));
-        PLK_HIP(hipMemcpyAsync(ctx->pinned, ctx->msm_d.p, blocks * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
+        PLK_TRY(ensure_pinned(ctx, (size_t)batch * blocks * sizeof(G1Xyzz)));
+        PLK_HIP(hipMemcpyAsync(ctx->pinned, ctx->msm_d.p, (size_t)batch * blocks * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
         return PLK_OK;
     }
     MsmParams p;
@@ -423,13 +436,16 @@ int32_t msm_enqueue(plk_ctx *ctx, const Fr *scalars_dev, uint64_t n, uint64_t ba
     p.windows = 254 / p.c + 1;
     p.coarse_bits = p.c - 1 - FINE_BITS;
     p.nbins = 1u << p.coarse_bits;
-    const uint32_t total_bins = p.windows * p.nbins;
-    const uint32_t max_tasks = total_bins + (uint32_t)(((uint64_t)p.windows * n) / TASK_MAX) + 1;
+    p.batch = batch;
+    ScalarSet set{};
+    for (uint32_t m = 0; m < batch; m++) set.v[m] = scalars_dev[m];
+    const uint32_t bins_per = p.windows * p.nbins, total_bins = batch * bins_per, total_windows = batch * p.windows;
+    const uint32_t max_tasks = total_bins + (uint32_t)(((uint64_t)total_windows * n) / TASK_MAX) + 1;
     PLK_TRY(ctx->msm_a.reserve((size_t)(3 * total_bins + 4) * sizeof(uint32_t)));               // hist/cursor, bin_start, task_start
-    PLK_TRY(ctx->msm_b.reserve((size_t)p.windows * n * sizeof(uint32_t)));                       // entries
+    PLK_TRY(ctx->msm_b.reserve((size_t)total_windows * n * sizeof(uint32_t)));                   // entries
     PLK_TRY(ctx->msm_c.reserve((size_t)max_tasks * 2 * sizeof(XyzzW) + (size_t)max_tasks * 4));  // per-task (S, T) + hot-bucket id
     PLK_TRY(ctx->msm_e.reserve((size_t)max_tasks * (2 * FINE + MSM_THREADS) * sizeof(XyzzW)));  // lane partials + overflow rows
-    PLK_TRY(ctx->msm_d.reserve((size_t)p.windows * sizeof(G1Xyzz)));                             // window sums
+    PLK_TRY(ctx->msm_d.reserve((size_t)total_windows * sizeof(G1Xyzz)));                         // window sums
     uint32_t *hist = ctx->msm_a.as<uint32_t>(), *bin_start = hist + total_bins, *task_start = bin_start + total_bins + 1;
     uint32_t *entries = ctx->msm_b.as<uint32_t>();
     XyzzW *task_out = ctx->msm_c.as<XyzzW>();
@@ -439,23 +455,27 @@ int32_t msm_enqueue(plk_ctx *ctx, const Fr *scalars_dev, uint64_t n, uint64_t ba
 
     PLK_HIP(hipMemsetAsync(hist, 0, total_bins * sizeof(uint32_t), stream));
     const uint32_t pblocks = (uint32_t)((n + SCALARS_PER_BLOCK - 1) / SCALARS_PER_BLOCK);
-    const size_t plds = (size_t)2 * total_bins * sizeof(uint32_t);
-    hipLaunchKernelGGL(msm_partition<false>, dim3(pblocks), dim3(MSM_THREADS), plds, stream, scalars_dev, p, hist, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+    const size_t plds = (size_t)2 * bins_per * sizeof(uint32_t);
+    hipLaunchKernelGGL(msm_partition<false>, dim3(pblocks, batch), dim3(MSM_THREADS), plds, stream, set, p, hist, (const uint32_t *)nullptr, (uint32_t *)nullptr);
     hipLaunchKernelGGL(msm_scan_bins, dim3(1), dim3(1024), 0, stream, hist, bin_start, task_start, total_bins);
-    hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks), dim3(MSM_THREADS), plds, stream, scalars_dev, p, hist, (const uint32_t *)bin_start, entries);
+    hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks, batch), dim3(MSM_THREADS), plds, stream, set, p, hist, (const uint32_t *)bin_start, entries);
     if (ctx->ev_on) PLK_HIP(hipEventRecord(ctx->ev[0], stream));
     hipLaunchKernelGGL(msm_accumulate, dim3(max_tasks), dim3(MSM_THREADS), 0, stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
                        (const uint32_t *)task_start, partials, overflow, task_heavy, p);
     if (ctx->ev_on) PLK_HIP(hipEventRecord(ctx->ev[1], stream));
     hipLaunchKernelGGL(msm_task_reduce, dim3((max_tasks * 16 + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
                        (const XyzzW *)partials, (const XyzzW *)overflow, (const uint32_t *)task_heavy, (const uint32_t *)task_start, task_out, total_bins);
-    hipLaunchKernelGGL(msm_window_sums, dim3(p.windows), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins);
+    hipLaunchKernelGGL(msm_window_sums, dim3(total_windows), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins);
     PLK_HIP(hipGetLastError());
-    PLK_TRY(ensure_pinned(ctx, p.windows * sizeof(G1Xyzz)));
-    PLK_HIP(hipMemcpyAsync(ctx->pinned, window_out, p.windows * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
+    PLK_TRY(ensure_pinned(ctx, total_windows * sizeof(G1Xyzz)));
+    PLK_HIP(hipMemcpyAsync(ctx->pinned, window_out, total_windows * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
     ctx->msm_windows = p.windows;
     ctx->msm_c_bits = p.c;
     return PLK_OK;
+}
+
+int32_t msm_enqueue(plk_ctx *ctx, const Fr *scalars_dev, uint64_t n, uint64_t base_offset, hipStream_t stream) {
+    return msm_enqueue_batch(ctx, &scalars_dev, 1, n, base_offset, stream);
 }
 
 static host::HJac xyzz_host_to_jac(const uint64_t *v) {
@@ -472,21 +492,29 @@ static host::HJac xyzz_host_to_jac(const uint64_t *v) {
 }
 
 // waits for the stream, then folds the window sums (Horner, c doublings per window) on the host
-int32_t msm_finish(plk_ctx *ctx, hipStream_t stream, host::HJac *out) {
+int32_t msm_finish_batch(plk_ctx *ctx, hipStream_t stream, host::HJac *out) {
     using namespace host;
     PLK_HIP(hipStreamSynchronize(stream));
-    const uint64_t *raw = reinterpret_cast<const uint64_t *>(ctx->pinned);
-    HJac acc = HJac::inf();
-    if (ctx->msm_windows) {
-        for (int w = (int)ctx->msm_windows - 1; w >= 0; w--) {
-            for (uint32_t i = 0; i < ctx->msm_c_bits; i++) acc = jac_double(acc);
-            acc = jac_add(acc, xyzz_host_to_jac(raw + 16 * w));
+    for (uint32_t m = 0; m < ctx->msm_batch; m++) {
+        HJac acc = HJac::inf();
+        if (ctx->msm_windows) {
+            const uint64_t *raw = reinterpret_cast<const uint64_t *>(ctx->pinned) + (size_t)16 * m * ctx->msm_windows;
+            for (int w = (int)ctx->msm_windows - 1; w >= 0; w--) {
+                for (uint32_t i = 0; i < ctx->msm_c_bits; i++) acc = jac_double(acc);
+                acc = jac_add(acc, xyzz_host_to_jac(raw + 16 * w));
+            }
+        } else {
+            const uint64_t *raw = reinterpret_cast<const uint64_t *>(ctx->pinned) + (size_t)16 * m * ctx->msm_pending_parts;
+            for (uint32_t i = 0; i < ctx->msm_pending_parts; i++) acc = jac_add(acc, xyzz_host_to_jac(raw + 16 * i));
         }
-    } else {
-        for (uint32_t i = 0; i < ctx->msm_pending_parts; i++) acc = jac_add(acc, xyzz_host_to_jac(raw + 16 * i));
+        out[m] = acc;
     }
-    *out = acc;
     return PLK_OK;
+}
+
+int32_t msm_finish(plk_ctx *ctx, hipStream_t stream, host::HJac *out) {
+    if (ctx->msm_batch != 1) { set_error("msm_finish: a batch is pending"); return PLK_ERR_ARG; }
+    return msm_finish_batch(ctx, stream, out);
 }
 
 }  // namespace plk
@@ -520,6 +548,24 @@ int32_t plk_msm_g1_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64
     plk_g1_jacobian j;
     PLK_TRY(plk_msm_g1_partial_dev(ctx, scalars_dev, n, base_offset, &j, stream));
     return plk_g1_sum_jacobian(&j, 1, out);
+}
+
+int32_t plk_msm_g1_batch_dev(plk_ctx *ctx, const void *const *scalars_dev, uint32_t count, uint64_t n, uint64_t base_offset, plk_g1_affine *out, void *stream) {
+    if (!ctx || !scalars_dev || !out || count == 0) { set_error("plk_msm_g1_batch_dev: bad argument"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    for (uint32_t done = 0; done < count;) {
+        uint32_t b = count - done > MSM_MAX_BATCH ? MSM_MAX_BATCH : count - done;
+        PLK_TRY(msm_enqueue_batch(ctx, reinterpret_cast<const Fr *const *>(scalars_dev + done), b, n, base_offset, st));
+        host::HJac j[MSM_MAX_BATCH];
+        PLK_TRY(msm_finish_batch(ctx, st, j));
+        for (uint32_t k = 0; k < b; k++) {
+            host::HAffine a = host::jac_to_affine(j[k]);
+            memcpy(out[done + k].x, a.x.l, 32); memcpy(out[done + k].y, a.y.l, 32);
+        }
+        done += b;
+    }
+    return PLK_OK;
 }
 
 int32_t plk_msm_g1(plk_ctx *ctx, const plk_fr *scalars, uint64_t n, uint64_t base_offset, plk_g1_affine *out) {

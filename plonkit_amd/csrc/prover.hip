@@ -16,6 +16,8 @@
 #include "circuit.h"
 #include "keccak.h"
 #include <chrono>
+#include <thread>
+#include <algorithm>
 #include <cstring>
 
 namespace plk {
@@ -40,6 +42,19 @@ static int32_t commit(plk_ctx *ctx, const Fr *coef, uint64_t n, HAffine *out) {
     return PLK_OK;
 }
 
+// several commitments over the same SRS prefix in one pass of the MSM kernels
+static int32_t commit_many(plk_ctx *ctx, const Fr *const *coefs, uint32_t count, uint64_t n, HAffine *out) {
+    for (uint32_t done = 0; done < count;) {
+        uint32_t b = count - done > 8 ? 8 : count - done;
+        PLK_TRY(msm_enqueue_batch(ctx, coefs + done, b, n, 0, ctx->stream));
+        HJac j[8];
+        PLK_TRY(msm_finish_batch(ctx, ctx->stream, j));
+        for (uint32_t k = 0; k < b; k++) out[done + k] = jac_to_affine(j[k]);
+        done += b;
+    }
+    return PLK_OK;
+}
+
 struct Arena {
     DevBuf *buf; size_t off = 0;
     template <class T> T *take(size_t count) {
@@ -58,8 +73,15 @@ struct plk_setup {
     plk::DevBuf store;                     // one allocation holding everything below
     plk::Fr *sel_coef[7] = {nullptr}, *sel_vals[7] = {nullptr}, *sig_coef[4] = {nullptr}, *sig_vals[4] = {nullptr};
     uint32_t *gate_vars[4] = {nullptr};
+    // coset LDEs (4N evaluations on 7*<omega_4N>) of the 7 selectors, 4 sigmas and L_0: circuit constants,
+    // computed by the first proof and kept (the reference recomputes them in every prove_by_steps call
+    // because plonkit passes `None` precomputations, src/plonk.rs:156; the values are identical)
+    mutable plk::DevBuf lde_store;
+    mutable plk::Fr *lde[12] = {nullptr};
+    mutable bool lde_ready = false;
     uint64_t num_circuit_vars = 0;         // circom wires; temporaries follow
     std::vector<plk::WitnessOp> ops;       // linear forms defining the transpiler's temporaries
+    bool ops_independent = false;          // no temporary reads another temporary -> order-free evaluation
     std::vector<plk::WitnessTerm> op_terms;
 };
 
@@ -68,7 +90,7 @@ using namespace plk;
 extern "C" {
 
 uint64_t plk_setup_domain_size(const plk_setup *s) { return s ? s->N : 0; }
-void plk_setup_free(plk_setup *s) { if (s) { s->store.release(); delete s; } }
+void plk_setup_free(plk_setup *s) { if (s) { s->store.release(); s->lde_store.release(); delete s; } }
 
 int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
     if (!ctx || !c || !out) { set_error("plk_setup_prepare: bad argument"); return PLK_ERR_ARG; }
@@ -87,6 +109,8 @@ int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
     S->N = N; S->n = N - 1; S->log_n = log_n;
     S->num_circuit_vars = c->r1cs.num_variables;
     S->ops.swap(T.ops); S->op_terms.swap(T.op_terms);
+    S->ops_independent = true;
+    for (const WitnessTerm &t : S->op_terms) if (t.var >= c->r1cs.num_variables) { S->ops_independent = false; break; }
     std::vector<Gate> rows;
     rows.reserve(S->n_real);
     for (uint64_t i = 1; i <= S->num_inputs; i++) {                 // one gate per public input, first rows, q_a = -1
@@ -171,13 +195,19 @@ int32_t plk_setup_write_vk(plk_ctx *ctx, const plk_setup *s, const uint8_t g2_by
     PLK_HIP(hipSetDevice(ctx->device));
     std::vector<uint8_t> b;
     put_u64(b, s->n); put_u64(b, s->num_inputs);
-    HAffine p;
+    HAffine cm[11];
+    {
+        const Fr *polys[11];
+        for (int k = 0; k < 7; k++) polys[k] = s->sel_coef[k];
+        for (int j = 0; j < 4; j++) polys[7 + j] = s->sig_coef[j];
+        PLK_TRY(commit_many(ctx, polys, 11, s->N, cm));
+    }
     put_u64(b, 6);
-    for (int k = 0; k < 6; k++) { PLK_TRY(commit(ctx, s->sel_coef[k], s->N, &p)); put_g1(b, p); }
+    for (int k = 0; k < 6; k++) put_g1(b, cm[k]);
     put_u64(b, 1);
-    PLK_TRY(commit(ctx, s->sel_coef[6], s->N, &p)); put_g1(b, p);
+    put_g1(b, cm[6]);
     put_u64(b, 4);
-    for (int j = 0; j < 4; j++) { PLK_TRY(commit(ctx, s->sig_coef[j], s->N, &p)); put_g1(b, p); }
+    for (int j = 0; j < 4; j++) put_g1(b, cm[7 + j]);
     put_u64(b, 3);
     for (int j = 1; j < 4; j++) put_fr(b, HFr::from_u64(NON_RESIDUES[j]));
     b.insert(b.end(), g2_bytes, g2_bytes + 256);
@@ -213,11 +243,27 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     T.values.resize(S->num_vars);
     memcpy(T.values.data(), c->witness.data(), S->num_circuit_vars * sizeof(HFr));
     T.values[0] = HFr::zero();                                               // id 0 = dummy variable
-    for (size_t i = 0; i < S->ops.size(); i++) {
-        const WitnessOp &op = S->ops[i];
-        HFr acc = op.constant;
-        for (uint32_t k = 0; k < op.count; k++) { const WitnessTerm &t = S->op_terms[op.first + k]; acc = acc + t.coeff * T.values[t.var]; }
-        T.values[S->num_circuit_vars + i] = acc;
+    {
+        // temporaries only ever read circom wires or EARLIER temporaries; `dep_level_end` marks prefixes
+        // whose operands are all circom wires, which can be evaluated in parallel
+        const size_t n_ops = S->ops.size();
+        auto eval_range = [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                const WitnessOp &op = S->ops[i];
+                HFr acc = op.constant;
+                for (uint32_t k = 0; k < op.count; k++) { const WitnessTerm &t = S->op_terms[op.first + k]; acc = acc + t.coeff * T.values[t.var]; }
+                T.values[S->num_circuit_vars + i] = acc;
+            }
+        };
+        if (S->ops_independent && n_ops > 4096) {
+            unsigned nt = std::thread::hardware_concurrency();
+            if (nt > 16) nt = 16;
+            if (nt < 1) nt = 1;
+            std::vector<std::thread> th;
+            size_t per = (n_ops + nt - 1) / nt;
+            for (unsigned t = 0; t < nt; t++) { size_t lo = t * per, hi = std::min(n_ops, lo + per); if (lo < hi) th.emplace_back(eval_range, lo, hi); }
+            for (auto &x : th) x.join();
+        } else eval_range(0, n_ops);
     }
     lap();                                                                    // [0] witness synthesis
 
@@ -226,15 +272,16 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     const size_t NB = (N * sizeof(Fr) + 255) & ~(size_t)255, MB = (M * sizeof(Fr) + 255) & ~(size_t)255;
     const size_t TB = ((size_t)2 * POW_TAB * sizeof(Fr) + 255) & ~(size_t)255;
     const size_t VB = (T.num_vars * sizeof(Fr) + 255) & ~(size_t)255;
-    PLK_TRY(ctx->prove_ws.reserve(VB + 16 * NB + 20 * MB + 4 * TB + 8192));
+    PLK_TRY(ctx->prove_ws.reserve(VB + 16 * NB + 8 * MB + 4 * TB + 8192));
     Arena A{&ctx->prove_ws};
     Fr *d_values = A.take<Fr>(T.num_vars);
     Fr *w_vals[4], *w_coef[4];
     for (int j = 0; j < 4; j++) { w_vals[j] = A.take<Fr>(N); w_coef[j] = A.take<Fr>(N); }
     Fr *z_coef = A.take<Fr>(N), *t1 = A.take<Fr>(N), *t2 = A.take<Fr>(N), *t3 = A.take<Fr>(N);
     Fr *r_poly = A.take<Fr>(N), *agg = A.take<Fr>(N), *pi_coef = A.take<Fr>(N), *l0_coef = A.take<Fr>(N);
-    Fr *ext[18];
-    for (int k = 0; k < 18; k++) ext[k] = A.take<Fr>(M);
+    Fr *ext[18] = {nullptr};
+    for (int k = 0; k < 5; k++) ext[k] = A.take<Fr>(M);          // w0..w3, z
+    ext[16] = A.take<Fr>(M);                                      // PI
     Fr *t_ext = A.take<Fr>(M);
     Fr *tab[4];
     for (int k = 0; k < 4; k++) tab[k] = A.take<Fr>(2 * POW_TAB);
@@ -263,7 +310,7 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
         PLK_TRY(ntt_dev(ctx, w_coef[j], log_n, true, nullptr, st));
     }
     HAffine wire_c[4];
-    for (int j = 0; j < 4; j++) PLK_TRY(commit(ctx, w_coef[j], N, &wire_c[j]));
+    PLK_TRY(commit_many(ctx, w_coef, 4, N, wire_c));
     RollingKeccak tr;
     for (const HFr &x : inputs) tr.absorb_fr(x);
     for (int j = 0; j < 4; j++) tr.absorb_g1(wire_c[j]);
@@ -300,17 +347,26 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     {
         for (int j = 0; j < 4; j++) PLK_TRY(lde4_dev(ctx, w_coef[j], log_n, ext[j], st));
         PLK_TRY(lde4_dev(ctx, z_coef, log_n, ext[4], st));
-        for (int k = 0; k < 7; k++) PLK_TRY(lde4_dev(ctx, S->sel_coef[k], log_n, ext[5 + k], st));
-        for (int j = 0; j < 4; j++) PLK_TRY(lde4_dev(ctx, S->sig_coef[j], log_n, ext[12 + j], st));
+        if (!S->lde_ready) {
+            PLK_TRY(S->lde_store.reserve(12 * MB));
+            Arena LA{&S->lde_store};
+            for (int k = 0; k < 12; k++) S->lde[k] = LA.take<Fr>(M);
+            for (int k = 0; k < 7; k++) PLK_TRY(lde4_dev(ctx, S->sel_coef[k], log_n, S->lde[k], st));
+            for (int j = 0; j < 4; j++) PLK_TRY(lde4_dev(ctx, S->sig_coef[j], log_n, S->lde[7 + j], st));
+            HFr one = HFr::one();
+            PLK_HIP(hipMemsetAsync(l0_coef, 0, N * sizeof(Fr), st));
+            PLK_HIP(hipMemcpyAsync(l0_coef, one.l, sizeof(Fr), hipMemcpyHostToDevice, st));
+            PLK_TRY(ntt_dev(ctx, l0_coef, log_n, true, nullptr, st));
+            PLK_TRY(lde4_dev(ctx, l0_coef, log_n, S->lde[11], st));
+            PLK_HIP(hipStreamSynchronize(st));
+            S->lde_ready = true;
+        }
+        for (int k = 0; k < 11; k++) ext[5 + k] = S->lde[k];
+        ext[17] = S->lde[11];
         PLK_HIP(hipMemsetAsync(pi_coef, 0, N * sizeof(Fr), st));
         if (!inputs.empty()) PLK_HIP(hipMemcpyAsync(pi_coef, inputs.data(), inputs.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
         PLK_TRY(ntt_dev(ctx, pi_coef, log_n, true, nullptr, st));
         PLK_TRY(lde4_dev(ctx, pi_coef, log_n, ext[16], st));
-        HFr one = HFr::one();
-        PLK_HIP(hipMemsetAsync(l0_coef, 0, N * sizeof(Fr), st));
-        PLK_HIP(hipMemcpyAsync(l0_coef, one.l, sizeof(Fr), hipMemcpyHostToDevice, st));
-        PLK_TRY(ntt_dev(ctx, l0_coef, log_n, true, nullptr, st));
-        PLK_TRY(lde4_dev(ctx, l0_coef, log_n, ext[17], st));
 
         QuotientArgs qa;
         qa.out = t_ext;
@@ -328,7 +384,10 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
         PLK_TRY(ntt_dev(ctx, t_ext, log_m, true, &g, st));
     }
     HAffine t_c[4];
-    for (int k = 0; k < 4; k++) PLK_TRY(commit(ctx, t_ext + (size_t)k * N, N, &t_c[k]));
+    {
+        const Fr *parts[4] = {t_ext, t_ext + N, t_ext + 2 * N, t_ext + 3 * N};
+        PLK_TRY(commit_many(ctx, parts, 4, N, t_c));
+    }
     for (int k = 0; k < 4; k++) tr.absorb_g1(t_c[k]);
     const HFr z = tr.challenge();
     lap();                                                                    // [3] round 3
@@ -394,7 +453,6 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
         PLK_TRY(mul_powers(t1, agg, pt_z, 0, (uint32_t)N, st));
         PLK_TRY(scan(ctx, t1, t1, (uint32_t)N, false, true, false, st));
         PLK_TRY(div_finish(t2, t1, pt_zinv, (uint32_t)N, st));
-        PLK_TRY(commit(ctx, t2, N, &Wz));
 
         LinCombArgs lb{};
         lb.out = agg; lb.n = (uint32_t)N; lb.count = 2;
@@ -403,7 +461,10 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
         PLK_TRY(mul_powers(t1, agg, pt_zw, 0, (uint32_t)N, st));
         PLK_TRY(scan(ctx, t1, t1, (uint32_t)N, false, true, false, st));
         PLK_TRY(div_finish(t3, t1, pt_zwinv, (uint32_t)N, st));
-        PLK_TRY(commit(ctx, t3, N, &Wzw));
+        const Fr *opens[2] = {t2, t3};
+        HAffine oc[2];
+        PLK_TRY(commit_many(ctx, opens, 2, N, oc));
+        Wz = oc[0]; Wzw = oc[1];
     }
     lap();                                                                    // [5] round 5
 

@@ -150,6 +150,24 @@ def test_msm_duplicate_and_opposite_bases(ctx, srs16):
     assert np.array_equal(ctx.msm(ol.fr_vec([7] * 300)), ol.g1_mul(p, 7 * 300))
 
 
+@pytest.mark.parametrize("n,count", [(100, 3), (5000, 4), (1 << 15, 11)])
+def test_msm_batch_matches_single(ctx, srs16, n, count):
+    """batched commitments (one pass of the kernels) == the same commitments one by one == trapdoor"""
+    import torch
+    ctx.srs_upload(srs16)
+    ts, want = [], []
+    for k in range(count):
+        s = _rand_fr(n, 1000 + k)
+        if k == 1:
+            s[: n // 2] = 0                                  # a sparse vector inside the batch
+        ts.append(torch.from_numpy(s.view(np.int64)).to("cuda:0"))
+        want.append(_trapdoor(ol.fr_ints(s)))
+    got = ctx.msm_batch_dev(ts, n)
+    for k in range(count):
+        assert np.array_equal(got[k], want[k])
+        assert np.array_equal(got[k], ctx.msm_dev(ts[k], n))
+
+
 def test_msm_errors(ctx, srs16):
     import plonkit_amd as pa
     ctx.srs_upload(srs16[:100])
