@@ -25,6 +25,7 @@
 #include "msm.h"
 #include "hostmath.h"
 #include <cstring>
+#include <cstdlib>
 
 namespace plk {
 
@@ -45,6 +46,7 @@ struct MsmParams {
     uint32_t coarse_bits;     // c - 1 - FINE_BITS
     uint32_t nbins;           // 1 << coarse_bits
     uint32_t batch;           // number of scalar vectors (same n, same bases); "global window" = m * W + w
+    uint32_t debug;           // experiments only: 1 = skip the additions (sort cost), 0 = normal
 };
 
 struct ScalarSet { const Fr *v[MSM_MAX_BATCH]; };
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_accumulate(const G1Affine 
             dst = overflow + (size_t)task * MSM_THREADS + tid;
         }
         XyzzW acc = xyzzw_identity();
-        accumulate_run(acc, bases, sorted, lo, hi);
+        if (p.debug != 1) accumulate_run(acc, bases, sorted, lo, hi);
         store_xyzzw(dst, acc);
     }
 }
@@ -437,6 +439,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     p.coarse_bits = p.c - 1 - FINE_BITS;
     p.nbins = 1u << p.coarse_bits;
     p.batch = batch;
+    { const char *dbg = getenv("PLK_MSM_DEBUG"); p.debug = dbg ? (uint32_t)atoi(dbg) : 0; }
     ScalarSet set{};
     for (uint32_t m = 0; m < batch; m++) set.v[m] = scalars_dev[m];
     const uint32_t bins_per = p.windows * p.nbins, total_bins = batch * bins_per, total_windows = batch * p.windows;
