@@ -34,6 +34,12 @@ def lib():
         if not os.path.exists(_SO):
             raise ImportError("plonkit_amd: %s is missing — build it with `python -m plonkit_amd.build` "
                               "(hipcc, gfx950). There is no fallback implementation." % _SO)
+        # PyTorch-ROCm ships its own libamdhip64; if /opt/rocm's copy (our DT_NEEDED) is mapped first, torch's
+        # later HIP initialisation finds "No HIP GPUs".  Import torch first so that one runtime serves both.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(_SO)
         L.plk_last_error.restype = ctypes.c_char_p
         L.plk_version.restype = ctypes.c_char_p

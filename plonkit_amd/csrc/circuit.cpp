@@ -418,7 +418,8 @@ extern "C" int32_t plk_circuit_load(const uint8_t *r1cs, uint64_t r1cs_len, int3
     return PLK_OK;
 }
 
-extern "C" void plk_circuit_free(plk_circuit *c) { delete c; }
+void plk_circuit_unregister(plk_circuit *c);
+extern "C" void plk_circuit_free(plk_circuit *c) { if (c) { plk_circuit_unregister(c); delete c; } }
 
 extern "C" int32_t plk_circuit_analyse(const plk_circuit *c, char *out_json, uint64_t cap) {
     if (!c || !out_json) { set_error("plk_circuit_analyse: bad argument"); return PLK_ERR_ARG; }

@@ -57,6 +57,7 @@ struct plk_circuit {
     plk::R1cs r1cs;
     std::vector<plk::HFr> witness;
     bool has_witness = false;
+    mutable bool witness_registered = false;   // page-locked for fast upload (done lazily by plk_prove)
 };
 
 namespace plk {

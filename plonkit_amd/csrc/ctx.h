@@ -68,12 +68,14 @@ struct plk_ctx {
     plk::DevBuf srs_w;                       // the same points in the 2^261 Montgomery domain of field29.cuh (MSM gathers)
     bool srs_w_valid = false;
     // MSM scratch
-    plk::DevBuf msm_a, msm_b, msm_c, msm_d, msm_e;
+    plk::DevBuf msm_a, msm_b, msm_c, msm_d, msm_e, msm_f;
     plk::DevBuf prove_ws;                    // workspace of the prover rounds (grows only)
     plk::DevBuf poly_tmp, poly_tmp2;         // scan block totals / evaluation partials
     plk::DevBuf stage;                       // host<->device staging for the host-pointer API
     void *pinned = nullptr;                  // small pinned host buffer for results
     size_t pinned_cap = 0;
+    void *pinned2 = nullptr;                 // pinned staging of the prover's temporaries
+    size_t pinned2_cap = 0;
     uint32_t msm_windows = 0, msm_c_bits = 0, msm_pending_parts = 0, msm_batch = 1;
     hipStream_t msm_stream = nullptr;
     std::vector<double> timings;

@@ -26,6 +26,7 @@ using namespace host;
 static const uint64_t NON_RESIDUES[4] = {1, 5, 7, 10};     // k_j (vk.bin stores 5, 7, 10)
 
 static inline Fr to_dev(const HFr &h) { Fr f; memcpy(f.l, h.l, 32); return f; }
+int32_t ensure_pinned2(plk_ctx *ctx, size_t bytes);
 static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static HFr host_omega(uint32_t log_n) {
@@ -86,6 +87,10 @@ struct plk_setup {
 };
 
 using namespace plk;
+
+void plk_circuit_unregister(plk_circuit *c) {
+    if (c->witness_registered) { (void)hipHostUnregister((void *)c->witness.data()); c->witness_registered = false; }
+}
 
 extern "C" {
 
@@ -238,21 +243,25 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     //      linear forms (the gate structure itself lives in plk_setup; the reference re-synthesises here)
     if (c->r1cs.num_variables != S->num_circuit_vars || c->witness.size() < S->num_circuit_vars) {
         set_error("plk_prove: circuit does not match the prepared setup"); return PLK_ERR_ARG; }
-    struct { std::vector<HFr> values; uint64_t num_vars; } T;
-    T.num_vars = S->num_vars;
-    T.values.resize(S->num_vars);
-    memcpy(T.values.data(), c->witness.data(), S->num_circuit_vars * sizeof(HFr));
-    T.values[0] = HFr::zero();                                               // id 0 = dummy variable
+    // circom wires are uploaded straight from the (page-locked) witness buffer; only the temporaries are
+    // computed here, into a pinned staging area.  id 0 (dummy) is zeroed on the device.
+    const uint64_t ncv = S->num_circuit_vars, n_tmp = S->num_vars - ncv;
+    if (!c->witness_registered) {
+        if (hipHostRegister((void *)c->witness.data(), c->witness.size() * sizeof(HFr), hipHostRegisterDefault) == hipSuccess) c->witness_registered = true;
+        else (void)hipGetLastError();                                        // not fatal: the copy is just slower
+    }
+    PLK_TRY(ensure_pinned2(ctx, (n_tmp + 1) * sizeof(HFr)));
+    HFr *tmp_vals = reinterpret_cast<HFr *>(ctx->pinned2);
+    const HFr *wit = c->witness.data();
     {
-        // temporaries only ever read circom wires or EARLIER temporaries; `dep_level_end` marks prefixes
-        // whose operands are all circom wires, which can be evaluated in parallel
         const size_t n_ops = S->ops.size();
+        auto value_of = [&](uint32_t v) -> HFr { return v == 0 ? HFr::zero() : (v < ncv ? wit[v] : tmp_vals[v - ncv]); };
         auto eval_range = [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; i++) {
                 const WitnessOp &op = S->ops[i];
                 HFr acc = op.constant;
-                for (uint32_t k = 0; k < op.count; k++) { const WitnessTerm &t = S->op_terms[op.first + k]; acc = acc + t.coeff * T.values[t.var]; }
-                T.values[S->num_circuit_vars + i] = acc;
+                for (uint32_t k = 0; k < op.count; k++) { const WitnessTerm &t = S->op_terms[op.first + k]; acc = acc + t.coeff * value_of(t.var); }
+                tmp_vals[i] = acc;
             }
         };
         if (S->ops_independent && n_ops > 4096) {
@@ -265,6 +274,8 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
             for (auto &x : th) x.join();
         } else eval_range(0, n_ops);
     }
+    struct { uint64_t num_vars; } T;
+    T.num_vars = S->num_vars;
     lap();                                                                    // [0] witness synthesis
 
     const uint64_t N = S->N, M = 4 * N;
@@ -288,8 +299,10 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     Fr *d_results = A.take<Fr>(16);
 
     uint32_t *d_flag = A.take<uint32_t>(64);
-    PLK_HIP(hipMemcpyAsync(d_values, T.values.data(), T.num_vars * sizeof(Fr), hipMemcpyHostToDevice, st));
-    std::vector<HFr> inputs(T.values.begin() + 1, T.values.begin() + 1 + S->num_inputs);
+    PLK_HIP(hipMemcpyAsync(d_values, wit, ncv * sizeof(Fr), hipMemcpyHostToDevice, st));
+    PLK_HIP(hipMemsetAsync(d_values, 0, sizeof(Fr), st));
+    if (n_tmp) PLK_HIP(hipMemcpyAsync(d_values + ncv, tmp_vals, n_tmp * sizeof(Fr), hipMemcpyHostToDevice, st));
+    std::vector<HFr> inputs(wit + 1, wit + 1 + S->num_inputs);
     {   // is_satisfied_using_one_shot_check (src/plonk.rs:137) on the device
         CheckArgs ca;
         ca.values = d_values; ca.n = (uint32_t)N; ca.num_inputs = (uint32_t)S->num_inputs; ca.flag = d_flag;

@@ -45,6 +45,16 @@ int32_t ensure_pinned(plk_ctx *ctx, size_t bytes) {
     return PLK_OK;
 }
 
+int32_t ensure_pinned2(plk_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->pinned2_cap) return PLK_OK;
+    if (ctx->pinned2) (void)hipHostFree(ctx->pinned2);
+    ctx->pinned2 = nullptr; ctx->pinned2_cap = 0;
+    size_t want = bytes + (bytes >> 2);
+    PLK_HIP(hipHostMalloc(&ctx->pinned2, want, hipHostMallocDefault));
+    ctx->pinned2_cap = want;
+    return PLK_OK;
+}
+
 }  // namespace plk
 
 using namespace plk;
@@ -94,9 +104,10 @@ void plk_destroy(plk_ctx *ctx) {
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
     for (void *p : ctx->coset_allocs) (void)hipFree(p);
     ctx->tables.release(); ctx->ntt_scratch.release(); ctx->srs_own.release(); ctx->srs_w.release();
-    ctx->msm_a.release(); ctx->msm_b.release(); ctx->msm_c.release(); ctx->msm_d.release(); ctx->msm_e.release();
+    ctx->msm_a.release(); ctx->msm_b.release(); ctx->msm_c.release(); ctx->msm_d.release(); ctx->msm_e.release(); ctx->msm_f.release();
     ctx->stage.release(); ctx->poly_tmp.release(); ctx->poly_tmp2.release(); ctx->prove_ws.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pinned2) (void)hipHostFree(ctx->pinned2);
     if (ctx->ev[0]) { (void)hipEventDestroy(ctx->ev[0]); (void)hipEventDestroy(ctx->ev[1]); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
