@@ -92,6 +92,7 @@ def main():
     n = 1 << args.log_n
     ctx.srs_generate(n, start=rank * n, tau=42)          # this rank's shard of the N*2^20 monomial SRS
     scalars = rand_scalars(n, 0x706c6f6e6b6974 + rank, device)
+    torch.cuda.synchronize()                             # the scalars are consumed on another stream
     stream = torch.cuda.Stream(device=device)
     msm = ShardedMsm(ctx, dist if world > 1 else None, device)
     ctx.set_kernel_timing(True)
@@ -129,7 +130,7 @@ def main():
             "metric": "G1 MSM throughput at 2^%d terms per GPU (KZG commitment of the PLONK prover)" % args.log_n,
             "value": round(value, 3), "unit": "Mscalar·mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u256 (BN254 Fr/Fq Montgomery, 8x32-bit limbs)", "data": "synthetic",
+            "dtype": "u256 (BN254 Fr/Fq Montgomery; 9x29-bit limbs in registers, v_mad_u64_u32)", "data": "synthetic",
             "config": {"workload": "Pippenger G1 MSM, 2^%d uniform scalars per GPU, tau=42 monomial SRS sharded by rank "
                                    "(BASELINE.json configs[1]: SRS 2^20, single MI355X at N=1)" % args.log_n,
                        "terms_per_gpu": n, "parallelism": "srs-shard x%d + all_gather of partial sums" % world,
@@ -151,11 +152,10 @@ def main():
             got = ctx.msm(s_host)                         # same sample through the HIP path
             cb["matches_gpu"] = bool(np.array_equal(got, ref))
             line["cpu_baseline"] = cb
-        try:
+        if world == 1:
             from plonkit_amd import prover_bench
             line["prove"] = prover_bench.run(ctx, args.log_n)
-        except ImportError:
-            pass
+            line["kernels"] = prover_bench.kernel_table(ctx, device)
         print(json.dumps(line, ensure_ascii=False), flush=True)
     if dist:
         dist.barrier()

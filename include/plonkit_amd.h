@@ -103,6 +103,13 @@ int32_t plk_g1_from_bytes(const uint8_t in[64], plk_g1_affine *out);
 int32_t plk_fr_to_bytes(const plk_fr *a, uint8_t out[32]);
 int32_t plk_fr_from_bytes(const uint8_t in[32], plk_fr *out);
 
+/* ---- SRS key files: Crs::read / Crs::write (src/reader.rs:67-89; src/bin/main.rs:341,379), monomial and
+ *      Lagrange containers alike.  parse: points == NULL only reports n and the G2 bytes;
+ *      every point is range- and curve-checked like Crs::read.  serialize: out == NULL only reports len.  */
+int32_t plk_key_parse(const uint8_t *data, uint64_t len, plk_g1_affine *points, uint64_t cap, uint64_t *n_out, uint8_t g2_out[256]);
+int32_t plk_key_serialize(const plk_g1_affine *points, uint64_t n, const uint8_t g2[256], uint8_t *out, uint64_t cap, uint64_t *len);
+void plk_crs42_g2_bytes(uint8_t out[256]);        /* G2 section of Crs::crs_42: {G2, 42*G2} */
+
 /* ---- RollingKeccakTranscript (src/plonk.rs:10,140,152; spec contrib/template.sol:267-307) ---- */
 typedef struct { uint8_t state0[32], state1[32]; uint32_t counter; } plk_transcript;
 void plk_transcript_init(plk_transcript *t);

@@ -5,20 +5,23 @@
 // (src/plonk.rs:152-159) and the 11 of make_verification_key (src/plonk.rs:122-124).
 // The result is the same group element; the schedule is MI355X-first, not bellman's:
 //   * signed c-bit windows (c <= 16): 2^(c-1) buckets per window, W = floor(254/c)+1 windows.
-//   * scalars are taken out of Montgomery form and recoded on the fly (never stored).
+//   * scalars are taken out of Montgomery form once and recoded into int16 signed digits per window.
 //   * two-level bucket sort without a global sort: (1) a coarse partition by (window, top bits of
-//     the bucket index) built with LDS histograms + one global reservation per (block, bin);
+//     the bucket index): per (window, 16K-scalar chunk) workgroup an LDS counting sort, one global
+//     reservation per (block, bin) and contiguous copy-out of every bin's run;
 //     (2) each workgroup then owns one coarse bin = 128 consecutive buckets, counting-sorts its
-//     entries inside LDS and accumulates them — two lanes per bucket keep XYZZ accumulators in
-//     registers for the whole bin, SRS points are gathered as 64-byte coalesced affine records
-//     straight from the HBM-resident SRS (it stays in the 256 MiB Infinity Cache at 2^20).
-//   * a bucket that is hot inside a chunk (repeated scalars: all-ones, all -1) is reduced by the
-//     whole workgroup with wave64 shuffles (__shfl_xor tree) instead of serially.
-//   * per-window sum_b (b+1)*B_b by 16-bucket running sums + small scalar multiple, then a
-//     workgroup tree; the last 255 doublings (Horner over windows) run on the host, where one
-//     serial EC chain is 20x faster than on a GPU lane.
-// No MFMA (256-bit modular integers), arithmetic-bound on v_mad_u64_u32; HBM traffic is the
-// algorithmic 96 B/term plus 8 B/term/window of index lists.
+//     entries inside LDS and accumulates them — two lanes per bucket (ranked by population so that
+//     a wave walks runs of equal length) keep XYZZ accumulators in registers, SRS points are
+//     gathered as 64-byte affine records from the resident SRS (Infinity-Cache sized at 2^20).
+//     All field arithmetic is the carry-free 9x29-bit layer (field29.cuh / ec29.cuh).
+//   * a bucket that is hot inside a task (repeated scalars: all-ones, all -1) is sliced over all
+//     256 lanes; the slices are folded with wave64 shuffle trees in the reduce kernel.
+//   * per-task T = sum B_f and S = sum (f+1) B_f (running sums + 16-lane shuffle scan), then per
+//     window sum_t S_t + 128 * sum_c c * D_c; the last 255 doublings (Horner over windows) run on
+//     the host, where one serial EC chain is 20x faster than on a GPU lane.
+//   * up to 8 commitments over the same bases share every kernel launch (batch dimension).
+// No MFMA (256-bit modular integers), bound by v_mad_u64_u32 issue; HBM sees the algorithmic
+// 96 B/term, the per-window gathers (64 B x W per term) come out of the Infinity Cache.
 #include "ctx.h"
 #include "ec.cuh"
 #include "ec29.cuh"

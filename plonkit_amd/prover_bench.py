@@ -31,3 +31,43 @@ def run(ctx, log_n, reps=2):
             "setup_prepare_s": round(t_setup, 3), "circuit_generation_s": round(t_synth, 3),
             "what": "SetupForProver::prove (witness synthesis + satisfiability check on the host, rounds 1-5 on the GPU, "
                     "Proof::write); setup_prepare = transpile + 11 iNTT, timed separately as in the reference's CLI"}
+
+
+def kernel_table(ctx, device):
+    """HIP-event timings of the other kernels on the path, with their algorithmic HBM bytes
+    (NTT 64*M, LDE4 160*N) — the per-kernel roofline rows of DESIGN.md §4."""
+    import torch
+    out = {}
+    st = torch.cuda.Stream(device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(1)
+    with torch.cuda.stream(st):
+        for log_n in (20, 22, 24):
+            n = 1 << log_n
+            t = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device=device, generator=g)
+            t[:, 3] &= (1 << 60) - 1
+            ctx.ntt_dev(t, log_n, stream=st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(5):
+                ctx.ntt_dev(t, log_n, stream=st)
+            e1.record(st)
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            out["ntt_2^%d" % log_n] = {"ms": round(ms, 4), "algorithmic_GBs": round(64 * n / ms / 1e6, 1),
+                                       "hbm_frac": round(64 * n / ms / 1e6 / 8000.0, 4)}
+            del t
+        n = 1 << 20
+        c = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device=device, generator=g)
+        c[:, 3] &= (1 << 60) - 1
+        o = torch.empty((4 * n, 4), dtype=torch.int64, device=device)
+        ctx.lde4_dev(c, 20, o, stream=st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(5):
+            ctx.lde4_dev(c, 20, o, stream=st)
+        e1.record(st)
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        out["lde4_2^20"] = {"ms": round(ms, 4), "algorithmic_GBs": round(160 * n / ms / 1e6, 1), "hbm_frac": round(160 * n / ms / 1e6 / 8000.0, 4)}
+    return out

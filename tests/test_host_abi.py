@@ -132,3 +132,41 @@ def test_transpiler_matches_oracle_on_synthetic_shapes():
     obj = {"nPubInputs": 2, "nOutputs": 1, "nVars": nvars, "constraints": cons}
     c = pa.Circuit(json.dumps(obj).encode(), True)
     assert c.analyse() == po.analyse(po.load_r1cs_json(obj))
+
+
+def test_key_file_codec_roundtrip(golden_dir, golden_crs):
+    """Crs::read / Crs::write through the ABI: the committed 2^10 key parses (every point curve-checked),
+    re-serialises to the same bytes, and its G2 section is the crs_42 constant."""
+    import ctypes
+    raw = open(os.path.join(golden_dir, "setup_2pow10.key"), "rb").read()
+    L = pa.lib()
+    n = ctypes.c_uint64(0)
+    g2 = ctypes.create_string_buffer(256)
+    assert L.plk_key_parse(raw, ctypes.c_uint64(len(raw)), None, ctypes.c_uint64(0), ctypes.byref(n), g2) == 0
+    assert n.value == 1024
+    pts = np.zeros((1024, 8), dtype=np.uint64)
+    assert L.plk_key_parse(raw, ctypes.c_uint64(len(raw)), pts.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(1024), ctypes.byref(n), g2) == 0
+    assert np.array_equal(pts, golden_crs.g1)
+    c42 = ctypes.create_string_buffer(256)
+    L.plk_crs42_g2_bytes(c42)
+    assert c42.raw == g2.raw == raw[-256:]
+    ln = ctypes.c_uint64(0)
+    out = ctypes.create_string_buffer(len(raw))
+    assert L.plk_key_serialize(pts.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(1024), g2, out, ctypes.c_uint64(len(raw)), ctypes.byref(ln)) == 0
+    assert out.raw == raw
+    bad = bytearray(raw)
+    bad[8 + 64 * 5 + 40] ^= 1                              # y of point 5: no longer on the curve
+    assert L.plk_key_parse(bytes(bad), ctypes.c_uint64(len(bad)), pts.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(1024), ctypes.byref(n), g2) == 6
+    assert L.plk_key_parse(raw[:1000], ctypes.c_uint64(1000), None, ctypes.c_uint64(0), ctypes.byref(n), g2) == 6
+
+
+def test_cli_analyse_and_flag_surface(golden_dir, tmp_path):
+    cli = os.path.join(os.path.dirname(pa.lib_path()), "plonkit")
+    assert os.path.exists(cli)
+    out = tmp_path / "analyse.json"
+    subprocess.check_call([cli, "analyse", "-c", os.path.join(golden_dir, "circuit.r1cs.json"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    assert out.read_text() == open(os.path.join(golden_dir, "analyse.json")).read()
+    # unknown flags / missing required arguments are usage errors, like clap's exit code 2
+    assert subprocess.call([cli, "setup", "-p", "10"], stderr=subprocess.DEVNULL) == 2
+    assert subprocess.call([cli, "prove", "--bogus", "1"], stderr=subprocess.DEVNULL) == 2
+    assert subprocess.call([cli, "frobnicate"], stderr=subprocess.DEVNULL) == 2
