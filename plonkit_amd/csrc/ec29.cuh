@@ -6,7 +6,7 @@
 //     XYZZ accumulator   x, y      < 6 p       zz, zzz < 1.3 p
 // Bound bookkeeping (out of mulw < a*b*0.0059/p + p):
 //   madd:  U2,S2 < 1.02  P = U2-X+6p < 7.02  R = 8p-Y(+/-)S2 < 9.1  PP < 1.3  PPP < 1.06  Q < 1.05
-//          X3 = R^2-PPP-2Q+4p < 5.5   T = Q-X3+6p < 7.05   Y3 = R*T - Y*PPP + 2p < 3.4
+//          X3 = R^2-PPP-2Q+4p < 5.5   T = Q-X3+6p < 7.05   Y3 = R*T + Y*(2p-PPP) (one reduction) < 1.5
 //   add :  U,S < 1.05  P,R < 3.05  PP < 1.06  X3 < 5.06  Y3 < 3.2
 //   dbl :  U = 2Y < 12  V < 1.85  W < 1.14  S < 1.07  M = 3X^2 < 3.7  X3 < 5.1  Y3 < 3.2
 #pragma once
@@ -21,6 +21,8 @@ struct alignas(16) XyzzW { FqW9 x, y, zz, zzz; };              // 144 bytes
 // the product is inlined: 162 v_mad_u64_u32 + ~60 other instructions (1.9 KB), ten of them per
 // mixed addition keep the accumulate loop at ~25 KB, inside the 64 KB instruction cache
 #define WM(a, b) mulw<FqW>((a), (b))
+#define WS(a) sqrw<FqW>((a))                               // normalised input; 126 mads instead of 162
+#define WMA(a, b, c, d) mul2addw<FqW>((a), (b), (c), (d))  // a*b + c*d, one reduction
 
 PLK_HD bool is_inf(const XyzzW &p) { return w_all_zero(p.zz); }
 PLK_HD bool is_inf(const AffW &p) { return w_all_zero(p.x) && w_all_zero(p.y); }
@@ -28,22 +30,22 @@ PLK_HD XyzzW xyzzw_identity() { XyzzW r; r.x = w_zero<FqW>(); r.y = w_zero<FqW>(
 
 // 2 * (x, y) for an affine point; ysgn selects +y / -y
 PLK_HD XyzzW xyzzw_double_affine(const FqW9 &x, const FqW9 &y) {
-    FqW9 u = addn(y, y), v = WM(u, u), w = WM(u, v), s = WM(x, v);
-    FqW9 xx = WM(x, x), m = normw(addw(addw(xx, xx), xx));
+    FqW9 u = addn(y, y), v = WS(u), w = WM(u, v), s = WM(x, v);
+    FqW9 xx = WS(x), m = normw(addw(addw(xx, xx), xx));
     XyzzW r;
-    r.x = sub4(WM(m, m), addn(s, s));
-    r.y = sub2(WM(m, sub6(s, r.x)), WM(w, y));
+    r.x = sub4(WS(m), addn(s, s));
+    r.y = WMA(m, sub6(s, r.x), y, neg2(w));
     r.zz = v; r.zzz = w;
     return r;
 }
 
 PLK_HD XyzzW xyzzw_double(const XyzzW &p) {
     if (is_inf(p)) return p;
-    FqW9 u = addn(p.y, p.y), v = WM(u, u), w = WM(u, v), s = WM(p.x, v);
-    FqW9 xx = WM(p.x, p.x), m = normw(addw(addw(xx, xx), xx));
+    FqW9 u = addn(p.y, p.y), v = WS(u), w = WM(u, v), s = WM(p.x, v);
+    FqW9 xx = WS(p.x), m = normw(addw(addw(xx, xx), xx));
     XyzzW r;
-    r.x = sub4(WM(m, m), addn(s, s));
-    r.y = sub2(WM(m, sub6(s, r.x)), WM(w, p.y));
+    r.x = sub4(WS(m), addn(s, s));
+    r.y = WMA(m, sub6(s, r.x), p.y, neg2(w));
     r.zz = WM(v, p.zz); r.zzz = WM(w, p.zzz);
     return r;
 }
@@ -81,15 +83,15 @@ PLK_HD void xyzzw_add_mixed(XyzzW &acc, const AffW &q, bool neg_q) {
         xyzzw_add_mixed_special(acc, q, neg_q, p, r);
         return;
     }
-    FqW9 pp = WM(p, p), ppp = WM(p, pp), qq = WM(acc.x, pp);
+    FqW9 pp = WS(p), ppp = WM(p, pp), qq = WM(acc.x, pp);
     FqW9 x3;
     {
-        FqW9 rr = WM(r, r);
+        FqW9 rr = WS(r);
 #pragma unroll
         for (int i = 0; i < 9; i++) x3.l[i] = rr.l[i] + FqW::PAD4[i] - ppp.l[i] - 2 * qq.l[i];
         x3 = normw(x3);
     }
-    acc.y = sub2(WM(r, sub6(qq, x3)), WM(acc.y, ppp));
+    acc.y = WMA(r, sub6(qq, x3), acc.y, neg2(ppp));           // R*(Q - X3) - Y*PPP, one reduction
     acc.x = x3;
     acc.zz = WM(acc.zz, pp);
     acc.zzz = WM(acc.zzz, ppp);
@@ -106,15 +108,15 @@ PLK_HD void xyzzw_add(XyzzW &a, const XyzzW &b) {
         else a = xyzzw_identity();
         return;
     }
-    FqW9 pp = WM(p, p), ppp = WM(p, pp), qq = WM(u1, pp);
+    FqW9 pp = WS(p), ppp = WM(p, pp), qq = WM(u1, pp);
     FqW9 x3;
     {
-        FqW9 rr = WM(r, r);
+        FqW9 rr = WS(r);
 #pragma unroll
         for (int i = 0; i < 9; i++) x3.l[i] = rr.l[i] + FqW::PAD4[i] - ppp.l[i] - 2 * qq.l[i];
         x3 = normw(x3);
     }
-    a.y = sub2(WM(r, sub6(qq, x3)), WM(s1, ppp));
+    a.y = WMA(r, sub6(qq, x3), s1, neg2(ppp));
     a.x = x3;
     a.zz = WM(WM(a.zz, b.zz), pp);
     a.zzz = WM(WM(a.zzz, b.zzz), ppp);

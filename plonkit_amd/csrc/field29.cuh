@@ -169,7 +169,68 @@ PLK_HD W9<WP> mulw(const W9<WP> &a, const W9<WP> &b) {
     r.l[8] = (uint32_t)(t[8] + c);
     return r;
 }
-template <class WP> PLK_HD W9<WP> sqrw(const W9<WP> &a) { return mulw(a, a); }
+// a^2: the cross products a_i*a_j (i < j) are taken once against the doubled operand, 45 + 81 mads instead
+// of 162.  Row i adds a_i^2 to column 2i and 2*a_j*a_i (j > i) to column i+j; every product that belongs to
+// global column g is in place before step g reduces it (the smaller index is <= g/2).
+template <class WP>
+PLK_HD W9<WP> sqrw(const W9<WP> &a) {
+    uint64_t t[10];
+    uint32_t a2[9];
+#pragma unroll
+    for (int j = 0; j < 10; j++) t[j] = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) a2[j] = a.l[j] << 1;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        t[i] += (uint64_t)a.l[i] * a.l[i];                           // global column 2i = local column i
+#pragma unroll
+        for (int j = i + 1; j < 9; j++) t[j] += (uint64_t)a2[j] * a.l[i];   // global column i+j = local column j
+        const uint32_t m = ((uint32_t)t[0] * WP::INV29) & M29;
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * WP::P29[j];
+        const uint64_t c = t[0] >> 29;
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[j] = t[j + 1];
+        t[0] += c;
+        t[9] = 0;
+    }
+    W9<WP> r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { uint64_t s = t[j] + c; r.l[j] = (uint32_t)s & M29; c = s >> 29; }
+    r.l[8] = (uint32_t)(t[8] + c);
+    return r;
+}
+
+// a*b + c*d with ONE Montgomery reduction (243 mads instead of 324).  Used as a*b - c*e by passing
+// d = k*p - e.  Limbs: a, c < 2^30; b, d < 2^29.  Columns hold at most 9 * (2*2^59 + 2^58) < 2^63.4.
+template <class WP>
+PLK_HD W9<WP> mul2addw(const W9<WP> &a, const W9<WP> &b, const W9<WP> &c, const W9<WP> &d) {
+    uint64_t t[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) t[j] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[j] += (uint64_t)a.l[j] * b.l[i];
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[j] += (uint64_t)c.l[j] * d.l[i];
+        const uint32_t m = ((uint32_t)t[0] * WP::INV29) & M29;
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * WP::P29[j];
+        const uint64_t cy = t[0] >> 29;
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[j] = t[j + 1];
+        t[0] += cy;
+        t[9] = 0;
+    }
+    W9<WP> r;
+    uint64_t cy = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { uint64_t s = t[j] + cy; r.l[j] = (uint32_t)s & M29; cy = s >> 29; }
+    r.l[8] = (uint32_t)(t[8] + cy);
+    return r;
+}
 
 // exact conditional subtraction: normalised a < 2p  ->  a mod p in [0, p)
 template <class WP>
