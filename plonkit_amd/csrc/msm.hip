@@ -38,7 +38,7 @@ constexpr uint32_t FINE = 1u << FINE_BITS;
 constexpr uint32_t CHUNK = 8192;                  // entries per accumulate workgroup (sorted in LDS)
 constexpr uint32_t DIGIT_CHUNK = 16384;            // scalars per partition workgroup (per window): 64 KB of LDS staging
 constexpr uint32_t TASK_MAX = CHUNK;
-constexpr uint32_t HEAVY = 320;                   // per-chunk bucket population handled cooperatively
+                   // per-chunk bucket population handled cooperatively
 
 constexpr uint32_t MSM_MAX_BATCH = 8;              // commitments sharing one pass over the same bases
 
@@ -195,9 +195,13 @@ __device__ __forceinline__ XyzzW shfl_down_w(const XyzzW &v, int delta) {
     return r;
 }
 
-// full additions are off the hot path (pair combine, hot buckets, epilogue): one out-of-line copy
+// full additions / doublings are off the hot path (reduction kernels): one out-of-line copy each.
+// (Measured: also routing their products through out-of-line routines makes them 1.6x slower — the
+//  save/restore traffic around 14 calls outweighs the smaller instruction footprint.)
 __device__ __noinline__ void xyzzw_add_call(XyzzW *a, const XyzzW *b) { XyzzW t = *a; xyzzw_add(t, *b); *a = t; }
+__device__ __noinline__ void xyzzw_double_call(XyzzW *a) { XyzzW t = *a; *a = xyzzw_double(t); }
 __device__ __forceinline__ void xyzzw_add_nl(XyzzW &a, const XyzzW &b) { xyzzw_add_call(&a, &b); }
+__device__ __forceinline__ XyzzW xyzzw_double_nl(const XyzzW &a) { XyzzW t = a; xyzzw_double_call(&t); return t; }
 
 __global__ void __launch_bounds__(256) srs_to_w_kernel(G1Affine *out, const G1Affine *in, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,21 +226,25 @@ __device__ __forceinline__ void accumulate_run(XyzzW &acc, const G1Affine *bases
     }
 }
 
+// Per-task output of kernel A: 128 PRIMARY slots (a bucket whose run lies inside one lane's slice), and per
+// lane one HEAD slot (its first run continues a bucket begun by an earlier lane) and one TAIL slot (its last
+// run is continued by a later lane).  Which slots are live follows from the bucket offsets alone.
+constexpr uint32_t SLOT_PRIMARY = 0, SLOT_HEAD = FINE, SLOT_TAIL = FINE + MSM_THREADS, SLOTS_PER_TASK = FINE + 2 * MSM_THREADS;
+constexpr uint32_t META_PER_TASK = FINE + 2;              // start[0..128] and the entry count
+
 // Kernel A — one workgroup per task = one slice (<= CHUNK entries) of a (window, coarse bin): 128 buckets.
 //  1. counting sort of the slice by fine bucket inside LDS
-//  2. buckets ranked by population; lane pair p takes the p-th most populated bucket, half a run per
-//     lane, so the lanes of a wave walk runs of (nearly) equal length and short waves retire early
-//  3. the most populated bucket, when hotter than HEAVY (repeated scalars), is instead sliced over all
-//     256 lanes into an overflow row
+//  2. the sorted slice is cut into 256 equal pieces, one per lane: every lane performs the same number of
+//     mixed additions whatever the bucket populations are (uniform, witness-like or one hot bucket);
+//     a lane starts a new accumulator at each bucket boundary inside its piece
 // Only mixed additions happen here (10 products each, ~25 KB of code).  One wave per SIMD already saturates the
-// VALU (tools/ubench_w: 14.6 G mixed-adds/s at any occupancy, 25 % less when squeezed into 128 VGPRs with
-// spills), so the register budget is the full 256 and nothing is spilled.  Every lane leaves
-// its partial sum in `partials[task][2*bucket + half]` and kernel B folds them.
+// VALU (tools/ubench_w: 15 G mixed-adds/s at any occupancy, 25 % less when squeezed into 128 VGPRs with
+// spills), so the register budget is the full 256 and nothing is spilled.  Kernel B folds the partial sums.
 __global__ void __launch_bounds__(MSM_THREADS, 2) msm_accumulate(const G1Affine *bases, const uint32_t *entries,
                                                                   const uint32_t *bin_start, const uint32_t *task_start,
-                                                                  XyzzW *partials, XyzzW *overflow, uint32_t *task_heavy, MsmParams p) {
+                                                                  XyzzW *partials, uint32_t *task_meta, MsmParams p) {
     __shared__ uint32_t sorted[CHUNK];
-    __shared__ uint32_t cnt[FINE], start[FINE + 1], cursor[FINE], order[FINE];
+    __shared__ uint32_t cnt[FINE], start[FINE + 1], cursor[FINE];
     const uint32_t tid = threadIdx.x, task = blockIdx.x;
     const uint32_t total_bins = p.batch * p.windows * p.nbins;
     if (task >= task_start[total_bins]) return;
@@ -257,127 +265,187 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_accumulate(const G1Affine 
         start[2 * tid] = ex; start[2 * tid + 1] = ex + a;
         if (tid == 63) start[FINE] = v;
     }
-    if (tid >= 64 && tid < 64 + FINE) {                       // rank by population (descending, ties by index)
-        uint32_t b = tid - 64, c = cnt[b], r = 0;
-        for (uint32_t o = 0; o < FINE; o++) { uint32_t co = cnt[o]; r += (co > c) || (co == c && o < b); }
-        order[r] = b;
-    }
     __syncthreads();
+    uint32_t *meta = task_meta + (size_t)task * META_PER_TASK;
+    if (tid <= FINE) meta[tid] = start[tid];
+    if (tid == 0) meta[FINE + 1] = nc;
     for (uint32_t idx = tid; idx < nc; idx += MSM_THREADS) {
         uint32_t en = entries[s + idx], f = en & (FINE - 1);
         sorted[start[f] + atomicAdd(&cursor[f], 1u)] = en;
     }
     __syncthreads();
-    const uint32_t hot = order[0];
-    const bool has_hot = cnt[hot] > HEAVY;
-    const uint32_t pair = tid >> 1, half = tid & 1, my_bucket = order[pair];
-    if (tid == 0) task_heavy[task] = has_hot ? hot : 0xffffffffu;
-    // phase 0: the lane's half of its bucket; phase 1 (only with a hot bucket): the lane's slice of it.
-    // One loop, one copy of the mixed-addition code.
-    for (uint32_t phase = 0; phase < (has_hot ? 2u : 1u); phase++) {
-        uint32_t lo, hi;
-        XyzzW *dst;
-        if (phase == 0) {
-            uint32_t b0 = start[my_bucket], n_b = cnt[my_bucket], mid = b0 + (n_b + 1) / 2;
-            lo = half ? mid : b0; hi = half ? b0 + n_b : mid;
-            if (has_hot && my_bucket == hot) hi = lo;
-            dst = partials + (size_t)task * (2 * FINE) + 2 * my_bucket + half;
-        } else {
-            uint32_t b0 = start[hot], n_b = cnt[hot], per = (n_b + MSM_THREADS - 1) / MSM_THREADS;
-            lo = b0 + tid * per; hi = lo + per;
-            if (lo > b0 + n_b) lo = b0 + n_b;
-            if (hi > b0 + n_b) hi = b0 + n_b;
-            dst = overflow + (size_t)task * MSM_THREADS + tid;
+    if (nc == 0) return;
+    const uint32_t mu = (nc + MSM_THREADS - 1) / MSM_THREADS;
+    const uint32_t lo = tid * mu < nc ? tid * mu : nc, hi = lo + mu < nc ? lo + mu : nc;
+    XyzzW *out = partials + (size_t)task * SLOTS_PER_TASK;
+    if (lo >= hi) return;
+    // one flat loop over the lane's piece: every lane of the wave executes the same number of mixed additions
+    // in lockstep; a bucket boundary only costs the (divergent) 144-byte flush of the finished accumulator
+    uint32_t en = sorted[lo], b = en & (FINE - 1), bend = start[b + 1], run_start = lo;
+    G1Affine pt = load_affine(bases + (en >> 8));
+    XyzzW acc = xyzzw_identity();
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t e_cur = en;
+        AffW cur; cur.x = unpack<FqW>(pt.x); cur.y = unpack<FqW>(pt.y);
+        if (i + 1 < hi) { en = sorted[i + 1]; pt = load_affine(bases + (en >> 8)); }   // prefetch the next gather
+        if (i == bend) {                                      // the previous bucket ended inside this piece
+            const bool from_prev = (run_start == lo) && (start[b] < lo);
+            store_xyzzw(out + (from_prev ? SLOT_HEAD + tid : SLOT_PRIMARY + b), acc);
+            acc = xyzzw_identity();
+            run_start = i; b = e_cur & (FINE - 1); bend = start[b + 1];
         }
-        XyzzW acc = xyzzw_identity();
-        if (p.debug != 1) accumulate_run(acc, bases, sorted, lo, hi);
-        store_xyzzw(dst, acc);
+        if (p.debug != 1) xyzzw_add_mixed(acc, cur, (e_cur & 0x80u) != 0);
+    }
+    const bool from_prev = (run_start == lo) && (start[b] < lo), into_next = bend > hi;
+    store_xyzzw(out + (from_prev ? SLOT_HEAD + tid : (into_next ? SLOT_TAIL + tid : SLOT_PRIMARY + b)), acc);
+}
+
+// Kernel B0 — folds a bucket that kernel A spread over more than HOT_SPAN lanes (repeated scalars: a witness
+// full of 0/1 values) into that bucket's otherwise unused PRIMARY slot, RL lanes per task working together.
+// Uniform scalars never take this path; the kernel then only reads the bucket offsets.
+constexpr uint32_t RL = 32, RL_LOG = 5, RB = FINE / RL, RB_LOG = 2, HOT_SPAN = 8;
+static_assert((1u << RB_LOG) == RB && (1u << RL_LOG) == RL, "task-reduce shape");
+__device__ __forceinline__ uint32_t bucket_span(const uint32_t *meta, uint32_t b, uint32_t mu) {
+    const uint32_t s0 = meta[b], e0 = meta[b + 1];
+    return e0 > s0 ? (e0 - 1) / mu - s0 / mu : 0;
+}
+__global__ void __launch_bounds__(MSM_THREADS) msm_fold_hot(XyzzW *partials, const uint32_t *task_meta, const uint32_t *task_start, uint32_t total_bins) {
+    const uint32_t gt = blockIdx.x * MSM_THREADS + threadIdx.x;
+    const uint32_t task = gt / RL, sub = gt % RL;
+    const bool live = task < task_start[total_bins];
+    const uint32_t *meta = task_meta + (size_t)(live ? task : 0) * META_PER_TASK;
+    const uint32_t nc = live ? meta[FINE + 1] : 0;
+    const uint32_t mu = nc ? (nc + MSM_THREADS - 1) / MSM_THREADS : 1;
+    uint32_t hot_mask = 0;                                    // which of this lane's RB buckets are wide
+    if (nc) for (uint32_t k = 0; k < RB; k++) if (bucket_span(meta, RB * sub + k, mu) > HOT_SPAN) hot_mask |= 1u << k;
+    if (!__any(hot_mask != 0)) return;
+    XyzzW *P = partials + (size_t)(live ? task : 0) * SLOTS_PER_TASK;
+    for (uint32_t owner = 0; owner < RL; owner++) {
+        const uint32_t m = __shfl(hot_mask, owner, RL);        // uniform over the RL lanes of the task
+        for (uint32_t k = 0; k < RB; k++) {
+            if (!((m >> k) & 1)) continue;
+            const uint32_t b = RB * owner + k, tf = meta[b] / mu, tl = (meta[b + 1] - 1) / mu;
+            XyzzW acc = xyzzw_identity();
+            for (uint32_t t = tf + 1 + sub; t <= tl; t += RL) { XyzzW o = load_xyzzw(P + SLOT_HEAD + t); xyzzw_add_nl(acc, o); }
+            for (uint32_t x = 1; x < RL; x <<= 1) { XyzzW o = shfl_xor_w(acc, x); xyzzw_add_nl(acc, o); }
+            if (sub == 0) store_xyzzw(P + SLOT_PRIMARY + b, acc);
+        }
     }
 }
 
-// Kernel B — 16 lanes per task, 8 buckets per lane: folds the lane partials of kernel A (and the
-// overflow row of a hot bucket), then T = sum_f B_f and S = sum_f (f+1) B_f by running sums inside
-// the lane and a 16-lane shuffle suffix scan across lanes.  Leaves (S, T) per task.
-__global__ void __launch_bounds__(MSM_THREADS) msm_task_reduce(const XyzzW *partials, const XyzzW *overflow, const uint32_t *task_heavy,
-                                                                const uint32_t *task_start, XyzzW *task_out, uint32_t total_bins) {
+// Kernel B — RL lanes per task, RB = 128/RL buckets per lane: T = sum_f B_f and S = sum_f (f+1) B_f with
+// B_f = the bucket's partial sums from kernel A (PRIMARY, or TAIL of the first lane + HEADs of the following
+// lanes, or TAIL + the folded PRIMARY of B0).  Running sums inside the lane (X = sum of the buckets seen so
+// far, from the top; Y = sum of the X's), then a shuffle suffix scan and a tree across the RL lanes.
+//
+// The whole kernel is a chain of full additions.  They are all issued from ONE inlined call site inside a
+// step loop — every step is "X += O" or "Y += X" with the operand selected beforehand — so the operands live
+// in registers: passing two 144-byte points to an out-of-line addition through scratch memory cost more
+// L2 write-through traffic than the arithmetic (measured 0.60 ms for this kernel against 0.3 ms of VALU work).
+__global__ void __launch_bounds__(MSM_THREADS, 2) msm_task_reduce(const XyzzW *partials, const uint32_t *task_meta,
+                                                                   const uint32_t *task_start, XyzzW *task_out, uint32_t total_bins) {
     const uint32_t gt = blockIdx.x * MSM_THREADS + threadIdx.x;
-    const uint32_t task = gt >> 4, sub = gt & 15;
-    const uint32_t ntasks = task_start[total_bins];
-    const bool live = task < ntasks;
-    XyzzW run = xyzzw_identity(), sum = xyzzw_identity(), hot_total = xyzzw_identity();
-    if (live) {
-        const uint32_t hot = task_heavy[task];
-        const XyzzW *P = partials + (size_t)task * (2 * FINE);
-        for (int k = 7; k >= 0; k--) {
-            const uint32_t b = 8 * sub + k;
-            XyzzW v = load_xyzzw(P + 2 * b), v1 = load_xyzzw(P + 2 * b + 1);
-            xyzzw_add_nl(v, v1);
-            if (hot != 0xffffffffu) {                        // uniform across the task's 16 lanes
-                // the hot bucket's 256 slices: 16 per lane, then a 16-lane tree; lane owning the bucket takes it
-                const XyzzW *O = overflow + (size_t)task * MSM_THREADS + 16 * sub;
-                XyzzW part = xyzzw_identity();
-                if (k == 7) {
-                    for (uint32_t i = 0; i < 16; i++) { XyzzW o = load_xyzzw(O + i); xyzzw_add_nl(part, o); }
-                    for (int m = 1; m < 16; m <<= 1) { XyzzW o = shfl_xor_w(part, m); xyzzw_add_nl(part, o); }
-                    hot_total = part;
-                }
-                if (b == hot) xyzzw_add_nl(v, hot_total);
+    const uint32_t task = gt / RL, sub = gt % RL;
+    const bool live = task < task_start[total_bins];
+    const uint32_t *meta = task_meta + (size_t)(live ? task : 0) * META_PER_TASK;
+    const uint32_t nc = live ? meta[FINE + 1] : 0;
+    const uint32_t mu = nc ? (nc + MSM_THREADS - 1) / MSM_THREADS : 1;
+    const XyzzW *P = partials + (size_t)(live ? task : 0) * SLOTS_PER_TASK;
+    XyzzW X = xyzzw_identity(), Y = xyzzw_identity();
+    uint32_t k = nc ? RB : 0;                                 // buckets of this lane still to open (top first)
+    uint32_t piece = 0, piece_end = 0;                        // slots of the open bucket still to add
+    bool pending_sum = false;
+    constexpr uint32_t USTEPS = RL_LOG + RB_LOG + 1 + RL_LOG;
+    uint32_t ustep = 0;
+    for (;;) {
+        const bool done = (piece >= piece_end) && !pending_sum && k == 0;
+        const bool lockstep = __all(done);                    // every lane of the wave has folded its buckets
+        if (lockstep && ustep == USTEPS) break;
+        XyzzW O = xyzzw_identity();                           // (a finished lane adds the identity: no-op)
+        bool to_y = false;
+        if (!lockstep) {
+            // (decoding one step ahead to overlap the load with the addition was measured slower: the extra
+            //  36 live registers spill)
+            if (piece < piece_end) { O = load_xyzzw(P + piece); piece++; }
+            else if (pending_sum) { to_y = true; pending_sum = false; }
+            else if (k > 0) {
+                k--;
+                const uint32_t b = RB * sub + k, s0 = meta[b], e0 = meta[b + 1];
+                if (e0 > s0) {
+                    const uint32_t tf = s0 / mu, tl = (e0 - 1) / mu;
+                    pending_sum = true;
+                    if (tf == tl) O = load_xyzzw(P + SLOT_PRIMARY + b);
+                    else {
+                        O = load_xyzzw(P + SLOT_TAIL + tf);
+                        if (tl - tf > HOT_SPAN) { piece = SLOT_PRIMARY + b; piece_end = piece + 1; }      // folded by B0
+                        else { piece = SLOT_HEAD + tf + 1; piece_end = SLOT_HEAD + tl + 1; }
+                    }
+                } else to_y = true;                           // empty bucket: only Y += X
             }
-            xyzzw_add_nl(run, v);
-            xyzzw_add_nl(sum, run);                          // sum = sum_k (k+1) * B[8 sub + k]
+        } else {
+            // S = sum_sub Y_sub + RB * sum_{sub >= 1} R_sub with R_sub = sum_{s >= sub} X_s (suffix scan); T = R_0
+            if (ustep < RL_LOG) {
+                const uint32_t off = 1u << ustep;
+                O = shfl_down_w(X, off);
+                if (sub + off >= RL) O = xyzzw_identity();
+            } else {
+                if (ustep == RL_LOG) {
+                    if (live && sub == 0) store_xyzzw(task_out + 2 * (size_t)task + 1, X);
+                    if (sub == 0) X = xyzzw_identity();
+                }
+                if (ustep < RL_LOG + RB_LOG) O = X;                               // doubling (the addition handles P + P)
+                else if (ustep == RL_LOG + RB_LOG) O = Y;
+                else O = shfl_xor_w(X, 1 << (ustep - RL_LOG - RB_LOG - 1));
+            }
+            ustep++;
         }
+        if (to_y) O = Y;
+        XyzzW Tacc = X;
+        xyzzw_add(Tacc, O);                                   // the one addition site of the kernel
+        if (to_y) Y = Tacc; else X = Tacc;
     }
-    // across the 16 lanes of the task: R_sub = sum_{s >= sub} run_s (suffix scan), then
-    // S = sum_sub sum_sub + 8 * sum_{sub >= 1} R_sub ,  T = R_0
-    XyzzW R = run;
-    for (int off = 1; off < 16; off <<= 1) {
-        XyzzW o = shfl_down_w(R, off);
-        if ((int)sub + off < 16) xyzzw_add_nl(R, o);
-    }
-    XyzzW wsum = sub >= 1 ? R : xyzzw_identity();
-    for (int i = 0; i < 3; i++) wsum = xyzzw_double(wsum);
-    xyzzw_add_nl(wsum, sum);
-    for (int m = 1; m < 16; m <<= 1) { XyzzW o = shfl_xor_w(wsum, m); xyzzw_add_nl(wsum, o); }
-    if (live && sub == 0) {
-        store_xyzzw(task_out + 2 * (size_t)task, wsum);
-        store_xyzzw(task_out + 2 * (size_t)task + 1, R);
-    }
+    if (live && sub == 0) store_xyzzw(task_out + 2 * (size_t)task, X);
 }
 
 // ------------------------------------------------------------------------ window reduction
-// one workgroup per window: W_w = sum_t S_t + 2^FINE_BITS * sum_c c * D_c,  D_c = sum of T_t over bin c.
-// The result is exported in the library's external form (canonical, R = 2^256) for the host Horner.
-__global__ void __launch_bounds__(MSM_THREADS) msm_window_sums(const XyzzW *task_out, const uint32_t *task_start, G1Xyzz *window_out, uint32_t nbins) {
+// W_w = sum_t S_t + 2^FINE_BITS * sum_c c * D_c,  D_c = sum of T_t over the tasks of coarse bin c.
+// Two workgroups per window, running side by side: role 0 tree-sums the S_t, role 1 forms sum_c c * D_c as
+// the sum of the suffix sums of D (Hillis-Steele scan through LDS, then a tree).  Both are pure chains of
+// full additions issued from one inlined call site (operands in registers, see msm_task_reduce); the
+// shift by 2^FINE_BITS and the final addition are left to the host Horner, which doubles anyway.
+// Results are exported in the library's external form (canonical, R = 2^256).
+constexpr uint32_t THREADS_LOG = 8;
+static_assert((1u << THREADS_LOG) == MSM_THREADS, "THREADS_LOG");
+__global__ void __launch_bounds__(MSM_THREADS, 2) msm_window_sums(const XyzzW *task_out, const uint32_t *task_start, G1Xyzz *window_out, uint32_t nbins) {
     __shared__ __attribute__((aligned(16))) XyzzW sh[MSM_THREADS];
-    const uint32_t tid = threadIdx.x, w = blockIdx.x;
-    XyzzW ssum = xyzzw_identity(), d = xyzzw_identity();
-    if (tid < nbins) {
-        uint32_t bin = w * nbins + tid;
-        for (uint32_t t = task_start[bin]; t < task_start[bin + 1]; t++) {
-            XyzzW sv = load_xyzzw(task_out + 2 * (size_t)t), tv = load_xyzzw(task_out + 2 * (size_t)t + 1);
-            xyzzw_add_nl(ssum, sv);
-            xyzzw_add_nl(d, tv);
+    const uint32_t tid = threadIdx.x, w = blockIdx.x, role = blockIdx.y;
+    uint32_t t = 0, t_end = 0;
+    if (tid < nbins) { t = task_start[w * nbins + tid]; t_end = task_start[w * nbins + tid + 1]; }
+    XyzzW X = xyzzw_identity();
+    const uint32_t scan_steps = role ? THREADS_LOG : 0, usteps = scan_steps + THREADS_LOG;
+    uint32_t ustep = 0;
+    for (;;) {
+        const bool lockstep = __syncthreads_and(t >= t_end);  // (also the barrier that lets sh be rewritten)
+        if (lockstep && ustep == usteps) break;
+        XyzzW O = xyzzw_identity();
+        if (!lockstep) {
+            if (t < t_end) { O = load_xyzzw(task_out + 2 * (size_t)t + role); t++; }
+        } else {
+            if (role && ustep == scan_steps && tid == 0) X = xyzzw_identity();    // sum_c c*D_c = sum_{k>=1} suffix_k
+            sh[tid] = X;
+            __syncthreads();
+            if (ustep < scan_steps) {                          // inclusive suffix scan over the bins
+                const uint32_t off = 1u << ustep;
+                if (tid + off < MSM_THREADS) O = sh[tid + off];
+            } else {
+                const uint32_t off = (MSM_THREADS / 2) >> (ustep - scan_steps);
+                if (tid < off) O = sh[tid + off];
+            }
+            ustep++;
         }
+        xyzzw_add(X, O);                                      // the one addition site of the kernel
     }
-    sh[tid] = d;
-    __syncthreads();
-    for (uint32_t off = 1; off < MSM_THREADS; off <<= 1) {   // inclusive suffix scan of D over the bins
-        XyzzW o = (tid + off < MSM_THREADS) ? sh[tid + off] : xyzzw_identity();
-        __syncthreads();
-        if (tid + off < MSM_THREADS) { xyzzw_add_nl(d, o); sh[tid] = d; }
-        __syncthreads();
-    }
-    // sum_c c*D_c = sum_{k>=1} suffix_k ; times 2^FINE_BITS ; plus the S terms
-    XyzzW v = tid >= 1 ? d : xyzzw_identity();
-    for (uint32_t i = 0; i < FINE_BITS; i++) v = xyzzw_double(v);
-    xyzzw_add_nl(v, ssum);
-    sh[tid] = v;
-    __syncthreads();
-    for (uint32_t off = MSM_THREADS / 2; off > 0; off >>= 1) {
-        if (tid < off) { XyzzW o = sh[tid + off]; xyzzw_add_nl(v, o); sh[tid] = v; }
-        __syncthreads();
-    }
-    if (tid == 0) store_xyzz(window_out + w, xyzzw_export(v));
+    if (tid == 0) store_xyzz(window_out + 2 * w + role, xyzzw_export(X));
 }
 
 // ------------------------------------------------------------------- tiny inputs: no buckets
@@ -391,7 +459,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_naive(const G1Affine *bases, 
         if (!k.is_zero() && !is_inf(pt)) {
             AffW q; q.x = unpack<FqW>(pt.x); q.y = unpack<FqW>(pt.y);
             for (int bit = 253; bit >= 0; bit--) {
-                acc = xyzzw_double(acc);
+                acc = xyzzw_double_nl(acc);
                 if ((k.l[bit >> 5] >> (bit & 31)) & 1) xyzzw_add_mixed(acc, q, false);
             }
         }
@@ -406,10 +474,11 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_naive(const G1Affine *bases, 
 }
 
 // ------------------------------------------------------------------------------ host side
-// Window widths are chosen among those whose top window still has many bits (254 = 19*13 + 7 = 15*16 + 14):
+// Window widths are chosen among those whose top window still has many bits (254 = 19*13 + 7 = 16*15 + 14 = 15*16 + 14):
 // a top window of 1-2 bits would put every term into two or three buckets of a single bin.
 static uint32_t pick_window_bits(uint64_t n) {
     if (n < (1u << 17)) return 13;
+    if (n < (1u << 19)) return 15;                            // measured: 2^18 1.27 ms (c=15) vs 1.40 ms (c=16)
     return 16;
 }
 
@@ -447,6 +516,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     MsmParams p;
     p.n = (uint32_t)n;
     p.c = pick_window_bits(n);
+    { const char *wc = getenv("PLK_MSM_C"); if (wc && atoi(wc) >= 9 && atoi(wc) <= 16) p.c = (uint32_t)atoi(wc); }   // tuning probe
     p.windows = 254 / p.c + 1;
     p.coarse_bits = p.c - 1 - FINE_BITS;
     p.nbins = 1u << p.coarse_bits;
@@ -458,14 +528,14 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     const uint32_t max_tasks = total_bins + (uint32_t)(((uint64_t)total_windows * n) / TASK_MAX) + 1;
     PLK_TRY(ctx->msm_a.reserve((size_t)(3 * total_bins + 4) * sizeof(uint32_t)));               // hist/cursor, bin_start, task_start
     PLK_TRY(ctx->msm_b.reserve((size_t)total_windows * n * sizeof(uint32_t)));                   // entries
-    PLK_TRY(ctx->msm_c.reserve((size_t)max_tasks * 2 * sizeof(XyzzW) + (size_t)max_tasks * 4));  // per-task (S, T) + hot-bucket id
-    PLK_TRY(ctx->msm_e.reserve((size_t)max_tasks * (2 * FINE + MSM_THREADS) * sizeof(XyzzW)));  // lane partials + overflow rows
-    PLK_TRY(ctx->msm_d.reserve((size_t)total_windows * sizeof(G1Xyzz)));                         // window sums
+    PLK_TRY(ctx->msm_c.reserve((size_t)max_tasks * 2 * sizeof(XyzzW) + (size_t)max_tasks * META_PER_TASK * 4));  // per-task (S, T) + bucket offsets
+    PLK_TRY(ctx->msm_e.reserve((size_t)max_tasks * SLOTS_PER_TASK * sizeof(XyzzW)));             // lane partial sums
+    PLK_TRY(ctx->msm_d.reserve((size_t)2 * total_windows * sizeof(G1Xyzz)));                     // per window: sum S, sum c*D
     uint32_t *hist = ctx->msm_a.as<uint32_t>(), *bin_start = hist + total_bins, *task_start = bin_start + total_bins + 1;
     uint32_t *entries = ctx->msm_b.as<uint32_t>();
     XyzzW *task_out = ctx->msm_c.as<XyzzW>();
-    uint32_t *task_heavy = reinterpret_cast<uint32_t *>(task_out + 2 * (size_t)max_tasks);
-    XyzzW *partials = ctx->msm_e.as<XyzzW>(), *overflow = partials + (size_t)max_tasks * 2 * FINE;
+    uint32_t *task_meta = reinterpret_cast<uint32_t *>(task_out + 2 * (size_t)max_tasks);
+    XyzzW *partials = ctx->msm_e.as<XyzzW>();
     G1Xyzz *window_out = ctx->msm_d.as<G1Xyzz>();
 
     PLK_HIP(hipMemsetAsync(hist, 0, total_bins * sizeof(uint32_t), stream));
@@ -485,14 +555,16 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks, total_windows), dim3(MSM_THREADS), plds_scatter, stream, (const int16_t *)digits, p, hist, (const uint32_t *)bin_start, entries);
     if (ctx->ev_on) PLK_HIP(hipEventRecord(ctx->ev[0], stream));
     hipLaunchKernelGGL(msm_accumulate, dim3(max_tasks), dim3(MSM_THREADS), 0, stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
-                       (const uint32_t *)task_start, partials, overflow, task_heavy, p);
+                       (const uint32_t *)task_start, partials, task_meta, p);
     if (ctx->ev_on) PLK_HIP(hipEventRecord(ctx->ev[1], stream));
-    hipLaunchKernelGGL(msm_task_reduce, dim3((max_tasks * 16 + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
-                       (const XyzzW *)partials, (const XyzzW *)overflow, (const uint32_t *)task_heavy, (const uint32_t *)task_start, task_out, total_bins);
-    hipLaunchKernelGGL(msm_window_sums, dim3(total_windows), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins);
+    hipLaunchKernelGGL(msm_fold_hot, dim3((max_tasks * RL + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
+                       partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
+    hipLaunchKernelGGL(msm_task_reduce, dim3((max_tasks * RL + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
+                       (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
+    hipLaunchKernelGGL(msm_window_sums, dim3(total_windows, 2), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins);
     PLK_HIP(hipGetLastError());
-    PLK_TRY(ensure_pinned(ctx, total_windows * sizeof(G1Xyzz)));
-    PLK_HIP(hipMemcpyAsync(ctx->pinned, window_out, total_windows * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
+    PLK_TRY(ensure_pinned(ctx, (size_t)2 * total_windows * sizeof(G1Xyzz)));
+    PLK_HIP(hipMemcpyAsync(ctx->pinned, window_out, (size_t)2 * total_windows * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
     ctx->msm_windows = p.windows;
     ctx->msm_c_bits = p.c;
     return PLK_OK;
@@ -522,10 +594,13 @@ int32_t msm_finish_batch(plk_ctx *ctx, hipStream_t stream, host::HJac *out) {
     for (uint32_t m = 0; m < ctx->msm_batch; m++) {
         HJac acc = HJac::inf();
         if (ctx->msm_windows) {
-            const uint64_t *raw = reinterpret_cast<const uint64_t *>(ctx->pinned) + (size_t)16 * m * ctx->msm_windows;
+            // per window the device leaves (sum S, sum c*D); W_w = sum S + 2^FINE_BITS * sum c*D
+            const uint64_t *raw = reinterpret_cast<const uint64_t *>(ctx->pinned) + (size_t)32 * m * ctx->msm_windows;
             for (int w = (int)ctx->msm_windows - 1; w >= 0; w--) {
                 for (uint32_t i = 0; i < ctx->msm_c_bits; i++) acc = jac_double(acc);
-                acc = jac_add(acc, xyzz_host_to_jac(raw + 16 * w));
+                HJac d = xyzz_host_to_jac(raw + 32 * w + 16);
+                for (uint32_t i = 0; i < FINE_BITS; i++) d = jac_double(d);
+                acc = jac_add(acc, jac_add(xyzz_host_to_jac(raw + 32 * w), d));
             }
         } else {
             const uint64_t *raw = reinterpret_cast<const uint64_t *>(ctx->pinned) + (size_t)16 * m * ctx->msm_pending_parts;
