@@ -67,6 +67,7 @@ struct plk_ctx {
     plk::DevBuf srs_own;
     plk::DevBuf srs_w;                       // the same points in the 2^261 Montgomery domain of field29.cuh (MSM gathers)
     bool srs_w_valid = false;
+    uint32_t srs_w_copies = 0;               // shifted copies 2^(16k) * P held in srs_w (fixed-base table of the MSM)
     // MSM scratch
     plk::DevBuf msm_a, msm_b, msm_c, msm_d, msm_e, msm_f;
     plk::DevBuf prove_ws;                    // workspace of the prover rounds (grows only)

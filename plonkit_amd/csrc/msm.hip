@@ -50,6 +50,12 @@ struct MsmParams {
     uint32_t nbins;           // 1 << coarse_bits
     uint32_t batch;           // number of scalar vectors (same n, same bases); "global window" = m * W + w
     uint32_t debug;           // experiments only: 1 = skip the additions (sort cost), 0 = normal
+    // Shifted copies of the bases (fixed-base precomputation): window w = j*groups + g takes its points from
+    // copy j*groups of the table (2^(16*j*groups) * P_i) and drops them into bucket set g, so only `groups`
+    // bucket sets have to be reduced and only c*groups doublings are left for the host Horner.
+    uint32_t groups;          // bucket sets per commitment (= windows when there is one copy)
+    uint32_t nbits;           // entry index = (j << nbits) | i
+    uint32_t copy_stride;     // points between table copies j and j+1 (= groups * srs_n)
 };
 
 struct ScalarSet { const Fr *v[MSM_MAX_BATCH]; };
@@ -96,7 +102,9 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_partition(const int16_t *digi
     const uint32_t first = blockIdx.x * DIGIT_CHUNK;
     const uint32_t last = first + DIGIT_CHUNK < p.n ? first + DIGIT_CHUNK : p.n;
     const int16_t *dg = digits + (size_t)gw * p.n;
-    hist_or_cursor += gw * p.nbins;
+    const uint32_t w = gw % p.windows, set = (gw / p.windows) * p.groups + w % p.groups;    // bucket set of this window
+    const uint32_t copy_tag = (w / p.groups) << p.nbits;                                     // which table copy its points come from
+    hist_or_cursor += set * p.nbins;
     for (uint32_t b = tid; b < p.nbins; b += MSM_THREADS) lcnt[b] = 0;
     __syncthreads();
     for (uint32_t i = first + tid; i < last; i += MSM_THREADS) {
@@ -108,7 +116,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_partition(const int16_t *digi
         for (uint32_t b = tid; b < p.nbins; b += MSM_THREADS) if (lcnt[b]) atomicAdd(&hist_or_cursor[b], lcnt[b]);
         return;
     }
-    bin_start += gw * p.nbins;
+    bin_start += set * p.nbins;
     if (tid < 64) {                                                    // exclusive scan of <= 256 counts by one wave
         uint32_t per = (p.nbins + 63) / 64, lo = tid * per, hi = lo + per < p.nbins ? lo + per : p.nbins, sum = 0;
         for (uint32_t b = lo; b < hi && b < p.nbins; b++) sum += lcnt[b];
@@ -129,7 +137,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_partition(const int16_t *digi
         int32_t d = dg[i];
         if (d) {
             uint32_t mg = (uint32_t)(d < 0 ? -d : d) - 1, bin = mg >> FINE_BITS;
-            staged[lstart[bin] + atomicAdd(&lcnt[bin], 1u)] = (i << 8) | (d < 0 ? 0x80u : 0u) | (mg & (FINE - 1));
+            staged[lstart[bin] + atomicAdd(&lcnt[bin], 1u)] = ((copy_tag | i) << 8) | (d < 0 ? 0x80u : 0u) | (mg & (FINE - 1));
         }
     }
     __syncthreads();
@@ -214,16 +222,90 @@ __global__ void __launch_bounds__(256) srs_to_w_kernel(G1Affine *out, const G1Af
     store_fp(&out[i].y, o.y);
 }
 
-__device__ __forceinline__ void accumulate_run(XyzzW &acc, const G1Affine *bases, const uint32_t *sorted, uint32_t lo, uint32_t hi) {
-    if (lo >= hi) return;
-    uint32_t e = sorted[lo];
-    G1Affine pt = load_affine(bases + (e >> 8));
-    for (uint32_t i = lo; i < hi; i++) {
-        uint32_t e_cur = e;
-        AffW cur; cur.x = unpack<FqW>(pt.x); cur.y = unpack<FqW>(pt.y);
-        if (i + 1 < hi) { e = sorted[i + 1]; pt = load_affine(bases + (e >> 8)); }   // prefetch the next gather
-        xyzzw_add_mixed(acc, cur, (e_cur & 0x80u) != 0);
+// ------------------------------------------------------------- shifted copies of the bases
+// The SRS is a fixed base: copy k of the table holds 2^(16k) * P_i (affine, W domain), built once per SRS
+// (15 x 16 doublings per point and one batched inversion per copy; 64 MB per copy at 2^20 points).
+// With all 16 copies resident a 2^20-term commitment has ONE bucket set instead of 16: the reduction
+// kernels and the host Horner shrink accordingly, the accumulate kernel gathers from a 1 GB table in
+// HBM instead of a cache-resident 64 MB one (measured: no difference, it is bound by the multiplier).
+constexpr uint32_t COPY_SHIFT = 16, MAX_COPIES = 16, NORM_K = 32;
+
+__global__ void __launch_bounds__(256) srs_shift_kernel(const G1Affine *prev, G1Xyzz *out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const G1Affine p = load_affine(prev + i);
+    G1Xyzz r = xyzz_identity();
+    if (!is_inf(p)) {
+        r = xyzz_double_affine(p);
+        for (uint32_t k = 1; k < COPY_SHIFT; k++) r = xyzz_double(r);
     }
+    store_xyzz(out + i, r);
+}
+
+// XYZZ -> affine with one field inversion per NORM_K points (Montgomery's trick on ZZZ; 1/Z = ZZ/ZZZ)
+__global__ void __launch_bounds__(256) srs_normalise_kernel(const G1Xyzz *in, Fq *prefix, G1Affine *out, uint64_t n) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lo = t * NORM_K, hi = lo + NORM_K < n ? lo + NORM_K : n;
+    if (lo >= n) return;
+    Fq acc = Fq::one();
+    for (uint64_t i = lo; i < hi; i++) {
+        Fq z = load_fp(&in[i].zzz);
+        if (!z.is_zero()) acc = ECM(acc, z);
+        store_fp(prefix + i, acc);
+    }
+    Fq inv_acc = inv(acc);
+    for (uint64_t i = hi; i-- > lo;) {
+        const G1Xyzz q = load_xyzz(in + i);
+        G1Affine o; o.x = Fq::zero(); o.y = Fq::zero();
+        if (!q.zzz.is_zero()) {
+            const Fq before = i > lo ? load_fp(prefix + i - 1) : Fq::one();
+            const Fq zi = ECM(inv_acc, before);               // 1 / ZZZ_i
+            inv_acc = ECM(inv_acc, q.zzz);
+            const Fq iz = ECM(q.zz, zi), izz = ECS(iz);       // 1 / Z, 1 / ZZ
+            o.x = ECM(q.x, izz);
+            o.y = ECM(q.y, zi);
+        }
+        store_fp(&out[i].x, o.x);
+        store_fp(&out[i].y, o.y);
+    }
+}
+
+static uint32_t table_copies_for(uint64_t srs_n) {           // the table may take up to 32 GiB of the 288 GB
+    uint32_t f = MAX_COPIES;
+    while (f > 1 && (uint64_t)f * srs_n * sizeof(G1Affine) > (32ull << 30)) f >>= 1;
+    return f;
+}
+
+static int32_t ensure_base_table(plk_ctx *ctx, uint32_t copies, hipStream_t stream) {
+    if (ctx->srs_w_valid && ctx->srs_w_copies >= copies) return PLK_OK;
+    const uint64_t n = ctx->srs_n;
+    const uint32_t blocks = (uint32_t)((n + 255) / 256);
+    PLK_TRY(ctx->srs_w.reserve((size_t)copies * n * sizeof(G1Affine)));
+    G1Affine *table = ctx->srs_w.as<G1Affine>();
+    hipLaunchKernelGGL(srs_to_w_kernel, dim3(blocks), dim3(256), 0, stream, table, reinterpret_cast<const G1Affine *>(ctx->srs), n);
+    if (copies > 1) {
+        DevBuf xyzz, prefix, aff[2];
+        PLK_TRY(xyzz.reserve(n * sizeof(G1Xyzz)));
+        PLK_TRY(prefix.reserve(n * sizeof(Fq)));
+        PLK_TRY(aff[0].reserve(n * sizeof(G1Affine)));
+        PLK_TRY(aff[1].reserve(n * sizeof(G1Affine)));
+        const G1Affine *prev = reinterpret_cast<const G1Affine *>(ctx->srs);
+        const uint32_t nblocks = (uint32_t)(((n + NORM_K - 1) / NORM_K + 255) / 256);
+        for (uint32_t k = 1; k < copies; k++) {
+            G1Affine *next = aff[k & 1].as<G1Affine>();
+            hipLaunchKernelGGL(srs_shift_kernel, dim3(blocks), dim3(256), 0, stream, prev, xyzz.as<G1Xyzz>(), n);
+            hipLaunchKernelGGL(srs_normalise_kernel, dim3(nblocks), dim3(256), 0, stream, (const G1Xyzz *)xyzz.as<G1Xyzz>(), prefix.as<Fq>(), next, n);
+            hipLaunchKernelGGL(srs_to_w_kernel, dim3(blocks), dim3(256), 0, stream, table + (size_t)k * n, (const G1Affine *)next, n);
+            prev = next;
+        }
+        hipError_t e = hipStreamSynchronize(stream);
+        xyzz.release(); prefix.release(); aff[0].release(); aff[1].release();
+        PLK_HIP(e);
+    }
+    PLK_HIP(hipGetLastError());
+    ctx->srs_w_valid = true;
+    ctx->srs_w_copies = copies;
+    return PLK_OK;
 }
 
 // Per-task output of kernel A: 128 PRIMARY slots (a bucket whose run lies inside one lane's slice), and per
@@ -246,7 +328,7 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_accumulate(const G1Affine 
     __shared__ uint32_t sorted[CHUNK];
     __shared__ uint32_t cnt[FINE], start[FINE + 1], cursor[FINE];
     const uint32_t tid = threadIdx.x, task = blockIdx.x;
-    const uint32_t total_bins = p.batch * p.windows * p.nbins;
+    const uint32_t total_bins = p.batch * p.groups * p.nbins;
     if (task >= task_start[total_bins]) return;
     uint32_t blo = 0, bhi = total_bins;                       // bin = last index with task_start[bin] <= task
     while (bhi - blo > 1) { uint32_t mid = (blo + bhi) >> 1; if (task_start[mid] <= task) blo = mid; else bhi = mid; }
@@ -281,13 +363,18 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_accumulate(const G1Affine 
     if (lo >= hi) return;
     // one flat loop over the lane's piece: every lane of the wave executes the same number of mixed additions
     // in lockstep; a bucket boundary only costs the (divergent) 144-byte flush of the finished accumulator
+    const uint32_t imask = (1u << p.nbits) - 1;
+    auto point_of = [&](uint32_t entry) -> const G1Affine * {          // (copy j, index i) -> address in the table
+        const uint32_t t = entry >> 8;
+        return bases + (size_t)(t >> p.nbits) * p.copy_stride + (t & imask);
+    };
     uint32_t en = sorted[lo], b = en & (FINE - 1), bend = start[b + 1], run_start = lo;
-    G1Affine pt = load_affine(bases + (en >> 8));
+    G1Affine pt = load_affine(point_of(en));
     XyzzW acc = xyzzw_identity();
     for (uint32_t i = lo; i < hi; i++) {
         const uint32_t e_cur = en;
         AffW cur; cur.x = unpack<FqW>(pt.x); cur.y = unpack<FqW>(pt.y);
-        if (i + 1 < hi) { en = sorted[i + 1]; pt = load_affine(bases + (en >> 8)); }   // prefetch the next gather
+        if (i + 1 < hi) { en = sorted[i + 1]; pt = load_affine(point_of(en)); }   // prefetch the next gather
         if (i == bend) {                                      // the previous bucket ended inside this piece
             const bool from_prev = (run_start == lo) && (start[b] < lo);
             store_xyzzw(out + (from_prev ? SLOT_HEAD + tid : SLOT_PRIMARY + b), acc);
@@ -489,13 +576,16 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     if (base_offset + n > ctx->srs_n) { set_error("msm: SRS too small for this commitment"); return PLK_ERR_SRS; }
     if (n >= (1ull << 24) + 1) { set_error("msm: more than 2^24 terms per call (shard the commitment)"); return PLK_ERR_SIZE; }
     if (batch < 1 || batch > MSM_MAX_BATCH) { set_error("msm: batch must be 1..8"); return PLK_ERR_ARG; }
-    if (!ctx->srs_w_valid) {                                     // resident copy of the SRS in the 2^261 domain of the lazy field layer
-        PLK_TRY(ctx->srs_w.reserve(ctx->srs_n * sizeof(G1Affine)));
-        hipLaunchKernelGGL(srs_to_w_kernel, dim3((uint32_t)((ctx->srs_n + 255) / 256)), dim3(256), 0, stream,
-                           ctx->srs_w.as<G1Affine>(), reinterpret_cast<const G1Affine *>(ctx->srs), ctx->srs_n);
-        PLK_HIP(hipGetLastError());
-        ctx->srs_w_valid = true;
+    // resident table of the SRS in the 2^261 domain of the lazy field layer; large commitments use its shifted copies
+    uint32_t nbits = 1;
+    while ((1ull << nbits) < n) nbits++;
+    const uint32_t c_bits = n >= 4096 ? pick_window_bits(n) : 0;
+    uint32_t copies = 1;
+    if (c_bits == COPY_SHIFT) {
+        copies = table_copies_for(ctx->srs_n);
+        while (copies > 1 && ((uint64_t)copies << nbits) > (1ull << 24)) copies >>= 1;     // 24-bit (copy, index) field of an entry
     }
+    PLK_TRY(ensure_base_table(ctx, copies, stream));
     const G1Affine *bases = ctx->srs_w.as<G1Affine>() + base_offset;
     ctx->msm_pending_parts = 0;
     ctx->msm_windows = 0;
@@ -515,22 +605,24 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     }
     MsmParams p;
     p.n = (uint32_t)n;
-    p.c = pick_window_bits(n);
-    { const char *wc = getenv("PLK_MSM_C"); if (wc && atoi(wc) >= 9 && atoi(wc) <= 16) p.c = (uint32_t)atoi(wc); }   // tuning probe
+    p.c = c_bits;
     p.windows = 254 / p.c + 1;
+    p.groups = p.windows / copies;                            // copies > 1 only for c = 16: 16 windows, copies | 16
+    p.nbits = nbits;
+    p.copy_stride = copies > 1 ? (uint32_t)(p.groups * ctx->srs_n) : 0;
     p.coarse_bits = p.c - 1 - FINE_BITS;
     p.nbins = 1u << p.coarse_bits;
     p.batch = batch;
     { const char *dbg = getenv("PLK_MSM_DEBUG"); p.debug = dbg ? (uint32_t)atoi(dbg) : 0; }
     ScalarSet set{};
     for (uint32_t m = 0; m < batch; m++) set.v[m] = scalars_dev[m];
-    const uint32_t bins_per = p.windows * p.nbins, total_bins = batch * bins_per, total_windows = batch * p.windows;
+    const uint32_t total_sets = batch * p.groups, total_bins = total_sets * p.nbins, total_windows = batch * p.windows;
     const uint32_t max_tasks = total_bins + (uint32_t)(((uint64_t)total_windows * n) / TASK_MAX) + 1;
     PLK_TRY(ctx->msm_a.reserve((size_t)(3 * total_bins + 4) * sizeof(uint32_t)));               // hist/cursor, bin_start, task_start
     PLK_TRY(ctx->msm_b.reserve((size_t)total_windows * n * sizeof(uint32_t)));                   // entries
     PLK_TRY(ctx->msm_c.reserve((size_t)max_tasks * 2 * sizeof(XyzzW) + (size_t)max_tasks * META_PER_TASK * 4));  // per-task (S, T) + bucket offsets
     PLK_TRY(ctx->msm_e.reserve((size_t)max_tasks * SLOTS_PER_TASK * sizeof(XyzzW)));             // lane partial sums
-    PLK_TRY(ctx->msm_d.reserve((size_t)2 * total_windows * sizeof(G1Xyzz)));                     // per window: sum S, sum c*D
+    PLK_TRY(ctx->msm_d.reserve((size_t)2 * total_sets * sizeof(G1Xyzz)));                     // per window: sum S, sum c*D
     uint32_t *hist = ctx->msm_a.as<uint32_t>(), *bin_start = hist + total_bins, *task_start = bin_start + total_bins + 1;
     uint32_t *entries = ctx->msm_b.as<uint32_t>();
     XyzzW *task_out = ctx->msm_c.as<XyzzW>();
@@ -561,11 +653,11 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
                        partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
     hipLaunchKernelGGL(msm_task_reduce, dim3((max_tasks * RL + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
                        (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
-    hipLaunchKernelGGL(msm_window_sums, dim3(total_windows, 2), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins);
+    hipLaunchKernelGGL(msm_window_sums, dim3(total_sets, 2), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins);
     PLK_HIP(hipGetLastError());
-    PLK_TRY(ensure_pinned(ctx, (size_t)2 * total_windows * sizeof(G1Xyzz)));
-    PLK_HIP(hipMemcpyAsync(ctx->pinned, window_out, (size_t)2 * total_windows * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
-    ctx->msm_windows = p.windows;
+    PLK_TRY(ensure_pinned(ctx, (size_t)2 * total_sets * sizeof(G1Xyzz)));
+    PLK_HIP(hipMemcpyAsync(ctx->pinned, window_out, (size_t)2 * total_sets * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
+    ctx->msm_windows = p.groups;
     ctx->msm_c_bits = p.c;
     return PLK_OK;
 }
