@@ -28,11 +28,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 ALGO_BYTES_PER_TERM = 96         # 64 B base + 32 B scalar
 # PMC traffic of msm_accumulate for ONE 2^20-term launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-# separate passes, profiles/r01_pmc_traffic_bench.csv, single-commitment rows): 1,054,298 KB fetched
-# (the 16 per-window gathers of the 64 MiB SRS, 64 B per lane — served by the Infinity Cache, which the
-# counter includes) + 197,522 KB written (lane partial sums).  Only valid for --log-n 20, N=1.
-PMC_TRAFFIC_BYTES_2POW20 = (1054298 + 197522) * 1024
-VALU_PEAK_GMADD = 14.6           # tools/ubench_w: isolated mixed-addition loop, G additions/s (profiles/r01_ubench_w.txt)
+# separate passes, profiles/r01_pmc_traffic_v2.txt, median of the single-commitment launches):
+# 1,091,894 KB fetched (16.8 M gathers of one 64-byte point each from the 1 GiB fixed-base table
+# = 1.07 GB, + 67 MB of sorted entries: the counter is consistent with 64 B per gather, i.e. no
+# over-fetch) + 132,115 KB written (lane partial sums).  Only valid for --log-n 20, N=1.
+PMC_TRAFFIC_BYTES_2POW20 = (1091894 + 132115) * 1024
+VALU_PEAK_GMADD = 15.6           # tools/ubench_w: isolated mixed-addition loop, G additions/s (profiles/r01_ubench_w.txt)
 
 
 def rand_scalars(n, seed, device):
@@ -144,8 +145,8 @@ def main():
                                   "frac": round(n * (254 // 16 + 1) / (k_ms * 1e-3) / 1e9 / VALU_PEAK_GMADD, 3)},
                          "note": "the kernel is bound by v_mad_u64_u32 issue, not HBM (SURVEY.md §8d): `valu` compares its "
                                  "mixed-addition rate with the same loop measured in isolation (tools/ubench_w); `traffic` "
-                                 "is 12x the algorithmic bytes because Pippenger gathers every base once per window "
-                                 "(16 windows), from the Infinity-Cache-resident SRS"},
+                                 "is 12x the algorithmic bytes because Pippenger gathers one 64-byte point per (term, window): "
+                                 "16 windows, each from its own shifted copy of the SRS (1 GiB fixed-base table in HBM)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb, ref, s_host = cpu_baseline(ctx, min(args.cpu_log_n, args.log_n), 1234)
