@@ -118,6 +118,15 @@ void plk_transcript_absorb_g1(plk_transcript *t, const plk_g1_affine *p);
 void plk_transcript_challenge(plk_transcript *t, plk_fr *out);
 void plk_keccak256(const uint8_t *in, uint64_t len, uint8_t out[32]);
 
+/* ---- verifier (pure CPU, as in the reference): verifier::verify::<E,P,RollingKeccakTranscript>(&proof,&vk,None)
+ *      behind plonk::verify (src/plonk.rs:189-210; CLI src/bin/main.rs:425-437).  Takes the bytes of vk.bin and
+ *      proof.bin; *valid = 1/0.  Malformed files (short, point off the curve, scalar >= r)
+ *      return PLK_ERR_ARG — the reference panics in its readers at that point.  The final check
+ *      e(A, g2[0]) * e(B, g2[1]) == 1 is a real BN254 optimal-ate pairing (pairing.cpp), no trapdoor.          */
+int32_t plk_verify(const uint8_t *vk, uint64_t vk_len, const uint8_t *proof, uint64_t proof_len, int32_t *valid);
+/* e(a, g2_a) * e(b, g2_b) == 1 ?   G2 as 128 bytes x.c1|x.c0|y.c1|y.c0 big-endian (the key/vk file encoding) */
+int32_t plk_pairing_check(const plk_g1_affine *a, const uint8_t *g2_a, const plk_g1_affine *b, const uint8_t *g2_b, int32_t *is_one);
+
 /* ---- circuit pipeline: circom loaders + transpile + setup + prove ----------------------------
  * plk_circuit mirrors CircomCircuit{r1cs, witness, wire_mapping: None, aux_offset: 1}
  * (src/circom_circuit.rs:41-47).  Loaders follow src/reader.rs:178-241, src/r1cs_file.rs:100-154

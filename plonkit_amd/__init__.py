@@ -7,7 +7,8 @@ CPU fallback: creating a Context without a gfx950 device raises.
 """
 from ._lib import (PlkError, lib, lib_path, Context, last_error, have_gpu,   # noqa: F401
                    g1_sum_jacobian, g1_to_bytes, g1_from_bytes, fr_to_bytes, fr_from_bytes,
-                   Transcript, keccak256, Circuit, SetupForProver)
+                   Transcript, keccak256, Circuit, SetupForProver, verify, pairing_check, crs42_g2_bytes)
 
 __all__ = ["PlkError", "lib", "lib_path", "Context", "last_error", "have_gpu", "g1_sum_jacobian",
-           "g1_to_bytes", "g1_from_bytes", "fr_to_bytes", "fr_from_bytes", "Transcript", "keccak256", "Circuit", "SetupForProver"]
+           "g1_to_bytes", "g1_from_bytes", "fr_to_bytes", "fr_from_bytes", "Transcript", "keccak256", "Circuit", "SetupForProver",
+           "verify", "pairing_check", "crs42_g2_bytes"]

@@ -334,6 +334,27 @@ def fr_from_bytes(b):
     return out
 
 
+def verify(vk_bytes, proof_bytes):
+    """plonk::verify(&vk, &proof, "keccak") (src/plonk.rs:189-210) on the bytes of vk.bin / proof.bin; pure CPU."""
+    valid = ctypes.c_int32(0)
+    _check(lib().plk_verify(bytes(vk_bytes), ctypes.c_uint64(len(vk_bytes)), bytes(proof_bytes), ctypes.c_uint64(len(proof_bytes)), ctypes.byref(valid)))
+    return bool(valid.value)
+
+
+def pairing_check(a, g2_a, b, g2_b):
+    """e(a, g2_a) * e(b, g2_b) == 1 ; G1 as 8 x u64 Montgomery affine, G2 as the 128-byte file encoding"""
+    out = ctypes.c_int32(0)
+    a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)
+    _check(lib().plk_pairing_check(_np(a), bytes(g2_a), _np(b), bytes(g2_b), ctypes.byref(out)))
+    return bool(out.value)
+
+
+def crs42_g2_bytes():
+    out = ctypes.create_string_buffer(256)
+    lib().plk_crs42_g2_bytes(out)
+    return out.raw
+
+
 def keccak256(data):
     out = ctypes.create_string_buffer(32)
     lib().plk_keccak256(bytes(data), ctypes.c_uint64(len(data)), out)

@@ -1,5 +1,5 @@
 // `plonkit` command line over the C ABI — the five prover commands of the reference's CLI
-// (src/bin/main.rs:27-53): setup, dump-lagrange, prove, export-verification-key, analyse (+ verify stub).
+// (src/bin/main.rs:27-53): setup, dump-lagrange, prove, export-verification-key, analyse, verify.
 // Same option names, short flags and defaults (src/bin/main.rs:55-136,176-190), same refusal to overwrite
 // (src/bin/main.rs:336-339,374-377,403-406) and the circuit-file default rule (src/bin/main.rs:346-357).
 // Everything arithmetic goes through include/plonkit_amd.h.
@@ -164,9 +164,14 @@ int main(int argc, char **argv) {
         refuse_duplicate(a, out, "proof");
         spit(out, buf.data(), len);
         fprintf(stderr, "Proof saved to %s\n", out.c_str());
-    } else if (cmd == "verify") {
-        fprintf(stderr, "verify: the host-side BN254 pairing is not part of this build yet; use the reference `plonkit verify` on the produced proof.bin\n");
-        return 2;
+    } else if (cmd == "verify") {                                    // src/bin/main.rs:425-437 (no GPU involved)
+        Args a = parse(argc, argv, {{"p", "proof"}, {"v", "vk"}, {"t", "transcript"}});
+        if (a.get("transcript", "keccak") != "keccak") { fprintf(stderr, "not implemented: transcript '%s' (only keccak; rescue needs franklin-crypto)\n", a.get("transcript").c_str()); return 101; }
+        std::vector<uint8_t> vk = slurp(a.get("vk", "vk.bin"), "read vk file err"), pr = slurp(a.get("proof", "proof.bin"), "read proof file err");
+        int32_t valid = 0;
+        CK("fail to verify proof", plk_verify(vk.data(), vk.size(), pr.data(), pr.size(), &valid));
+        if (valid) fprintf(stderr, "Proof is valid.\n");
+        else { fprintf(stderr, "Proof is invalid!\n"); return 400 & 0xff; }   // std::process::exit(400): the shell sees 144
     } else {
         fprintf(stderr, "error: unrecognized subcommand '%s'\n", cmd.c_str());
         return 2;

@@ -1,0 +1,202 @@
+// PLONK verifier on the host: bellman_ce::plonk::better_cs::verifier::verify as plonkit calls it
+// (reference call site src/plonk.rs:189-210, CLI src/bin/main.rs:425-437); the algorithm is the one the
+// reference's Solidity template spells out (contrib/template.sol:445-494 verify_initial, 496-586
+// verify_at_z, 588-689 reconstruct_d, 691-758 verify_commitments) over the file formats of SURVEY.md A.1.
+// Keccak transcript only (`-t keccak`); CPU code in the reference too.
+#include "../../include/plonkit_amd.h"
+#include "keccak.h"
+#include "pairing.h"
+#include <string>
+#include <vector>
+
+namespace plk { void set_error(const std::string &msg); }
+#define PLK_API extern "C" __attribute__((visibility("default")))
+using namespace plk;
+using namespace plk::host;
+
+namespace {
+
+struct Reader {
+    const uint8_t *p; uint64_t left; bool ok = true;
+    uint64_t u64() {
+        if (left < 8) { ok = false; return 0; }
+        uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | p[i];
+        p += 8; left -= 8; return v;
+    }
+    HFr fr() {
+        HFr v = HFr::zero();
+        if (left < 32) { ok = false; return v; }
+        if (!HFr::from_be_bytes(p, &v)) ok = false;
+        p += 32; left -= 32; return v;
+    }
+    HAffine g1() {
+        HAffine a; a.x = HFq::zero(); a.y = HFq::zero();
+        if (left < 64) { ok = false; return a; }
+        if (!g1_from_bytes(p, &a) || !on_curve(a)) ok = false;
+        p += 64; left -= 64; return a;
+    }
+    G2Affine g2() {
+        G2Affine a; a.inf = true; a.x = Fq2::zero(); a.y = Fq2::zero();
+        if (left < 128) { ok = false; return a; }
+        if (!g2_from_bytes(p, &a)) ok = false;
+        p += 128; left -= 128; return a;
+    }
+    template <class T, class Fn> bool vec(std::vector<T> &out, uint64_t expect, Fn rd) {
+        uint64_t n = u64();
+        if (!ok || (expect && n != expect) || n > 1024) { ok = false; return false; }
+        for (uint64_t i = 0; i < n && ok; i++) out.push_back(rd());
+        return ok;
+    }
+};
+
+struct Vk {
+    uint64_t n, num_inputs;
+    std::vector<HAffine> selectors, next_step, sigma;
+    std::vector<HFr> non_residues;
+    G2Affine g2[2];
+};
+struct ProofData {
+    uint64_t n;
+    std::vector<HFr> inputs, wire_z, wire_zw, sigma_z;
+    std::vector<HAffine> wires, quotient;
+    HAffine grand_product, open_z, open_zw;
+    HFr z_zw, t_z, r_z;
+};
+
+bool parse_vk(const uint8_t *b, uint64_t len, Vk *vk) {
+    Reader r{b, len};
+    vk->n = r.u64(); vk->num_inputs = r.u64();
+    r.vec(vk->selectors, 6, [&] { return r.g1(); });
+    r.vec(vk->next_step, 1, [&] { return r.g1(); });
+    r.vec(vk->sigma, 4, [&] { return r.g1(); });
+    r.vec(vk->non_residues, 3, [&] { return r.fr(); });
+    vk->g2[0] = r.g2(); vk->g2[1] = r.g2();
+    return r.ok && r.left == 0;
+}
+bool parse_proof(const uint8_t *b, uint64_t len, ProofData *p) {
+    Reader r{b, len};
+    p->n = r.u64();
+    r.vec(p->inputs, 0, [&] { return r.fr(); });
+    r.vec(p->wires, 4, [&] { return r.g1(); });
+    p->grand_product = r.g1();
+    r.vec(p->quotient, 4, [&] { return r.g1(); });
+    r.vec(p->wire_z, 4, [&] { return r.fr(); });
+    r.vec(p->wire_zw, 1, [&] { return r.fr(); });
+    p->z_zw = r.fr(); p->t_z = r.fr(); p->r_z = r.fr();
+    r.vec(p->sigma_z, 3, [&] { return r.fr(); });
+    p->open_z = r.g1(); p->open_zw = r.g1();
+    return r.ok && r.left == 0;
+}
+
+HFr omega_of(uint32_t log_n) {                                // omega_{2^28} = 7^((r-1)/2^28), SURVEY.md A.2
+    const uint64_t c[4] = {0xd34f1ed960c37c9cULL, 0x3215cf6dd39329c8ULL, 0x98865ea93dd31f74ULL, 0x03ddb9f5166d18b7ULL};
+    HFr w = HFr::from_canonical(c);
+    for (uint32_t i = log_n; i < 28; i++) w = w.sqr();
+    return w;
+}
+
+HJac smul(const HAffine &p, const HFr &k) { uint64_t c[4]; k.to_canonical(c); return jac_mul(jac_from_affine(p), c); }
+HJac smulj(const HJac &p, const HFr &k) { uint64_t c[4]; k.to_canonical(c); return jac_mul(p, c); }
+
+bool verify_keccak(const Vk &vk, const ProofData &P) {
+    const uint64_t N = vk.n + 1;
+    if (N < 2 || (N & (N - 1)) || N > (1ull << 28)) return false;
+    uint32_t log_n = 0; while ((1ull << log_n) < N) log_n++;
+    if (P.n != vk.n || P.inputs.size() != vk.num_inputs || vk.num_inputs < 1) return false;
+    const HFr om = omega_of(log_n), one = HFr::one();
+    RollingKeccak tr;
+    for (const HFr &x : P.inputs) tr.absorb_fr(x);
+    for (const HAffine &c : P.wires) tr.absorb_g1(c);
+    const HFr beta = tr.challenge(), gamma = tr.challenge();
+    tr.absorb_g1(P.grand_product);
+    const HFr alpha = tr.challenge();
+    for (const HAffine &c : P.quotient) tr.absorb_g1(c);
+    const HFr z = tr.challenge();
+    HFr zN = z; for (uint32_t i = 0; i < log_n; i++) zN = zN.sqr();
+    if (zN == one) return false;
+    // L_i(z) = w^i (z^N - 1) / (N (z - w^i)) for the public-input rows
+    std::vector<HFr> lag(vk.num_inputs);
+    { HFr wi = one; const HFr nf = HFr::from_u64(N);
+      for (uint64_t i = 0; i < vk.num_inputs; i++) { lag[i] = wi * (zN - one) * (nf * (z - wi)).inv(); wi = wi * om; } }
+    const std::vector<HFr> &wz = P.wire_z, &sz = P.sigma_z;
+    // verify_at_z: t(z) (z^N - 1) == r(z) + PI(z) - alpha z(zw) prod_j(..) (gamma + d) - alpha^2 L_0(z)
+    {
+        const HFr lhs = (zN - one) * P.t_z;
+        HFr rhs = P.r_z;
+        for (uint64_t i = 0; i < vk.num_inputs; i++) rhs = rhs + lag[i] * P.inputs[i];
+        HFr zpart = P.z_zw;
+        for (int j = 0; j < 3; j++) zpart = zpart * (sz[j] * beta + gamma + wz[j]);
+        zpart = zpart * (gamma + wz[3]) * alpha;
+        rhs = rhs - zpart - lag[0] * alpha * alpha;
+        if (!(lhs == rhs)) return false;
+    }
+    for (const HFr &x : wz) tr.absorb_fr(x);
+    for (const HFr &x : P.wire_zw) tr.absorb_fr(x);
+    for (const HFr &x : sz) tr.absorb_fr(x);
+    tr.absorb_fr(P.t_z); tr.absorb_fr(P.r_z); tr.absorb_fr(P.z_zw);
+    const HFr v = tr.challenge();
+    tr.absorb_g1(P.open_z); tr.absorb_g1(P.open_zw);
+    const HFr u = tr.challenge();
+
+    // reconstruct_d: the commitment of the linearisation polynomial
+    HJac d = jac_from_affine(vk.selectors[5]);
+    for (int j = 0; j < 4; j++) d = jac_add(d, smul(vk.selectors[j], wz[j]));
+    d = jac_add(d, smul(vk.selectors[4], wz[0] * wz[1]));
+    d = jac_add(d, smul(vk.next_step[0], P.wire_zw[0]));
+    HFr gz = z * beta + wz[0] + gamma;
+    for (int j = 0; j < 3; j++) gz = gz * (z * vk.non_residues[j] * beta + gamma + wz[j + 1]);
+    gz = gz * alpha + lag[0] * alpha * alpha;
+    HFr v9 = one; for (int i = 0; i < 9; i++) v9 = v9 * v;      // v^(1 + 1 + 4 + 4 - 1)
+    const HFr gzw = v9 * u;
+    HFr last = one;
+    for (int j = 0; j < 3; j++) last = last * (beta * sz[j] + gamma + wz[j]);
+    last = last * beta * P.z_zw * alpha;
+    HJac t = jac_add(smul(P.grand_product, gz), jac_neg(smul(vk.sigma[3], last)));
+    d = smulj(jac_add(d, t), v);
+    d = jac_add(d, smul(P.grand_product, gzw));
+
+    // verify_commitments: aggregate the openings at z and z*omega
+    HJac agg = jac_from_affine(P.quotient[0]);
+    { HFr tf = one; for (int k = 1; k < 4; k++) { tf = tf * zN; agg = jac_add(agg, smul(P.quotient[k], tf)); } }
+    HFr ch = v;
+    agg = jac_add(agg, d);
+    for (const HAffine &c : P.wires) { ch = ch * v; agg = jac_add(agg, smul(c, ch)); }
+    for (int j = 0; j < 3; j++) { ch = ch * v; agg = jac_add(agg, smul(vk.sigma[j], ch)); }
+    ch = ch * v; ch = ch * v;
+    agg = jac_add(agg, smul(P.wires[3], ch * u));
+    ch = v;
+    HFr val = P.t_z + P.r_z * ch;
+    for (const HFr &x : wz) { ch = ch * v; val = val + x * ch; }
+    for (const HFr &x : sz) { ch = ch * v; val = val + x * ch; }
+    ch = ch * v; val = val + P.z_zw * ch * u;
+    ch = ch * v; val = val + P.wire_zw[0] * ch * u;
+    HAffine G; G.x = HFq::from_u64(1); G.y = HFq::from_u64(2);
+    agg = jac_add(agg, jac_neg(smul(G, val)));
+    HJac pg = jac_add(agg, smul(P.open_z, z));
+    pg = jac_add(pg, smul(P.open_zw, z * om * u));
+    HJac px = jac_neg(jac_add(smul(P.open_zw, u), jac_from_affine(P.open_z)));
+    // e(pg, g2[0]) * e(px, g2[1]) == 1
+    const HAffine g1s[2] = {jac_to_affine(pg), jac_to_affine(px)};
+    return pairing_product_is_one(g1s, vk.g2, 2);
+}
+
+}  // namespace
+
+PLK_API int32_t plk_verify(const uint8_t *vk_bytes, uint64_t vk_len, const uint8_t *proof_bytes, uint64_t proof_len, int32_t *valid) {
+    if (!vk_bytes || !proof_bytes || !valid) { set_error("plk_verify: null argument"); return PLK_ERR_ARG; }
+    Vk vk; ProofData pr;
+    if (!parse_vk(vk_bytes, vk_len, &vk)) { set_error("plk_verify: malformed verification key"); return PLK_ERR_ARG; }
+    if (!parse_proof(proof_bytes, proof_len, &pr)) { set_error("plk_verify: malformed proof"); return PLK_ERR_ARG; }
+    *valid = verify_keccak(vk, pr) ? 1 : 0;
+    return PLK_OK;
+}
+
+PLK_API int32_t plk_pairing_check(const plk_g1_affine *a, const uint8_t *g2_a, const plk_g1_affine *b, const uint8_t *g2_b, int32_t *is_one) {
+    if (!a || !b || !g2_a || !g2_b || !is_one) { set_error("plk_pairing_check: null argument"); return PLK_ERR_ARG; }
+    HAffine g1s[2]; G2Affine g2s[2];
+    memcpy(&g1s[0], a, 64); memcpy(&g1s[1], b, 64);
+    if (!on_curve(g1s[0]) || !on_curve(g1s[1])) { set_error("plk_pairing_check: G1 point not on the curve"); return PLK_ERR_ARG; }
+    if (!g2_from_bytes(g2_a, &g2s[0]) || !g2_from_bytes(g2_b, &g2s[1])) { set_error("plk_pairing_check: G2 point not on the twist"); return PLK_ERR_ARG; }
+    *is_one = pairing_product_is_one(g1s, g2s, 2) ? 1 : 0;
+    return PLK_OK;
+}

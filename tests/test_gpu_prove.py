@@ -128,22 +128,24 @@ def test_prove_2pow20_verifies(ctx):
     2^20 tau=42 SRS generated on the GPU.  The oracle cannot re-prove this in test time, so parity is
     checked through the size-independent property: the reference verifier algorithm
     (contrib/template.sol, oracle restatement) accepts the proof against the GPU-made verification key,
-    rejects it after tampering, and proving twice gives identical bytes (deterministic prover)."""
+    rejects it after tampering — and so does the library's own host verifier with a real pairing —, and proving twice gives identical bytes (deterministic prover)."""
     import plonkit_amd as pa
     log_n = 20
     circ = pa.Circuit.synthetic((1 << log_n) - 2)
     ctx.srs_generate(1 << log_n, 0, 42)
     setup = pa.SetupForProver(ctx, circ)
     assert setup.domain_size == 1 << log_n
-    g2 = bytes(range(256))
-    vk = po.read_vk(setup.verification_key_bytes(g2))
+    vk_bytes = setup.verification_key_bytes(pa.crs42_g2_bytes())
+    vk = po.read_vk(vk_bytes)
     proof_bytes = setup.prove(circ)
     assert setup.prove(circ) == proof_bytes
     P = po.read_proof(proof_bytes)
     assert P.n == (1 << log_n) - 1 and len(P.inputs) == 1
-    assert po.verify(vk, P, tau=42)
+    assert po.verify(vk, P, tau=42)                                   # oracle verifier (tau trapdoor)
+    assert pa.verify(vk_bytes, proof_bytes)                           # host verifier of the library (real pairing)
     P.quotient_polynomial_at_z = (P.quotient_polynomial_at_z + 1) % R_MOD
     assert not po.verify(vk, P, tau=42)
+    assert not pa.verify(vk_bytes, po.write_proof(P))
 
 
 def test_cli_end_to_end_golden(ctx, golden_dir, golden_crs, tmp_path):
@@ -163,6 +165,7 @@ def test_cli_end_to_end_golden(ctx, golden_dir, golden_crs, tmp_path):
     assert open(vk, "rb").read() == open(os.path.join(golden_dir, "vk.bin"), "rb").read()
     subprocess.check_call([cli, "prove", "-m", key, "-c", circ, "-w", wit, "-p", proof], stderr=subprocess.DEVNULL)
     assert open(proof, "rb").read() == open(os.path.join(golden_dir, "proof.bin"), "rb").read()
+    subprocess.check_call([cli, "verify", "-p", proof, "-v", vk], stderr=subprocess.DEVNULL)
     subprocess.check_call([cli, "prove", "-m", key, "-c", circ, "-w", wit, "-p", proof, "--overwrite"], stderr=subprocess.DEVNULL)
     assert subprocess.call([cli, "prove", "-m", key, "-c", circ, "-w", wit, "-p", proof], stderr=subprocess.DEVNULL) == 101
     lag = str(tmp_path / "lagrange.key")
