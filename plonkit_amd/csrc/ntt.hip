@@ -75,21 +75,67 @@ __device__ __forceinline__ FrW9 small_tw(const PowTable &t, uint32_t i, uint32_t
     return ldw(t.hi + (i << (POW_SPLIT - log_r)));
 }
 
-// log2(R) radix-2 DIT stages over an LDS tile of R rows x C columns (element (i, c) at i*pitch + c),
-// input rows in bit-reversed order.  Values stay lazily reduced: each stage adds at most 2p.
+// log2(R) DIT stages over an LDS tile of R rows x C columns (element (i, c) at i*pitch + c), input rows in
+// bit-reversed order.  Values stay lazily reduced: each stage adds at most 2p.
+//
+// Two stages at a time (radix 4 in registers): a group is the four rows i0 + {0, h, 2h, 3h}; stage s pairs
+// (0,1) and (2,3) with omega_{2h}^jl, stage s+1 pairs (0,2) with omega_{4h}^jl and (1,3) with omega_{4h}^(jl+h).
+// That halves the LDS round trips and barriers.  A full 2048-element tile gives every thread exactly two
+// groups; both are loaded (8 elements + 6 twiddles) before the first product so that the LDS and L2 latencies
+// are paid once per eight products — with 74 KB of LDS per workgroup only two waves share a SIMD, and the
+// one-butterfly-at-a-time version left the multiplier idle about 40 % of the time.
+struct Radix4Group {
+    FrW9 x0, x1, x2, x3, t1, t2, t3;
+    uint32_t a0, a1, a2, a3;
+};
+
+__device__ __forceinline__ void r4_load(Radix4Group &q, const LdsTile &L, const PowTable &tw, uint32_t g, uint32_t s,
+                                        uint32_t log_r, uint32_t log_c, uint32_t pitch) {
+    const uint32_t C = 1u << log_c, h = 1u << s;
+    const uint32_t c = g & (C - 1), j = g >> log_c, jl = j & (h - 1);
+    const uint32_t i0 = ((j >> s) << (s + 2)) | jl;
+    q.a0 = i0 * pitch + c; q.a1 = q.a0 + h * pitch; q.a2 = q.a1 + h * pitch; q.a3 = q.a2 + h * pitch;
+    q.x0 = L.get(q.a0); q.x1 = L.get(q.a1); q.x2 = L.get(q.a2); q.x3 = L.get(q.a3);
+    if (s) q.t1 = small_tw(tw, jl << (log_r - s - 1), log_r);
+    q.t2 = small_tw(tw, jl << (log_r - s - 2), log_r);
+    q.t3 = small_tw(tw, (jl + h) << (log_r - s - 2), log_r);
+}
+
+__device__ __forceinline__ void r4_finish(const Radix4Group &q, const LdsTile &L, uint32_t s) {
+    const FrW9 y1 = s ? mulw(q.x1, q.t1) : normw(q.x1), y3 = s ? mulw(q.x3, q.t1) : normw(q.x3);   // stage 0: twiddle 1
+    const FrW9 b0 = addn(q.x0, y1), b1 = sub2(q.x0, y1);
+    const FrW9 b2 = mulw(addn(q.x2, y3), q.t2), b3 = mulw(sub2(q.x2, y3), q.t3);
+    L.put(q.a0, addn(b0, b2)); L.put(q.a2, sub2(b0, b2));
+    L.put(q.a1, addn(b1, b3)); L.put(q.a3, sub2(b1, b3));
+}
+
 __device__ __forceinline__ void dit_stages(const LdsTile &L, const PowTable &tw, uint32_t log_r, uint32_t log_c, uint32_t pitch, uint32_t tid) {
-    const uint32_t C = 1u << log_c, half_tile = 1u << (log_r + log_c - 1);
-    for (uint32_t s = 0; s < log_r; s++) {
-        const uint32_t h = 1u << s;
+    const uint32_t C = 1u << log_c, half_tile = 1u << (log_r + log_c - 1), quarter_tile = half_tile >> 1;
+    uint32_t s = 0;
+    if (log_r & 1) {                                          // odd number of stages: one twiddle-free radix-2 stage first
         for (uint32_t b = tid; b < half_tile; b += NTT_THREADS) {
             uint32_t c = b & (C - 1), j = b >> log_c;
-            uint32_t jl = j & (h - 1);
-            uint32_t i0 = (((j >> s) << (s + 1)) | jl), i1 = i0 + h;
-            FrW9 u = L.get(i0 * pitch + c), v = L.get(i1 * pitch + c);
-            if (s) v = mulw(v, small_tw(tw, jl << (log_r - s - 1), log_r));
-            else v = normw(v);
+            uint32_t i0 = j << 1, i1 = i0 + 1;
+            FrW9 u = L.get(i0 * pitch + c), v = normw(L.get(i1 * pitch + c));
             L.put(i0 * pitch + c, addn(u, v));
-            L.put(i1 * pitch + c, sub2(u, v));               // v < 2p after the product (stage 0: inputs < 1.1p)
+            L.put(i1 * pitch + c, sub2(u, v));               // inputs < 1.1p
+        }
+        __syncthreads();
+        s = 1;
+    }
+    for (; s < log_r; s += 2) {
+        if (quarter_tile == 2 * NTT_THREADS) {
+            Radix4Group q0, q1;
+            r4_load(q0, L, tw, tid, s, log_r, log_c, pitch);
+            r4_load(q1, L, tw, tid + NTT_THREADS, s, log_r, log_c, pitch);
+            r4_finish(q0, L, s);
+            r4_finish(q1, L, s);
+        } else {
+            for (uint32_t g = tid; g < quarter_tile; g += NTT_THREADS) {
+                Radix4Group q;
+                r4_load(q, L, tw, g, s, log_r, log_c, pitch);
+                r4_finish(q, L, s);
+            }
         }
         __syncthreads();
     }
@@ -267,7 +313,7 @@ int32_t ntt_dev(plk_ctx *ctx, Fr *data, uint32_t log_n, bool inverse, const Fr *
     uint32_t d[4] = {0, 0, 0, 0}, p = 1;
     if (log_n <= LOG_TILE) d[0] = log_n;
     else {
-        p = (log_n + 8) / 9;
+        p = (log_n + 9) / 10;                              // up to 10 bits per pass: 2^20 = 10 + 10 (two passes)
         for (uint32_t i = 0; i < p; i++) d[i] = log_n / p + (i < log_n % p ? 1 : 0);
     }
     const size_t n = (size_t)1 << log_n;

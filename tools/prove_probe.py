@@ -1,0 +1,14 @@
+"""one setup + N proves at the 2^log_n domain (for rocprofv3 --kernel-trace --stats): python tools/prove_probe.py [log_n] [proves]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import plonkit_amd as pa
+log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+ctx = pa.Context(0)
+ctx.srs_generate(1 << log_n, 0, 42)
+circ = pa.Circuit.synthetic((1 << log_n) - 2)
+setup = pa.SetupForProver(ctx, circ)
+setup.prove(circ)
+for _ in range(reps):
+    t0 = time.perf_counter(); setup.prove(circ); dt = time.perf_counter() - t0
+    print("prove 2^%d: %.2f ms  %s" % (log_n, dt * 1e3, {k: round(v, 2) for k, v in setup.timings_ms().items()}), flush=True)
