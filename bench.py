@@ -53,13 +53,42 @@ def cpu_baseline(ctx, log_sample, seed):
     rng = np.random.default_rng(seed)
     s = rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64)
     s[:, 3] &= np.uint64((1 << 60) - 1)
-    cores = os.cpu_count() or 1
+    # the restatement keeps bellman's per-thread bucket arrays, whose reduction grows with the thread count: on the
+    # 256-core GPU host 16 threads is the fastest setting (profiles/r01_cpu_msm_threads.txt: 1.49 M/s at 16, 0.06 at 256)
+    cores = min(os.cpu_count() or 1, 16)
     ol.msm(bases[:1024], s[:1024], threads=cores)            # warm the library
     t0 = time.perf_counter()
     ref = ol.msm(bases, s, threads=cores)
     dt = time.perf_counter() - t0
     return {"value": m / dt / 1e6, "unit": "Mscalar·mul/s", "cores": cores, "kind": "port",
             "sample": "one dense_multiexp (c=ceil(ln n), per-thread buckets) of 2^%d uniform scalars, %.2f s" % (log_sample, dt)}, ref, s
+
+
+def cpu_prove_baseline(ctx, log_domain):
+    """the oracle's restatement of the whole prove (numpy glue + OpenMP C kernels, kind "port") on a smaller
+    domain than the headline one, beside the HIP prover on the SAME circuit, witness and SRS; the two proofs
+    must be byte-identical.  Bounded sample: 2^16 gates is ~5-10 s of CPU work."""
+    import plonkit_amd as pa
+    from oracle import oracle_lib as ol, plonk_oracle as po      # checker / baseline only
+    circ = pa.Circuit.synthetic((1 << log_domain) - 2)
+    r1cs, wit = po.load_r1cs_bin(circ.export("r1cs")), po.parse_wtns(circ.export("wtns"))
+    srs_keep = ctx.srs_size()
+    ctx.srs_generate(1 << log_domain, 0, 42)
+    crs = po.Crs(ctx.srs_download(0, 1 << log_domain), b"\x01" * 256)
+    S = po.setup(r1cs)
+    t0 = time.perf_counter()
+    ref = po.write_proof(po.prove(r1cs, wit, crs, S))
+    cpu_s = time.perf_counter() - t0
+    setup = pa.SetupForProver(ctx, circ)
+    setup.prove(circ)
+    t0 = time.perf_counter()
+    got = setup.prove(circ)
+    gpu_s = time.perf_counter() - t0
+    setup.close(); circ.close()
+    ctx.srs_generate(srs_keep, 0, 42)
+    return {"domain": 1 << log_domain, "cpu_s": round(cpu_s, 3), "gpu_s": round(gpu_s, 5), "threads": ol.ncpu(),
+            "kind": "port", "proof_bytes_identical": bool(got == ref),
+            "sample": "one prove (rounds 1-5, 11 MSM + 25 NTT-equivalents) of a synthetic 2^%d-gate circuit" % log_domain}
 
 
 def main():
@@ -152,6 +181,7 @@ def main():
             cb, ref, s_host = cpu_baseline(ctx, min(args.cpu_log_n, args.log_n), 1234)
             got = ctx.msm(s_host)                         # same sample through the HIP path
             cb["matches_gpu"] = bool(np.array_equal(got, ref))
+            cb["prove"] = cpu_prove_baseline(ctx, min(16, args.log_n))
             line["cpu_baseline"] = cb
         if world == 1:
             from plonkit_amd import prover_bench

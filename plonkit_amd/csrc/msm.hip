@@ -35,7 +35,7 @@ namespace plk {
 constexpr int MSM_THREADS = 256;
 constexpr uint32_t FINE_BITS = 7;                 // 128 buckets per accumulate workgroup
 constexpr uint32_t FINE = 1u << FINE_BITS;
-constexpr uint32_t CHUNK = 8192;                  // entries per accumulate workgroup (sorted in LDS)
+constexpr uint32_t CHUNK = 16384;                 // entries per accumulate workgroup (sorted in 64 KB of LDS; two workgroups per CU)
 constexpr uint32_t DIGIT_CHUNK = 16384;            // scalars per partition workgroup (per window): 64 KB of LDS staging
 constexpr uint32_t TASK_MAX = CHUNK;
                    // per-chunk bucket population handled cooperatively
@@ -325,7 +325,7 @@ constexpr uint32_t META_PER_TASK = FINE + 2;              // start[0..128] and t
 __global__ void __launch_bounds__(MSM_THREADS, 2) msm_accumulate(const G1Affine *bases, const uint32_t *entries,
                                                                   const uint32_t *bin_start, const uint32_t *task_start,
                                                                   XyzzW *partials, uint32_t *task_meta, MsmParams p) {
-    __shared__ uint32_t sorted[CHUNK];
+    extern __shared__ uint32_t sorted[];                      // [CHUNK]
     __shared__ uint32_t cnt[FINE], start[FINE + 1], cursor[FINE];
     const uint32_t tid = threadIdx.x, task = blockIdx.x;
     const uint32_t total_bins = p.batch * p.groups * p.nbins;
@@ -640,13 +640,14 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     static bool attr_set = false;
     if (!attr_set) {
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_partition<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
         attr_set = true;
     }
     hipLaunchKernelGGL(msm_partition<false>, dim3(pblocks, total_windows), dim3(MSM_THREADS), plds_count, stream, (const int16_t *)digits, p, hist, (const uint32_t *)nullptr, (uint32_t *)nullptr);
     hipLaunchKernelGGL(msm_scan_bins, dim3(1), dim3(1024), 0, stream, hist, bin_start, task_start, total_bins);
     hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks, total_windows), dim3(MSM_THREADS), plds_scatter, stream, (const int16_t *)digits, p, hist, (const uint32_t *)bin_start, entries);
     if (ctx->ev_on) PLK_HIP(hipEventRecord(ctx->ev[0], stream));
-    hipLaunchKernelGGL(msm_accumulate, dim3(max_tasks), dim3(MSM_THREADS), 0, stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
+    hipLaunchKernelGGL(msm_accumulate, dim3(max_tasks), dim3(MSM_THREADS), CHUNK * sizeof(uint32_t), stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
                        (const uint32_t *)task_start, partials, task_meta, p);
     if (ctx->ev_on) PLK_HIP(hipEventRecord(ctx->ev[1], stream));
     hipLaunchKernelGGL(msm_fold_hot, dim3((max_tasks * RL + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
