@@ -270,10 +270,10 @@ __global__ void __launch_bounds__(256) srs_normalise_kernel(const G1Xyzz *in, Fq
     }
 }
 
+// All 16 copies or none: a commitment that can only address `copies` < 16 of them ((copy, index) must fit the
+// 24-bit field of an entry) uses every (16/copies)-th copy, so the full table serves every size.
 static uint32_t table_copies_for(uint64_t srs_n) {           // the table may take up to 32 GiB of the 288 GB
-    uint32_t f = MAX_COPIES;
-    while (f > 1 && (uint64_t)f * srs_n * sizeof(G1Affine) > (32ull << 30)) f >>= 1;
-    return f;
+    return (uint64_t)MAX_COPIES * srs_n * sizeof(G1Affine) <= (32ull << 30) ? MAX_COPIES : 1;
 }
 
 static int32_t ensure_base_table(plk_ctx *ctx, uint32_t copies, hipStream_t stream) {
@@ -583,9 +583,9 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     uint32_t copies = 1;
     if (c_bits == COPY_SHIFT) {
         copies = table_copies_for(ctx->srs_n);
+        PLK_TRY(ensure_base_table(ctx, copies, stream));
         while (copies > 1 && ((uint64_t)copies << nbits) > (1ull << 24)) copies >>= 1;     // 24-bit (copy, index) field of an entry
-    }
-    PLK_TRY(ensure_base_table(ctx, copies, stream));
+    } else PLK_TRY(ensure_base_table(ctx, 1, stream));
     const G1Affine *bases = ctx->srs_w.as<G1Affine>() + base_offset;
     ctx->msm_pending_parts = 0;
     ctx->msm_windows = 0;

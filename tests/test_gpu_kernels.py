@@ -184,3 +184,19 @@ def test_msm_2pow20_trapdoor(ctx):
     s = _rand_fr(n, 99)
     ks = ol.fr_ints(s)
     assert np.array_equal(ctx.msm(s), _trapdoor(ks))
+
+
+@pytest.mark.parametrize("log_n", [21, 22])
+def test_msm_above_2pow20_on_a_fresh_context(log_n):
+    """above 2^20 terms an entry can address only 8 / 4 of the 16 shifted SRS copies (24-bit field), so the
+    commitment uses every 2nd / 4th copy and 2 / 4 bucket sets; first MSM of a fresh context (the table is
+    built for this size), SRS generated on the GPU, checked against the tau = 42 trapdoor answer."""
+    import plonkit_amd as pa
+    c = pa.Context(0)
+    n = 1 << log_n
+    c.srs_generate(n, 0, 42)
+    s = _rand_fr(n, 1000 + log_n)
+    s[::3] = 0                                                   # witness-like: a third of the scalars vanish
+    assert np.array_equal(c.msm(s), _trapdoor(ol.fr_ints(s)))
+    assert np.array_equal(c.msm(s[: n // 2 + 7], base_offset=5), ol.g1_mul(_trapdoor(ol.fr_ints(s[: n // 2 + 7])), pow(42, 5, R_MOD)))
+    c.close()
