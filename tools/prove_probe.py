@@ -12,3 +12,7 @@ setup.prove(circ)
 for _ in range(reps):
     t0 = time.perf_counter(); setup.prove(circ); dt = time.perf_counter() - t0
     print("prove 2^%d: %.2f ms  %s" % (log_n, dt * 1e3, {k: round(v, 2) for k, v in setup.timings_ms().items()}), flush=True)
+if os.environ.get("PROBE_VERIFY"):
+    vk = setup.verification_key_bytes(pa.crs42_g2_bytes())
+    t0 = time.perf_counter(); ok = pa.verify(vk, setup.prove(circ)); dt = time.perf_counter() - t0
+    print("host verifier (real pairing) accepts the 2^%d proof: %s  (prove + verify %.1f ms)" % (log_n, ok, dt * 1e3), flush=True)
