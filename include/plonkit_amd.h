@@ -94,6 +94,17 @@ int32_t plk_g1_intt(plk_ctx *ctx, const plk_g1_affine *in_host, uint32_t log_n, 
 /* same, from the first 2^log_n points of the resident SRS into a device buffer (64 B per point) */
 int32_t plk_g1_intt_srs_dev(plk_ctx *ctx, uint32_t log_n, void *out_dev, void *stream);
 
+/* ---- Lagrange-form key: Crs<E, CrsForLagrangeForm> (L_i(tau)*G, i < N), the optional `-l` key of `plonkit prove`
+ *      (src/bin/main.rs:384-391; src/plonk.rs:138-146: with it, prove() commits the witness and grand-product
+ *      polynomials from their evaluations — commit_using_values — instead of their coefficients).  A second resident
+ *      SRS with its own fixed-base table; while one is set, plk_prove uses it for those 5 commitments and requires
+ *      its size to equal the circuit's domain.  The proof bytes are the same either way.
+ *      set_dev: points already on the device, e.g. the output of plk_g1_intt_srs_dev (not copied, must stay alive). */
+int32_t plk_srs_lagrange_upload(plk_ctx *ctx, const plk_g1_affine *bases, uint64_t n);
+int32_t plk_srs_lagrange_set_dev(plk_ctx *ctx, const void *bases_dev, uint64_t n);
+int32_t plk_srs_lagrange_clear(plk_ctx *ctx);
+uint64_t plk_srs_lagrange_size(const plk_ctx *ctx);
+
 /* ---- host-side G1 helpers (pure CPU, usable without a GPU) ---------------------------------- */
 int32_t plk_g1_sum_jacobian(const plk_g1_jacobian *parts, uint64_t n, plk_g1_affine *out);
 int32_t plk_g1_on_curve(const plk_g1_affine *p);                       /* 1 / 0                   */

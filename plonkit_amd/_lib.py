@@ -116,6 +116,21 @@ class Context:
     def srs_size(self):
         return lib().plk_srs_size(self._h)
 
+    # Lagrange-form key (`prove -l`): second resident SRS used by prove() for commit_using_values
+    def srs_lagrange_upload(self, bases):
+        bases = np.ascontiguousarray(bases, dtype=np.uint64)
+        assert bases.ndim == 2 and bases.shape[1] == 8
+        _check(lib().plk_srs_lagrange_upload(self._h, _np(bases), ctypes.c_uint64(bases.shape[0])))
+
+    def srs_lagrange_set_dev(self, ptr, n):
+        _check(lib().plk_srs_lagrange_set_dev(self._h, _devptr(ptr), ctypes.c_uint64(n)))
+
+    def srs_lagrange_clear(self):
+        _check(lib().plk_srs_lagrange_clear(self._h))
+
+    def srs_lagrange_size(self):
+        return lib().plk_srs_lagrange_size(self._h)
+
     def srs_generate(self, n, start=0, tau=42):
         """Crs::crs_42 on the GPU (src/plonk.rs:30-48): resident SRS <- tau^(start+i) * G."""
         _check(lib().plk_srs_generate(self._h, ctypes.c_uint64(n), ctypes.c_uint64(start), ctypes.c_uint32(tau)))

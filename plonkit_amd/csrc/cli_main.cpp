@@ -68,13 +68,15 @@ static plk_circuit *load_circuit(const std::string &cf, const std::string *wf) {
     return c;
 }
 static plk_ctx *open_ctx() { plk_ctx *ctx = nullptr; CK("plk_create", plk_create(0, &ctx)); return ctx; }
-static void load_key(plk_ctx *ctx, const std::string &path, uint8_t g2[256]) {
-    std::vector<uint8_t> raw = slurp(path, "read key_monomial_form file err");
+static void load_key(plk_ctx *ctx, const std::string &path, uint8_t g2[256], bool lagrange = false) {
+    const char *what = lagrange ? "read key_lagrange_form err" : "read key_monomial_form err";
+    std::vector<uint8_t> raw = slurp(path, what);
     uint64_t n = 0;
-    CK("read key_monomial_form err", plk_key_parse(raw.data(), raw.size(), nullptr, 0, &n, g2));
+    CK(what, plk_key_parse(raw.data(), raw.size(), nullptr, 0, &n, g2));
     std::vector<plk_g1_affine> pts(n);
-    CK("read key_monomial_form err", plk_key_parse(raw.data(), raw.size(), pts.data(), n, &n, g2));
-    CK("srs upload", plk_srs_upload(ctx, pts.data(), n));
+    CK(what, plk_key_parse(raw.data(), raw.size(), pts.data(), n, &n, g2));
+    if (lagrange) CK("srs upload", plk_srs_lagrange_upload(ctx, pts.data(), n));
+    else CK("srs upload", plk_srs_upload(ctx, pts.data(), n));
 }
 
 int main(int argc, char **argv) {
@@ -151,8 +153,9 @@ int main(int argc, char **argv) {
         plk_ctx *ctx = open_ctx();
         uint8_t g2[256];
         load_key(ctx, a.get("srs_monomial_form"), g2);
-        // a Lagrange-form key (-l) changes how wire commitments are computed in the reference, never the proof bytes:
-        // the monomial path below yields the identical proof, so the file is accepted and not needed.
+        // a Lagrange-form key (-l) changes how the witness commitments are computed (commit_using_values), never the
+        // proof bytes (src/plonk.rs:138-146); an empty or missing option means "monomial only" as in the reference
+        if (!a.get("srs_lagrange_form", "").empty()) { uint8_t g2l[256]; load_key(ctx, a.get("srs_lagrange_form"), g2l, true); }
         plk_setup *s = nullptr;
         CK("prepare err", plk_setup_prepare(ctx, c, &s));
         fprintf(stderr, "Proving...\n");

@@ -1,6 +1,7 @@
 // Execution context: one GPU, one stream, cached twiddle tables, resident SRS, scratch arenas.
 // Stands where bellman_ce's `Worker` stands in the reference (src/plonk.rs:41,47,183).
 #pragma once
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
@@ -68,6 +69,12 @@ struct plk_ctx {
     plk::DevBuf srs_w;                       // the same points in the 2^261 Montgomery domain of field29.cuh (MSM gathers)
     bool srs_w_valid = false;
     uint32_t srs_w_copies = 0;               // shifted copies 2^(16k) * P held in srs_w (fixed-base table of the MSM)
+    // optional second key: Crs<E, CrsForLagrangeForm> (L_i(tau)*G), used by plk_prove for commit_using_values
+    // (`prove -l`, src/plonk.rs:138-146).  Same fields as above; SrsSlotSwap makes it the active key for one call.
+    struct LagrangeKey {
+        const void *pts = nullptr; uint64_t n = 0;
+        plk::DevBuf own, w; bool w_valid = false; uint32_t w_copies = 0;
+    } lag;
     // MSM scratch
     plk::DevBuf msm_a, msm_b, msm_c, msm_d, msm_e, msm_f;
     plk::DevBuf prove_ws;                    // workspace of the prover rounds (grows only)
@@ -84,3 +91,19 @@ struct plk_ctx {
     bool ev_on = false;
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
+
+namespace plk {
+// makes the Lagrange key the context's active SRS for the lifetime of the guard (host-side pointer swap only;
+// kernels already enqueued keep the addresses they were launched with)
+struct SrsSlotSwap {
+    plk_ctx *c; bool on;
+    SrsSlotSwap(plk_ctx *ctx, bool lagrange) : c(ctx), on(lagrange) { flip(); }
+    ~SrsSlotSwap() { flip(); }
+    void flip() {
+        if (!on) return;
+        std::swap(c->srs, c->lag.pts); std::swap(c->srs_n, c->lag.n);
+        std::swap(c->srs_own, c->lag.own); std::swap(c->srs_w, c->lag.w);
+        std::swap(c->srs_w_valid, c->lag.w_valid); std::swap(c->srs_w_copies, c->lag.w_copies);
+    }
+};
+}  // namespace plk

@@ -43,8 +43,10 @@ static int32_t commit(plk_ctx *ctx, const Fr *coef, uint64_t n, HAffine *out) {
     return PLK_OK;
 }
 
-// several commitments over the same SRS prefix in one pass of the MSM kernels
-static int32_t commit_many(plk_ctx *ctx, const Fr *const *coefs, uint32_t count, uint64_t n, HAffine *out) {
+// several commitments over the same SRS prefix in one pass of the MSM kernels.  lagrange = commit_using_values:
+// the vectors are evaluations over the domain and the bases the resident Lagrange-form key (same group element).
+static int32_t commit_many(plk_ctx *ctx, const Fr *const *coefs, uint32_t count, uint64_t n, HAffine *out, bool lagrange = false) {
+    SrsSlotSwap active(ctx, lagrange);
     for (uint32_t done = 0; done < count;) {
         uint32_t b = count - done > 8 ? 8 : count - done;
         PLK_TRY(msm_enqueue_batch(ctx, coefs + done, b, n, 0, ctx->stream));
@@ -322,8 +324,12 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
         PLK_HIP(hipMemcpyAsync(w_coef[j], w_vals[j], N * sizeof(Fr), hipMemcpyDeviceToDevice, st));
         PLK_TRY(ntt_dev(ctx, w_coef[j], log_n, true, nullptr, st));
     }
+    // with a Lagrange-form key of the domain's size resident (`prove -l`, src/plonk.rs:138-146) the witness and
+    // grand-product polynomials are committed from their evaluations, as bellman's prove() does; same proof bytes
+    const bool use_lagrange = ctx->lag.pts != nullptr;
+    if (use_lagrange && ctx->lag.n != N) { set_error("Lagrange-form key has a different size than the circuit's domain"); return PLK_ERR_SRS; }
     HAffine wire_c[4];
-    PLK_TRY(commit_many(ctx, w_coef, 4, N, wire_c));
+    PLK_TRY(commit_many(ctx, use_lagrange ? w_vals : w_coef, 4, N, wire_c, use_lagrange));
     RollingKeccak tr;
     for (const HFr &x : inputs) tr.absorb_fr(x);
     for (int j = 0; j < 4; j++) tr.absorb_g1(wire_c[j]);
@@ -347,10 +353,11 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
         PLK_HIP(hipStreamSynchronize(st));
         if (total.is_zero()) { set_error("grand product denominator vanished (probability ~2^-230)"); return PLK_ERR_UNSAT; }
         PLK_TRY(mul3(z_coef, t1, t2, to_dev(total.inv()), (uint32_t)N, st));
+        if (use_lagrange) PLK_HIP(hipMemcpyAsync(t1, z_coef, N * sizeof(Fr), hipMemcpyDeviceToDevice, st));   // keep the values
         PLK_TRY(ntt_dev(ctx, z_coef, log_n, true, nullptr, st));
     }
     HAffine z_c;
-    PLK_TRY(commit(ctx, z_coef, N, &z_c));
+    { const Fr *zp = use_lagrange ? t1 : z_coef; PLK_TRY(commit_many(ctx, &zp, 1, N, &z_c, use_lagrange)); }
     tr.absorb_g1(z_c);
     const HFr alpha = tr.challenge();
     lap();                                                                    // [2] round 2

@@ -103,7 +103,7 @@ void plk_destroy(plk_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
     for (void *p : ctx->coset_allocs) (void)hipFree(p);
-    ctx->tables.release(); ctx->ntt_scratch.release(); ctx->srs_own.release(); ctx->srs_w.release();
+    ctx->tables.release(); ctx->ntt_scratch.release(); ctx->srs_own.release(); ctx->srs_w.release(); ctx->lag.own.release(); ctx->lag.w.release();
     ctx->msm_a.release(); ctx->msm_b.release(); ctx->msm_c.release(); ctx->msm_d.release(); ctx->msm_e.release(); ctx->msm_f.release();
     ctx->stage.release(); ctx->poly_tmp.release(); ctx->poly_tmp2.release(); ctx->prove_ws.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -141,6 +141,28 @@ int32_t plk_srs_set_dev(plk_ctx *ctx, const void *bases_dev, uint64_t n) {
 }
 
 uint64_t plk_srs_size(const plk_ctx *ctx) { return ctx ? ctx->srs_n : 0; }
+
+// Lagrange-form key (Crs<E, CrsForLagrangeForm>): second resident SRS, see include/plonkit_amd.h
+int32_t plk_srs_lagrange_upload(plk_ctx *ctx, const plk_g1_affine *bases, uint64_t n) {
+    if (!ctx || !bases || n == 0) { set_error("plk_srs_lagrange_upload: bad argument"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(ctx->lag.own.reserve(n * sizeof(plk_g1_affine)));
+    PLK_HIP(hipMemcpyAsync(ctx->lag.own.p, bases, n * sizeof(plk_g1_affine), hipMemcpyHostToDevice, ctx->stream));
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->lag.pts = ctx->lag.own.p; ctx->lag.n = n; ctx->lag.w_valid = false;
+    return PLK_OK;
+}
+int32_t plk_srs_lagrange_set_dev(plk_ctx *ctx, const void *bases_dev, uint64_t n) {
+    if (!ctx || !bases_dev || n == 0) { set_error("plk_srs_lagrange_set_dev: bad argument"); return PLK_ERR_ARG; }
+    ctx->lag.pts = bases_dev; ctx->lag.n = n; ctx->lag.w_valid = false;
+    return PLK_OK;
+}
+int32_t plk_srs_lagrange_clear(plk_ctx *ctx) {
+    if (!ctx) { set_error("plk_srs_lagrange_clear: bad argument"); return PLK_ERR_ARG; }
+    ctx->lag.pts = nullptr; ctx->lag.n = 0; ctx->lag.w_valid = false;
+    return PLK_OK;
+}
+uint64_t plk_srs_lagrange_size(const plk_ctx *ctx) { return ctx ? ctx->lag.n : 0; }
 
 // ------------------------------------------------------------------------------------ NTT
 int32_t plk_ntt_dev(plk_ctx *ctx, void *data_dev, uint32_t log_n, int32_t inverse, const plk_fr *coset, void *stream) {

@@ -172,3 +172,35 @@ def test_cli_end_to_end_golden(ctx, golden_dir, golden_crs, tmp_path):
     subprocess.check_call([cli, "dump-lagrange", "-m", key, "-l", lag, "-c", circ], stderr=subprocess.DEVNULL)
     L = po.read_crs(open(lag, "rb").read())
     assert L.g1.shape[0] == 8 and np.array_equal(L.g1, ol.g1_intt(golden_crs.g1[:8], 3))
+    # prove -l: witness commitments from evaluations against the Lagrange-form key; identical proof bytes
+    proof_l = str(tmp_path / "proof_l.bin")
+    subprocess.check_call([cli, "prove", "-m", key, "-l", lag, "-c", circ, "-w", wit, "-p", proof_l], stderr=subprocess.DEVNULL)
+    assert open(proof_l, "rb").read() == open(os.path.join(golden_dir, "proof.bin"), "rb").read()
+    assert subprocess.call([cli, "prove", "-m", key, "-l", key, "-c", circ, "-w", wit, "-p", str(tmp_path / "x.bin")],
+                           stderr=subprocess.DEVNULL) == 101          # a 1024-point key is not the 8-point Lagrange key
+
+
+@pytest.mark.parametrize("log_n", [12, 16])
+def test_prove_with_lagrange_key_gives_the_same_proof(ctx, log_n):
+    """commit_using_values (src/plonk.rs:138-146): with the Lagrange-form key L_i(42)*G resident (made on the GPU
+    by the G1 iNTT of dump-lagrange), prove() commits a, b, c, d and z from their evaluations; the proof is the
+    one of the monomial-only path, and a key of the wrong size is refused."""
+    import torch
+    import plonkit_amd as pa
+    n = 1 << log_n
+    circ = pa.Circuit.synthetic(n - 2)
+    ctx.srs_generate(n, 0, 42)
+    setup = pa.SetupForProver(ctx, circ)
+    ctx.srs_lagrange_clear()
+    want = setup.prove(circ)
+    lag = torch.zeros((n, 8), dtype=torch.int64, device="cuda:0")
+    ctx.g1_intt_srs_dev(log_n, lag.data_ptr())
+    ctx.synchronize()
+    ctx.srs_lagrange_set_dev(lag.data_ptr(), n)
+    assert ctx.srs_lagrange_size() == n
+    assert setup.prove(circ) == want
+    ctx.srs_lagrange_upload(lag.cpu().numpy().view(np.uint64)[: n // 2])
+    with pytest.raises(pa.PlkError):
+        setup.prove(circ)
+    ctx.srs_lagrange_clear()
+    assert setup.prove(circ) == want
