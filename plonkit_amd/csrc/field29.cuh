@@ -252,6 +252,24 @@ PLK_HD W9<WP> csub_p(const W9<WP> &a) {
 template <class WP>
 PLK_HD W9<WP> reduce_full(const W9<WP> &a) { return csub_p(mulw(a, w_one<WP>())); }
 
+// canonical residue of a normalised a < 64p without a product: q = floor(top limb / (top limb of p + 1)) is
+// floor(a/p) or one less (the error term is below 1e-5), so a - q*p < 2p and one conditional subtraction ends it.
+// ~100 cheap instructions against ~300 for the product by one.
+template <class WP>
+PLK_HD W9<WP> reduce_small(const W9<WP> &a) {
+    const uint32_t q = a.l[8] / (WP::P29[8] + 1u);               // constant divisor: a multiply-high and a shift
+    W9<WP> r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int64_t s = (int64_t)a.l[i] - (int64_t)q * (int64_t)WP::P29[i] + c;
+        r.l[i] = (uint32_t)s & M29;
+        c = s >> 29;
+    }
+    r.l[8] = (uint32_t)((int64_t)a.l[8] - (int64_t)q * (int64_t)WP::P29[8] + c);
+    return csub_p(r);
+}
+
 // a == 0 (mod p) for normalised a < 16p.  a = k*p forces l[0] * p^-1 = k (mod 2^29) with k < 16, which a
 // random value passes with probability 2^-25; only then is the value reduced and compared.
 template <class WP>

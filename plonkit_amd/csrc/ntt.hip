@@ -40,7 +40,8 @@ struct NttPassArgs {
     PowTable post;                             // optional: multiply output k by post^k (last pass)
     Fr scale;                                  // optional 1/n on the last pass
     uint32_t has_scale;
-};
+    uint32_t nonzero;                          // first pass: input elements at index >= nonzero are zero and are
+};                                             // neither read nor scaled (zero-padded LDE); 0 = the whole vector
 
 // ---- all butterfly arithmetic runs on the carry-free 9 x 29-bit layer (field29.cuh): data words are
 // ---- re-sliced, never converted; the constants (twiddles, coset powers, 1/n) live in its 2^261 domain.
@@ -155,8 +156,11 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
     for (uint32_t idx = tid; idx < T; idx += NTT_THREADS) {
         uint32_t c = idx & (C - 1), p = idx >> log_c;
         size_t g = base + ((size_t)brev(p, log_r) << a.log_inner) + c;     // rows fetched in bit-reversed order
-        FrW9 v = ldw(a.in + g);
-        if (a.pre.lo) v = mulw(v, pow2l_w(a.pre, (uint32_t)g));
+        FrW9 v = w_zero<FrW>();
+        if (!a.nonzero || g < a.nonzero) {
+            v = ldw(a.in + g);
+            if (a.pre.lo) v = mulw(v, pow2l_w(a.pre, (uint32_t)g));
+        }
         L.put(idx, v);
     }
     __syncthreads();
@@ -184,21 +188,24 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
         uint32_t n = idx & (R - 1), c = idx >> log_r;
         size_t rho = ((size_t)(k1_0 + c) << log_m) + mu;
         size_t g = (rho << log_r) + n;
-        FrW9 v = ldw(a.in + g);
-        if (a.pre.lo) v = mulw(v, pow2l_w(a.pre, (uint32_t)g));
+        FrW9 v = w_zero<FrW>();
+        if (!a.nonzero || g < a.nonzero) {
+            v = ldw(a.in + g);
+            if (a.pre.lo) v = mulw(v, pow2l_w(a.pre, (uint32_t)g));
+        }
         L.put(brev(n, log_r) * C + c, v);                                    // bit reversal as an LDS scatter
     }
     __syncthreads();
     dit_stages(L, a.tw, log_r, log_c, C, tid);
     const uint32_t k2 = mu >> a.log_m2, k3 = mu & ((1u << a.log_m2) - 1);
     const size_t drev = (size_t)k2 + ((size_t)k3 << a.log_m1);
-    const FrW9 last = a.has_scale ? unpack<FrW>(a.scale) : w_one<FrW>();     // 1/n, or the layer's "one": the final
-    for (uint32_t idx = tid; idx < T; idx += NTT_THREADS) {                  // product brings the value below 2p
+    const FrW9 last = unpack<FrW>(a.scale);                                  // 1/n on inverse transforms
+    for (uint32_t idx = tid; idx < T; idx += NTT_THREADS) {
         uint32_t c = idx & (C - 1), k = idx >> log_c;
         size_t o = (size_t)(k1_0 + c) + (drev << a.log_r1) + ((size_t)k << (a.log_n - log_r));
         FrW9 v = L.get(k * C + c);
         if (a.post.lo) v = mulw(v, pow2l_w(a.post, (uint32_t)o));
-        v = csub_p(mulw(v, last));
+        v = a.has_scale ? csub_p(mulw(v, last)) : reduce_small(v);          // canonical output (values here are < 24p)
         store_fp(a.out + o, pack<FrParams>(v));
     }
 }
@@ -294,8 +301,15 @@ int32_t ntt_coset_table(plk_ctx *ctx, const Fr &g, PowTable *out) {
 // ------------------------------------------------------------------------------- driver
 static bool g_attr_set = false;
 
+// src: where the first pass reads (data itself for an in-place transform); nonzero: see NttPassArgs
+static int32_t ntt_run(plk_ctx *ctx, const Fr *src, uint64_t nonzero, Fr *data, uint32_t log_n, bool inverse, const Fr *coset, hipStream_t stream);
+
 int32_t ntt_dev(plk_ctx *ctx, Fr *data, uint32_t log_n, bool inverse, const Fr *coset, hipStream_t stream) {
-    if (!data) { set_error("ntt: null data"); return PLK_ERR_ARG; }
+    return ntt_run(ctx, data, 0, data, log_n, inverse, coset, stream);
+}
+
+static int32_t ntt_run(plk_ctx *ctx, const Fr *src, uint64_t nonzero, Fr *data, uint32_t log_n, bool inverse, const Fr *coset, hipStream_t stream) {
+    if (!data || !src) { set_error("ntt: null data"); return PLK_ERR_ARG; }
     if (log_n > MAX_LOG_N) { set_error("ntt: log_n exceeds the 2-adicity of Fr (28)"); return PLK_ERR_SIZE; }
     if (log_n == 0) return PLK_OK;
     PLK_TRY(ntt_init_tables(ctx));
@@ -328,7 +342,8 @@ int32_t ntt_dev(plk_ctx *ctx, Fr *data, uint32_t log_n, bool inverse, const Fr *
     uint32_t rem = log_n;
     for (uint32_t i = 0; i + 1 < p; i++) {
         rem -= d[i];
-        a.in = (i == 0) ? data : scratch; a.out = scratch;
+        a.in = (i == 0) ? src : scratch; a.out = scratch;
+        a.nonzero = (i == 0) ? (uint32_t)nonzero : 0;
         a.log_r = d[i]; a.log_inner = rem;
         a.log_c = (LOG_TILE - d[i]) < rem ? (LOG_TILE - d[i]) : rem;
         a.pre = (i == 0) ? pre : PowTable{};
@@ -338,7 +353,8 @@ int32_t ntt_dev(plk_ctx *ctx, Fr *data, uint32_t log_n, bool inverse, const Fr *
         hipLaunchKernelGGL(ntt_pass_cols, dim3(tiles), dim3(NTT_THREADS), lds, stream, a);
     }
     {
-        a.in = (p == 1) ? data : scratch; a.out = (p == 1) ? scratch : data;
+        a.in = (p == 1) ? src : scratch; a.out = (p == 1) ? scratch : data;
+        a.nonzero = (p == 1) ? (uint32_t)nonzero : 0;
         a.log_r = d[p - 1];
         if (p == 1) { a.log_r1 = 0; a.log_m1 = a.log_m2 = 0; a.log_c = 0; }
         else {
@@ -363,10 +379,11 @@ int32_t ntt_dev(plk_ctx *ctx, Fr *data, uint32_t log_n, bool inverse, const Fr *
 int32_t lde4_dev(plk_ctx *ctx, const Fr *coeffs, uint32_t log_n, Fr *out_4n, hipStream_t stream) {
     if (log_n + 2 > MAX_LOG_N) { set_error("lde4: 4n exceeds 2^28"); return PLK_ERR_SIZE; }
     const size_t n = (size_t)1 << log_n;
-    PLK_HIP(hipMemcpyAsync(out_4n, coeffs, n * sizeof(Fr), hipMemcpyDeviceToDevice, stream));
-    PLK_HIP(hipMemsetAsync(out_4n + n, 0, 3 * n * sizeof(Fr), stream));
+    // the zero-padded 4n-point coset transform without materialising the padding: the first pass reads the n
+    // coefficients where they are and treats every index >= n as zero (no copy, no memset, no scaling of zeros)
+    if (coeffs == out_4n) { set_error("lde4: input and output must not alias"); return PLK_ERR_ARG; }
     Fr g = from_u64<FrParams>(7);
-    return ntt_dev(ctx, out_4n, log_n + 2, false, &g, stream);
+    return ntt_run(ctx, coeffs, n, out_4n, log_n + 2, false, &g, stream);
 }
 
 }  // namespace plk
