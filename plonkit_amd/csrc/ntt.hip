@@ -169,7 +169,9 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
     for (uint32_t idx = tid; idx < T; idx += NTT_THREADS) {
         uint32_t c = idx & (C - 1), k = idx >> log_c;
         uint32_t e = (k * (c0 + c)) << eshift;
-        FrW9 v = mulw(L.get(idx), pow2l_w(a.tw, e));                          // < 1.1p: fits 256 bits, stays lazy
+        // sub-transforms of <= 2^14 points only touch the hi table (the low 14 exponent bits are zero): no composition
+        const FrW9 t = eshift >= POW_SPLIT ? ldw(a.tw.hi + (e >> POW_SPLIT)) : pow2l_w(a.tw, e);
+        FrW9 v = mulw(L.get(idx), t);                                         // < 1.1p: fits 256 bits, stays lazy
         store_fp(a.out + base + ((size_t)k << a.log_inner) + c, pack<FrParams>(v));
     }
 }
@@ -329,6 +331,9 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *src, uint64_t nonzero, Fr *data, 
     else {
         p = (log_n + 9) / 10;                              // up to 10 bits per pass: 2^20 = 10 + 10 (two passes)
         for (uint32_t i = 0; i < p; i++) d[i] = log_n / p + (i < log_n % p ? 1 : 0);
+        if (p == 3 && log_n <= 23) {                       // leave 14 bits to passes 2 and 3: their inter-pass twiddles
+            d[0] = log_n - 14; d[1] = 7; d[2] = 7;         // then come straight out of the hi table (ntt_pass_cols)
+        }
     }
     const size_t n = (size_t)1 << log_n;
     Fr *scratch = nullptr;
