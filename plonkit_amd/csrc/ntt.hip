@@ -26,7 +26,7 @@
 
 namespace plk {
 
-constexpr int NTT_THREADS = 256;
+constexpr int NTT_THREADS = 512;               // 8 waves per workgroup, 2 workgroups per CU (LDS): 4 waves per SIMD
 constexpr int LOG_TILE = 11;                   // 2048 elements per workgroup
 
 struct NttPassArgs {
@@ -81,10 +81,10 @@ __device__ __forceinline__ FrW9 small_tw(const PowTable &t, uint32_t i, uint32_t
 //
 // Two stages at a time (radix 4 in registers): a group is the four rows i0 + {0, h, 2h, 3h}; stage s pairs
 // (0,1) and (2,3) with omega_{2h}^jl, stage s+1 pairs (0,2) with omega_{4h}^jl and (1,3) with omega_{4h}^(jl+h).
-// That halves the LDS round trips and barriers.  A full 2048-element tile gives every thread exactly two
-// groups; both are loaded (8 elements + 6 twiddles) before the first product so that the LDS and L2 latencies
-// are paid once per eight products — with 74 KB of LDS per workgroup only two waves share a SIMD, and the
-// one-butterfly-at-a-time version left the multiplier idle about 40 % of the time.
+// That halves the LDS round trips and barriers.  With 74 KB of LDS per tile two workgroups share a CU, so the
+// workgroup is 512 threads (one group per thread and step, 118 VGPRs): four waves per SIMD hide the LDS and L2
+// latencies.  Measured at 2^20: radix 2 / 256 threads 0.197 ms; radix 4 / 256 threads with two groups per thread
+// loaded up front (196 VGPRs) 0.150 ms; radix 4 / 512 threads 0.142 ms.
 struct Radix4Group {
     FrW9 x0, x1, x2, x3, t1, t2, t3;
     uint32_t a0, a1, a2, a3;
@@ -125,18 +125,10 @@ __device__ __forceinline__ void dit_stages(const LdsTile &L, const PowTable &tw,
         s = 1;
     }
     for (; s < log_r; s += 2) {
-        if (quarter_tile == 2 * NTT_THREADS) {
-            Radix4Group q0, q1;
-            r4_load(q0, L, tw, tid, s, log_r, log_c, pitch);
-            r4_load(q1, L, tw, tid + NTT_THREADS, s, log_r, log_c, pitch);
-            r4_finish(q0, L, s);
-            r4_finish(q1, L, s);
-        } else {
-            for (uint32_t g = tid; g < quarter_tile; g += NTT_THREADS) {
-                Radix4Group q;
-                r4_load(q, L, tw, g, s, log_r, log_c, pitch);
-                r4_finish(q, L, s);
-            }
+        for (uint32_t g = tid; g < quarter_tile; g += NTT_THREADS) {         // one iteration for a full 2048-element tile
+            Radix4Group q;
+            r4_load(q, L, tw, g, s, log_r, log_c, pitch);
+            r4_finish(q, L, s);
         }
         __syncthreads();
     }
