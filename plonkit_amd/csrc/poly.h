@@ -17,13 +17,19 @@ struct CheckArgs {
     uint32_t *flag;
 };
 
+// The quotient kernel computes on the 9 x 29-bit layer (field29.cuh), whose product is a*b*2^-261 while vectors in
+// HBM carry the factor 2^256.  Instead of converting anything per proof, the constant vectors cached in plk_setup
+// are stored pre-scaled (2^261: q_a..q_d, q_dnext, sigma_j, L0, the coset points x; 2^266: q_m, which meets a
+// product of two wires) and the host scales the challenges, so that every term lands on 2^256 by itself:
+//   alpha_pp = alpha * 2^281 (meets z * four 2^256 factors), alpha2_w = alpha^2 * 2^261, zh_inv_w = 2^261 / Z_H.
 struct QuotientArgs {
     Fr *out;
-    const Fr *w[4], *z, *q[7], *sigma[4], *pi, *l0;
-    Fr beta, gamma, alpha, alpha2, coset, beta_k[4], zh_inv[4];
+    const Fr *w[4], *z, *q[7], *sigma[4], *pi, *l0, *x;
+    Fr beta, gamma, alpha_pp, alpha2_w, beta_k[4], zh_inv_w[4];
     uint32_t m, log_m;                  // m = 4N
-    PowTable tw;
 };
+int32_t scale_const(Fr *out, const Fr *in, const Fr &c_s, uint32_t n, hipStream_t s);            // out_i = in_i * c (one W-layer product), canonical
+int32_t coset_points_w(Fr *out, const PowTable &tw_w, uint32_t log_m, const Fr &c_s, uint32_t m, hipStream_t s);   // out_i = c * omega_m^i
 
 constexpr uint32_t LINCOMB_MAX = 14;
 struct LinCombArgs {

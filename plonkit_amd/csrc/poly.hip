@@ -6,6 +6,7 @@
 // point) with a handful of modular multiplies per point.
 #include "ctx.h"
 #include "poly.h"
+#include "field29.cuh"
 
 namespace plk {
 
@@ -149,32 +150,47 @@ int32_t scan(plk_ctx *ctx, Fr *out, const Fr *in, uint32_t n, bool mult, bool re
 }
 
 // ----------------------------------------------------------------------------- quotient
-// t(x_i) = [gate + PI + alpha*(perm) + alpha^2*L0*(z-1)] / Z_H(x_i) on the coset 7*<omega_4N>
+__device__ __forceinline__ FrW9 ldw(const Fr *p) { return unpack<FrW>(load_fp(p)); }
+__device__ __forceinline__ FrW9 cw(const Fr &c) { return unpack<FrW>(c); }
+
+// out_i = in_i * c as ONE product of the 29-bit layer (c given with the scale the caller wants, see QuotientArgs)
+__global__ void __launch_bounds__(PT) k_scale_const(Fr *out, const Fr *in, Fr c, uint32_t n) {
+    uint32_t i = blockIdx.x * PT + threadIdx.x;
+    if (i < n) store_fp(out + i, pack<FrParams>(csub_p(mulw(ldw(in + i), cw(c)))));
+}
+// out_i = c * omega_m^i  (tw_w: the power table of omega_{2^28} in the 2^261 domain)
+__global__ void __launch_bounds__(PT) k_coset_points_w(Fr *out, PowTable tw_w, uint32_t shift, Fr c, uint32_t m) {
+    uint32_t i = blockIdx.x * PT + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t e = i << shift;
+    const FrW9 w = mulw(ldw(tw_w.lo + (e & (POW_TAB - 1))), ldw(tw_w.hi + (e >> POW_SPLIT)));
+    store_fp(out + i, pack<FrParams>(csub_p(mulw(w, cw(c)))));
+}
+
+// t(x_i) = [gate + PI + alpha*(perm) + alpha^2*L0*(z-1)] / Z_H(x_i) on the coset 7*<omega_4N>.
+// 27 products per point on the 29-bit layer, the seven gate products in two fused sums (one reduction per three).
 __global__ void __launch_bounds__(PT) k_quotient(QuotientArgs a) {
     uint32_t i = blockIdx.x * PT + threadIdx.x;
     if (i >= a.m) return;
     const uint32_t nxt = (i + 4) & (a.m - 1);                    // f(omega*x) on the 4N domain
-    Fr w[4];
+    FrW9 w[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) w[j] = load_fp(a.w[j] + i);
-    Fr g = load_fp(a.q[5] + i);
-#pragma unroll
-    for (int j = 0; j < 4; j++) g = add(g, mul(load_fp(a.q[j] + i), w[j]));
-    g = add(g, mul(load_fp(a.q[4] + i), mul(w[0], w[1])));
-    g = add(g, mul(load_fp(a.q[6] + i), load_fp(a.w[3] + nxt)));
-    g = add(g, load_fp(a.pi + i));
-    Fr x = mul(pow2l_(a.tw, i << (MAX_LOG_N - a.log_m)), a.coset);
-    Fr z = load_fp(a.z + i);
-    Fr pa = z, pb = load_fp(a.z + nxt);
+    for (int j = 0; j < 4; j++) w[j] = ldw(a.w[j] + i);
+    const FrW9 w01 = mulw(w[0], w[1]);                           // scale 2^251; q_m is stored with 2^266
+    const FrW9 f1 = mulsum3w(ldw(a.q[0] + i), w[0], ldw(a.q[1] + i), w[1], ldw(a.q[2] + i), w[2]);
+    const FrW9 f2 = mulsum3w(ldw(a.q[3] + i), w[3], ldw(a.q[4] + i), w01, ldw(a.q[6] + i), ldw(a.w[3] + nxt));
+    FrW9 g = addn(addn(f1, f2), addn(ldw(a.q[5] + i), ldw(a.pi + i)));
+    const FrW9 x = ldw(a.x + i), z = ldw(a.z + i), gamma = cw(a.gamma), beta = cw(a.beta);
+    FrW9 pa = z, pb = ldw(a.z + nxt);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        Fr wg = add(w[j], a.gamma);
-        pa = mul(pa, add(wg, mul(x, a.beta_k[j])));
-        pb = mul(pb, add(wg, mul(load_fp(a.sigma[j] + i), a.beta)));
+        const FrW9 wg = addn(w[j], gamma);
+        pa = mulw(pa, addn(wg, mulw(x, cw(a.beta_k[j]))));
+        pb = mulw(pb, addn(wg, mulw(ldw(a.sigma[j] + i), beta)));
     }
-    Fr t = add(g, mul(a.alpha, sub(pa, pb)));
-    t = add(t, mul(a.alpha2, mul(load_fp(a.l0 + i), sub(z, Fr::one()))));
-    store_fp(a.out + i, mul(t, a.zh_inv[i & 3]));
+    FrW9 t = addn(g, mulw(cw(a.alpha_pp), sub2(pa, pb)));
+    t = addn(t, mulw(cw(a.alpha2_w), mulw(ldw(a.l0 + i), sub2(z, cw(Fr::one())))));
+    store_fp(a.out + i, pack<FrParams>(csub_p(mulw(t, cw(a.zh_inv_w[i & 3])))));
 }
 
 // ------------------------------------------------------------------- linear combinations
@@ -289,6 +305,16 @@ int32_t perm_terms(const PermArgs &a, hipStream_t s) {
 }
 int32_t mul3(Fr *out, const Fr *a, const Fr *b, const Fr &sc, uint32_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_mul3, grid1(n), dim3(PT), 0, s, out, a, b, sc, n);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+int32_t scale_const(Fr *out, const Fr *in, const Fr &c_s, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_scale_const, grid1(n), dim3(PT), 0, s, out, in, c_s, n);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+int32_t coset_points_w(Fr *out, const PowTable &tw_w, uint32_t log_m, const Fr &c_s, uint32_t m, hipStream_t s) {
+    hipLaunchKernelGGL(k_coset_points_w, grid1(m), dim3(PT), 0, s, out, tw_w, MAX_LOG_N - log_m, c_s, m);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
 }

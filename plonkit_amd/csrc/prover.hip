@@ -80,7 +80,7 @@ struct plk_setup {
     // computed by the first proof and kept (the reference recomputes them in every prove_by_steps call
     // because plonkit passes `None` precomputations, src/plonk.rs:156; the values are identical)
     mutable plk::DevBuf lde_store;
-    mutable plk::Fr *lde[12] = {nullptr};
+    mutable plk::Fr *lde[13] = {nullptr};       // 7 selectors, 4 sigma, L0 (pre-scaled, see QuotientArgs), coset points
     mutable bool lde_ready = false;
     uint64_t num_circuit_vars = 0;         // circom wires; temporaries follow
     std::vector<plk::WitnessOp> ops;       // linear forms defining the transpiler's temporaries
@@ -368,9 +368,9 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
         for (int j = 0; j < 4; j++) PLK_TRY(lde4_dev(ctx, w_coef[j], log_n, ext[j], st));
         PLK_TRY(lde4_dev(ctx, z_coef, log_n, ext[4], st));
         if (!S->lde_ready) {
-            PLK_TRY(S->lde_store.reserve(12 * MB));
+            PLK_TRY(S->lde_store.reserve(13 * MB));
             Arena LA{&S->lde_store};
-            for (int k = 0; k < 12; k++) S->lde[k] = LA.take<Fr>(M);
+            for (int k = 0; k < 13; k++) S->lde[k] = LA.take<Fr>(M);
             for (int k = 0; k < 7; k++) PLK_TRY(lde4_dev(ctx, S->sel_coef[k], log_n, S->lde[k], st));
             for (int j = 0; j < 4; j++) PLK_TRY(lde4_dev(ctx, S->sig_coef[j], log_n, S->lde[7 + j], st));
             HFr one = HFr::one();
@@ -378,6 +378,14 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
             PLK_HIP(hipMemcpyAsync(l0_coef, one.l, sizeof(Fr), hipMemcpyHostToDevice, st));
             PLK_TRY(ntt_dev(ctx, l0_coef, log_n, true, nullptr, st));
             PLK_TRY(lde4_dev(ctx, l0_coef, log_n, S->lde[11], st));
+            // pre-scaled for the 29-bit layer of the quotient kernel (poly.h, QuotientArgs): 2^5 everywhere,
+            // 2^10 on q_m, none on q_const (it is only added); plus the coset points x_i = 7 * omega_4N^i
+            const HFr s5 = HFr::from_u64(1u << 10), s10 = HFr::from_u64(1u << 15);      // as factors of a product that removes 2^5
+            for (int k = 0; k < 12; k++) {
+                if (k == 5) continue;
+                PLK_TRY(scale_const(S->lde[k], S->lde[k], to_dev(k == 4 ? s10 : s5), (uint32_t)M, st));
+            }
+            PLK_TRY(coset_points_w(S->lde[12], ctx->tw_fwd_w, log_m, to_dev(HFr::from_u64(7u << 5)), (uint32_t)M, st));
             PLK_HIP(hipStreamSynchronize(st));
             S->lde_ready = true;
         }
@@ -393,12 +401,13 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
         for (int j = 0; j < 4; j++) { qa.w[j] = ext[j]; qa.sigma[j] = ext[12 + j]; qa.beta_k[j] = to_dev(beta * kk[j]); }
         qa.z = ext[4];
         for (int k = 0; k < 7; k++) qa.q[k] = ext[5 + k];
-        qa.pi = ext[16]; qa.l0 = ext[17];
-        qa.beta = to_dev(beta); qa.gamma = to_dev(gamma); qa.alpha = to_dev(alpha); qa.alpha2 = to_dev(alpha * alpha);
-        qa.coset = to_dev(coset);
+        qa.pi = ext[16]; qa.l0 = ext[17]; qa.x = S->lde[12];
+        const HFr two5 = HFr::from_u64(1u << 5), two25 = HFr::from_u64(1u << 25);
+        qa.beta = to_dev(beta); qa.gamma = to_dev(gamma);
+        qa.alpha_pp = to_dev(alpha * two25); qa.alpha2_w = to_dev(alpha * alpha * two5);
         HFr gN = coset.pow_u64(N), iota = host_omega(log_m).pow_u64(N), ip = HFr::one();
-        for (int k = 0; k < 4; k++) { qa.zh_inv[k] = to_dev((gN * ip - HFr::one()).inv()); ip = ip * iota; }
-        qa.m = (uint32_t)M; qa.log_m = log_m; qa.tw = ctx->tw_fwd;
+        for (int k = 0; k < 4; k++) { qa.zh_inv_w[k] = to_dev((gN * ip - HFr::one()).inv() * two5); ip = ip * iota; }
+        qa.m = (uint32_t)M; qa.log_m = log_m;
         PLK_TRY(quotient(qa, st));
         Fr g = to_dev(coset);
         PLK_TRY(ntt_dev(ctx, t_ext, log_m, true, &g, st));
