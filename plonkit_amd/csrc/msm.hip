@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_accumulate(const G1Affine 
         sorted[start[f] + atomicAdd(&cursor[f], 1u)] = en;
     }
     __syncthreads();
-    if (nc == 0) return;
+    if (nc == 0 || p.debug == 3) return;                      // (debug 3: time the sort alone)
     const uint32_t mu = (nc + MSM_THREADS - 1) / MSM_THREADS;
     const uint32_t lo = tid * mu < nc ? tid * mu : nc, hi = lo + mu < nc ? lo + mu : nc;
     XyzzW *out = partials + (size_t)task * SLOTS_PER_TASK;
