@@ -110,7 +110,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = bool(os.environ.get("PLK_FORCE_GATHER")) and "RANK" in os.environ     # one-rank test of the RCCL path
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -124,22 +125,19 @@ def main():
     scalars = rand_scalars(n, 0x706c6f6e6b6974 + rank, device)
     torch.cuda.synchronize()                             # the scalars are consumed on another stream
     stream = torch.cuda.Stream(device=device)
-    msm = ShardedMsm(ctx, dist if world > 1 else None, device)
+    msm = ShardedMsm(ctx, dist if (world > 1 or force_dist) else None, device)
     ctx.set_kernel_timing(True)
 
-    def step():
-        return msm.commit(scalars, n, stream=stream)
-
-    for _ in range(args.warmup):
-        out = step()
+    # K commitments back to back; the exchange of commitment k overlaps the kernels of k+1 (ShardedMsm.commit_stream)
+    for out in msm.commit_stream((scalars for _ in range(args.warmup)), n, stream=stream):
+        pass
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    for out in msm.commit_stream((scalars for _ in range(args.steps)), n, stream=stream):
         kernel_ms.append(ctx.msm_last_kernel_ms())
     torch.cuda.synchronize()
     if dist:

@@ -6,6 +6,8 @@ reduction op, so a literal all_reduce is impossible — SURVEY.md §8e).  NTTs s
 In the reference there is no counterpart (one process, bellman's Worker threads, src/plonk.rs:41);
 the sharded commitment is mathematically the same sum commit_using_monomials computes.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -16,8 +18,8 @@ def combine_partials(partial, dist=None, device=None):
     """partial: uint64[12] Jacobian of this rank -> affine uint64[8] of the sum over all ranks.
     With dist == None (single process) it is just the Jacobian -> affine conversion."""
     partial = np.ascontiguousarray(partial, dtype=np.uint64).reshape(12)
-    if dist is None or dist.get_world_size() == 1:
-        return _lib.g1_sum_jacobian(partial)
+    if dist is None or (dist.get_world_size() == 1 and not os.environ.get("PLK_FORCE_GATHER")):
+        return _lib.g1_sum_jacobian(partial)          # (PLK_FORCE_GATHER: exercise the collective with one rank)
     world = dist.get_world_size()
     t = torch.from_numpy(partial.view(np.int64).copy())
     if device is not None:
@@ -39,3 +41,19 @@ class ShardedMsm:
         self.ctx.msm_enqueue_dev(scalars_dev, n, base_offset, stream=stream)
         partial = self.ctx.msm_finish()
         return combine_partials(partial, self.dist, self.device)
+
+    def commit_stream(self, batches, n, base_offset=0, stream=None):
+        """Generator over a sequence of scalar vectors: commitment k is exchanged (all_gather + host EC sum)
+        while the GPU already runs the kernels of commitment k+1 — the exchange step of SURVEY.md §8(e)
+        ("what matters is overlapping ... MSM k+1 with MSM k") costs no GPU idle time."""
+        it = iter(batches)
+        cur = next(it, None)
+        if cur is None:
+            return
+        self.ctx.msm_enqueue_dev(cur, n, base_offset, stream=stream)
+        while cur is not None:
+            partial = self.ctx.msm_finish()                    # waits for commitment k, host Horner over the windows
+            cur = next(it, None)
+            if cur is not None:
+                self.ctx.msm_enqueue_dev(cur, n, base_offset, stream=stream)   # k+1 starts before k is exchanged
+            yield combine_partials(partial, self.dist, self.device)

@@ -60,3 +60,58 @@ def test_combine_single_process_is_affine_conversion():
     srs = ol.crs42(64, threads=1)
     s = ol.fr_vec([(i * 7919 + 13) % R_MOD for i in range(64)])
     assert np.array_equal(combine_partials(ol.msm_jacobian(srs, s, threads=1)), ol.msm(srs, s, threads=1))
+
+
+class _OracleShard:
+    """stands in for the rank's plk_ctx (no GPU in this test): msm_enqueue_dev / msm_finish over this rank's
+    SRS shard, computed by the oracle; records the call order so that the pipelining can be checked"""
+    def __init__(self, bases):
+        self.bases, self.pending, self.log = bases, [], []
+
+    def msm_enqueue_dev(self, scalars, n, base_offset=0, stream=None):
+        self.log.append("enqueue")
+        self.pending.append(ol.msm_jacobian(self.bases[base_offset:base_offset + n], scalars[:n], threads=2))
+
+    def msm_finish(self):
+        self.log.append("finish")
+        return self.pending.pop(0)
+
+
+def _stream_worker(rank, world, port, n_per_rank, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from plonkit_amd.sharded import ShardedMsm
+        srs = ol.crs42(world * n_per_rank, threads=2)
+        lo, hi = rank * n_per_rank, (rank + 1) * n_per_rank
+        vecs = []
+        for k in range(3):
+            rng = np.random.default_rng(7 + k)                # same scalars on every rank
+            s = rng.integers(0, 1 << 62, size=(world * n_per_rank, 4), dtype=np.uint64)
+            s[:, 3] &= np.uint64((1 << 60) - 1)
+            vecs.append(s)
+        shard = _OracleShard(srs[lo:hi])
+        msm = ShardedMsm(shard, dist, None)
+        got = list(msm.commit_stream((v[lo:hi] for v in vecs), n_per_rank))
+        ok = all(np.array_equal(g, ol.msm(srs, v, threads=2)) for g, v in zip(got, vecs))
+        # commitment k+1 is enqueued before commitment k is exchanged
+        ok = ok and shard.log == ["enqueue", "finish", "enqueue", "finish", "enqueue", "finish"]
+        q.put((rank, bool(ok), len(got)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_commit_stream_world2():
+    """ShardedMsm.commit_stream (what bench.py --gpus N times): three commitments in a row, every one equal to the
+    single-process MSM over the whole SRS"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, 200, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True, 3), (1, True, 3)]
