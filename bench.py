@@ -19,6 +19,10 @@ import os
 import sys
 import time
 
+# the library keeps two commitments in flight on two streams; with HIP's default of 4 hardware queues per device
+# those streams can land on one queue and serialise (measured: 2.04 ms per commitment instead of 1.66 ms)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -170,7 +174,10 @@ def main():
                          "valu": {"achieved_gmadd_s": round(n * (254 // 16 + 1) / (k_ms * 1e-3) / 1e9, 2),
                                   "peak_gmadd_s": VALU_PEAK_GMADD,
                                   "frac": round(n * (254 // 16 + 1) / (k_ms * 1e-3) / 1e9 / VALU_PEAK_GMADD, 3)},
-                         "note": "the kernel is bound by v_mad_u64_u32 issue, not HBM (SURVEY.md §8d): `valu` compares its "
+                         "note": "commitments are pipelined two deep, so this kernel runs beside the bucket reduction of the previous "
+                                 "commitment and its HIP-event duration (kernel_ms) equals the step time; alone it takes 1.35-1.40 ms "
+                                 "(profiles/r01_bench_final_kernel_stats.csv).  "
+                                 "The kernel is bound by v_mad_u64_u32 issue, not HBM (SURVEY.md §8d): `valu` compares its "
                                  "mixed-addition rate with the same loop measured in isolation (tools/ubench_w); `traffic` "
                                  "is 12x the algorithmic bytes because Pippenger gathers one 64-byte point per (term, window): "
                                  "16 windows, each from its own shifted copy of the SRS (1 GiB fixed-base table in HBM)"},

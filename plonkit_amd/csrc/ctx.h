@@ -75,8 +75,17 @@ struct plk_ctx {
         const void *pts = nullptr; uint64_t n = 0;
         plk::DevBuf own, w; bool w_valid = false; uint32_t w_copies = 0;
     } lag;
-    // MSM scratch
-    plk::DevBuf msm_a, msm_b, msm_c, msm_d, msm_e, msm_f;
+    // MSM: two commitments (or batches) may be in flight, each with its own scratch, result buffer and stream, so that
+    // the latency-bound tail of one (bucket reduction: <= 1 wave per SIMD) overlaps the accumulation of the next
+    struct MsmSlot {
+        plk::DevBuf a, b, c, d, e, f;
+        void *pinned = nullptr; size_t pinned_cap = 0;
+        uint32_t windows = 0, c_bits = 0, pending_parts = 0, batch = 1;
+        hipStream_t stream = nullptr;        // the kernels of this commitment; ordered after the caller's stream by `ready`
+        hipEvent_t ready = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};   // optional bracket around msm_accumulate (bench roofline)
+    } slot[2];
+    uint64_t msm_enq = 0, msm_fin = 0;       // FIFO: enqueue uses slot[msm_enq & 1], finish slot[msm_fin & 1]
     plk::DevBuf prove_ws;                    // workspace of the prover rounds (grows only)
     plk::DevBuf poly_tmp, poly_tmp2;         // scan block totals / evaluation partials
     plk::DevBuf stage;                       // host<->device staging for the host-pointer API
@@ -84,12 +93,8 @@ struct plk_ctx {
     size_t pinned_cap = 0;
     void *pinned2 = nullptr;                 // pinned staging of the prover's temporaries
     size_t pinned2_cap = 0;
-    uint32_t msm_windows = 0, msm_c_bits = 0, msm_pending_parts = 0, msm_batch = 1;
-    hipStream_t msm_stream = nullptr;
     std::vector<double> timings;
-    // optional HIP-event bracket around the dominant kernel of the last MSM (bench roofline)
-    bool ev_on = false;
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool ev_on = false;                      // record the per-slot event bracket around msm_accumulate
 };
 
 namespace plk {

@@ -75,8 +75,8 @@ int32_t g1_intt_dev(plk_ctx *ctx, const G1Affine *in, uint32_t log_n, G1Affine *
     if (log_n > 26) { set_error("g1_intt: size exceeds 2^26"); return PLK_ERR_SIZE; }
     PLK_TRY(ntt_init_tables(ctx));
     const uint32_t n = 1u << log_n;
-    PLK_TRY(ctx->msm_c.reserve((size_t)n * sizeof(G1Xyzz)));
-    G1Xyzz *pts = ctx->msm_c.as<G1Xyzz>();
+    PLK_TRY(ctx->slot[0].c.reserve((size_t)n * sizeof(G1Xyzz)));
+    G1Xyzz *pts = ctx->slot[0].c.as<G1Xyzz>();
     Fr n_inv = to_canonical(ctx->n_inv[log_n]);
     hipLaunchKernelGGL(g1ntt_load, dim3((n + 255) / 256), dim3(256), 0, st, pts, in, log_n, n_inv);
     for (uint32_t s = 0; s < log_n; s++)

@@ -571,7 +571,28 @@ static uint32_t pick_window_bits(uint64_t n) {
 
 int32_t ensure_pinned(plk_ctx *ctx, size_t bytes);
 
-int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t batch, uint64_t n, uint64_t base_offset, hipStream_t stream) {
+static int32_t slot_pinned(plk_ctx::MsmSlot &S, size_t bytes) {
+    if (bytes <= S.pinned_cap) return PLK_OK;
+    if (S.pinned) (void)hipHostFree(S.pinned);
+    S.pinned = nullptr; S.pinned_cap = 0;
+    PLK_HIP(hipHostMalloc(&S.pinned, bytes, hipHostMallocDefault));
+    S.pinned_cap = bytes;
+    return PLK_OK;
+}
+
+// `caller` is the stream on which the scalars were produced; the commitment runs on its slot's own stream after an
+// event recorded there.  The caller must leave the scalars alone until the matching msm_finish_batch.
+int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t batch, uint64_t n, uint64_t base_offset, hipStream_t caller) {
+    if (ctx->msm_enq - ctx->msm_fin >= 2) { set_error("msm: two commitments are already in flight (call the finish function first)"); return PLK_ERR_ARG; }
+    plk_ctx::MsmSlot &S = ctx->slot[ctx->msm_enq & 1];
+    if (!S.stream) {
+        PLK_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+        PLK_HIP(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
+    }
+    if (ctx->ev_on && !S.ev[0]) { PLK_HIP(hipEventCreate(&S.ev[0])); PLK_HIP(hipEventCreate(&S.ev[1])); }
+    PLK_HIP(hipEventRecord(S.ready, caller));
+    PLK_HIP(hipStreamWaitEvent(S.stream, S.ready, 0));
+    hipStream_t stream = S.stream;
     if (!ctx->srs) { set_error("msm: no SRS uploaded (plk_srs_upload)"); return PLK_ERR_SRS; }
     if (base_offset + n > ctx->srs_n) { set_error("msm: SRS too small for this commitment"); return PLK_ERR_SRS; }
     if (n >= (1ull << 24) + 1) { set_error("msm: more than 2^24 terms per call (shard the commitment)"); return PLK_ERR_SIZE; }
@@ -587,20 +608,21 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
         while (copies > 1 && ((uint64_t)copies << nbits) > (1ull << 24)) copies >>= 1;     // 24-bit (copy, index) field of an entry
     } else PLK_TRY(ensure_base_table(ctx, 1, stream));
     const G1Affine *bases = ctx->srs_w.as<G1Affine>() + base_offset;
-    ctx->msm_pending_parts = 0;
-    ctx->msm_windows = 0;
-    ctx->msm_batch = batch;
-    if (n == 0) return PLK_OK;
+    S.pending_parts = 0;
+    S.windows = 0;
+    S.batch = batch;
+    if (n == 0) { ctx->msm_enq++; return PLK_OK; }
     if (n < 4096) {
         uint32_t blocks = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
-        PLK_TRY(ctx->msm_d.reserve((size_t)batch * blocks * sizeof(G1Xyzz)));
+        PLK_TRY(S.d.reserve((size_t)batch * blocks * sizeof(G1Xyzz)));
         for (uint32_t m = 0; m < batch; m++)
-            hipLaunchKernelGGL(msm_naive, dim3(blocks), dim3(MSM_THREADS), 0, stream, bases, scalars_dev[m], (uint32_t)n, ctx->msm_d.as<G1Xyzz>() + (size_t)m * blocks);
+            hipLaunchKernelGGL(msm_naive, dim3(blocks), dim3(MSM_THREADS), 0, stream, bases, scalars_dev[m], (uint32_t)n, S.d.as<G1Xyzz>() + (size_t)m * blocks);
         PLK_HIP(hipGetLastError());
-        ctx->msm_pending_parts = blocks;
-        ctx->msm_c_bits = 0;
-        PLK_TRY(ensure_pinned(ctx, (size_t)batch * blocks * sizeof(G1Xyzz)));
-        PLK_HIP(hipMemcpyAsync(ctx->pinned, ctx->msm_d.p, (size_t)batch * blocks * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
+        S.pending_parts = blocks;
+        S.c_bits = 0;
+        PLK_TRY(slot_pinned(S, (size_t)batch * blocks * sizeof(G1Xyzz)));
+        PLK_HIP(hipMemcpyAsync(S.pinned, S.d.p, (size_t)batch * blocks * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
+        ctx->msm_enq++;
         return PLK_OK;
     }
     MsmParams p;
@@ -618,21 +640,21 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     for (uint32_t m = 0; m < batch; m++) set.v[m] = scalars_dev[m];
     const uint32_t total_sets = batch * p.groups, total_bins = total_sets * p.nbins, total_windows = batch * p.windows;
     const uint32_t max_tasks = total_bins + (uint32_t)(((uint64_t)total_windows * n) / TASK_MAX) + 1;
-    PLK_TRY(ctx->msm_a.reserve((size_t)(3 * total_bins + 4) * sizeof(uint32_t)));               // hist/cursor, bin_start, task_start
-    PLK_TRY(ctx->msm_b.reserve((size_t)total_windows * n * sizeof(uint32_t)));                   // entries
-    PLK_TRY(ctx->msm_c.reserve((size_t)max_tasks * 2 * sizeof(XyzzW) + (size_t)max_tasks * META_PER_TASK * 4));  // per-task (S, T) + bucket offsets
-    PLK_TRY(ctx->msm_e.reserve((size_t)max_tasks * SLOTS_PER_TASK * sizeof(XyzzW)));             // lane partial sums
-    PLK_TRY(ctx->msm_d.reserve((size_t)2 * total_sets * sizeof(G1Xyzz)));                     // per window: sum S, sum c*D
-    uint32_t *hist = ctx->msm_a.as<uint32_t>(), *bin_start = hist + total_bins, *task_start = bin_start + total_bins + 1;
-    uint32_t *entries = ctx->msm_b.as<uint32_t>();
-    XyzzW *task_out = ctx->msm_c.as<XyzzW>();
+    PLK_TRY(S.a.reserve((size_t)(3 * total_bins + 4) * sizeof(uint32_t)));               // hist/cursor, bin_start, task_start
+    PLK_TRY(S.b.reserve((size_t)total_windows * n * sizeof(uint32_t)));                   // entries
+    PLK_TRY(S.c.reserve((size_t)max_tasks * 2 * sizeof(XyzzW) + (size_t)max_tasks * META_PER_TASK * 4));  // per-task (S, T) + bucket offsets
+    PLK_TRY(S.e.reserve((size_t)max_tasks * SLOTS_PER_TASK * sizeof(XyzzW)));             // lane partial sums
+    PLK_TRY(S.d.reserve((size_t)2 * total_sets * sizeof(G1Xyzz)));                     // per window: sum S, sum c*D
+    uint32_t *hist = S.a.as<uint32_t>(), *bin_start = hist + total_bins, *task_start = bin_start + total_bins + 1;
+    uint32_t *entries = S.b.as<uint32_t>();
+    XyzzW *task_out = S.c.as<XyzzW>();
     uint32_t *task_meta = reinterpret_cast<uint32_t *>(task_out + 2 * (size_t)max_tasks);
-    XyzzW *partials = ctx->msm_e.as<XyzzW>();
-    G1Xyzz *window_out = ctx->msm_d.as<G1Xyzz>();
+    XyzzW *partials = S.e.as<XyzzW>();
+    G1Xyzz *window_out = S.d.as<G1Xyzz>();
 
     PLK_HIP(hipMemsetAsync(hist, 0, total_bins * sizeof(uint32_t), stream));
-    PLK_TRY(ctx->msm_f.reserve((size_t)total_windows * n * sizeof(int16_t)));
-    int16_t *digits = ctx->msm_f.as<int16_t>();
+    PLK_TRY(S.f.reserve((size_t)total_windows * n * sizeof(int16_t)));
+    int16_t *digits = S.f.as<int16_t>();
     hipLaunchKernelGGL(msm_digits, dim3((uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS), batch), dim3(MSM_THREADS), 0, stream, set, p, digits);
     const uint32_t pblocks = (uint32_t)((n + DIGIT_CHUNK - 1) / DIGIT_CHUNK);
     const size_t plds_count = (size_t)p.nbins * sizeof(uint32_t);
@@ -646,20 +668,21 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     hipLaunchKernelGGL(msm_partition<false>, dim3(pblocks, total_windows), dim3(MSM_THREADS), plds_count, stream, (const int16_t *)digits, p, hist, (const uint32_t *)nullptr, (uint32_t *)nullptr);
     hipLaunchKernelGGL(msm_scan_bins, dim3(1), dim3(1024), 0, stream, hist, bin_start, task_start, total_bins);
     hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks, total_windows), dim3(MSM_THREADS), plds_scatter, stream, (const int16_t *)digits, p, hist, (const uint32_t *)bin_start, entries);
-    if (ctx->ev_on) PLK_HIP(hipEventRecord(ctx->ev[0], stream));
+    if (ctx->ev_on) PLK_HIP(hipEventRecord(S.ev[0], stream));
     hipLaunchKernelGGL(msm_accumulate, dim3(max_tasks), dim3(MSM_THREADS), CHUNK * sizeof(uint32_t), stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
                        (const uint32_t *)task_start, partials, task_meta, p);
-    if (ctx->ev_on) PLK_HIP(hipEventRecord(ctx->ev[1], stream));
+    if (ctx->ev_on) PLK_HIP(hipEventRecord(S.ev[1], stream));
     hipLaunchKernelGGL(msm_fold_hot, dim3((max_tasks * RL + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
                        partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
     hipLaunchKernelGGL(msm_task_reduce, dim3((max_tasks * RL + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
                        (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
     hipLaunchKernelGGL(msm_window_sums, dim3(total_sets, 2), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins);
     PLK_HIP(hipGetLastError());
-    PLK_TRY(ensure_pinned(ctx, (size_t)2 * total_sets * sizeof(G1Xyzz)));
-    PLK_HIP(hipMemcpyAsync(ctx->pinned, window_out, (size_t)2 * total_sets * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
-    ctx->msm_windows = p.groups;
-    ctx->msm_c_bits = p.c;
+    PLK_TRY(slot_pinned(S, (size_t)2 * total_sets * sizeof(G1Xyzz)));
+    PLK_HIP(hipMemcpyAsync(S.pinned, window_out, (size_t)2 * total_sets * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
+    S.windows = p.groups;
+    S.c_bits = p.c;
+    ctx->msm_enq++;
     return PLK_OK;
 }
 
@@ -681,23 +704,26 @@ static host::HJac xyzz_host_to_jac(const uint64_t *v) {
 }
 
 // waits for the stream, then folds the window sums (Horner, c doublings per window) on the host
-int32_t msm_finish_batch(plk_ctx *ctx, hipStream_t stream, host::HJac *out) {
+int32_t msm_finish_batch(plk_ctx *ctx, hipStream_t, host::HJac *out) {
     using namespace host;
-    PLK_HIP(hipStreamSynchronize(stream));
-    for (uint32_t m = 0; m < ctx->msm_batch; m++) {
+    if (ctx->msm_fin == ctx->msm_enq) { set_error("msm: nothing in flight"); return PLK_ERR_ARG; }
+    plk_ctx::MsmSlot &S = ctx->slot[ctx->msm_fin & 1];
+    ctx->msm_fin++;
+    PLK_HIP(hipStreamSynchronize(S.stream));
+    for (uint32_t m = 0; m < S.batch; m++) {
         HJac acc = HJac::inf();
-        if (ctx->msm_windows) {
+        if (S.windows) {
             // per window the device leaves (sum S, sum c*D); W_w = sum S + 2^FINE_BITS * sum c*D
-            const uint64_t *raw = reinterpret_cast<const uint64_t *>(ctx->pinned) + (size_t)32 * m * ctx->msm_windows;
-            for (int w = (int)ctx->msm_windows - 1; w >= 0; w--) {
-                for (uint32_t i = 0; i < ctx->msm_c_bits; i++) acc = jac_double(acc);
+            const uint64_t *raw = reinterpret_cast<const uint64_t *>(S.pinned) + (size_t)32 * m * S.windows;
+            for (int w = (int)S.windows - 1; w >= 0; w--) {
+                for (uint32_t i = 0; i < S.c_bits; i++) acc = jac_double(acc);
                 HJac d = xyzz_host_to_jac(raw + 32 * w + 16);
                 for (uint32_t i = 0; i < FINE_BITS; i++) d = jac_double(d);
                 acc = jac_add(acc, jac_add(xyzz_host_to_jac(raw + 32 * w), d));
             }
         } else {
-            const uint64_t *raw = reinterpret_cast<const uint64_t *>(ctx->pinned) + (size_t)16 * m * ctx->msm_pending_parts;
-            for (uint32_t i = 0; i < ctx->msm_pending_parts; i++) acc = jac_add(acc, xyzz_host_to_jac(raw + 16 * i));
+            const uint64_t *raw = reinterpret_cast<const uint64_t *>(S.pinned) + (size_t)16 * m * S.pending_parts;
+            for (uint32_t i = 0; i < S.pending_parts; i++) acc = jac_add(acc, xyzz_host_to_jac(raw + 16 * i));
         }
         out[m] = acc;
     }
@@ -705,7 +731,7 @@ int32_t msm_finish_batch(plk_ctx *ctx, hipStream_t stream, host::HJac *out) {
 }
 
 int32_t msm_finish(plk_ctx *ctx, hipStream_t stream, host::HJac *out) {
-    if (ctx->msm_batch != 1) { set_error("msm_finish: a batch is pending"); return PLK_ERR_ARG; }
+    if (ctx->msm_fin != ctx->msm_enq && ctx->slot[ctx->msm_fin & 1].batch != 1) { set_error("msm_finish: a batch is pending"); return PLK_ERR_ARG; }
     return msm_finish_batch(ctx, stream, out);
 }
 
@@ -718,14 +744,13 @@ extern "C" {
 int32_t plk_msm_g1_enqueue_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, void *stream) {
     if (!ctx || (!scalars_dev && n)) { set_error("plk_msm_g1: bad argument"); return PLK_ERR_ARG; }
     PLK_HIP(hipSetDevice(ctx->device));
-    ctx->msm_stream = stream ? (hipStream_t)stream : ctx->stream;
-    return msm_enqueue(ctx, (const Fr *)scalars_dev, n, base_offset, ctx->msm_stream);
+    return msm_enqueue(ctx, (const Fr *)scalars_dev, n, base_offset, stream ? (hipStream_t)stream : ctx->stream);
 }
 
 int32_t plk_msm_g1_finish(plk_ctx *ctx, plk_g1_jacobian *out) {
     if (!ctx || !out) { set_error("plk_msm_g1_finish: bad argument"); return PLK_ERR_ARG; }
     host::HJac j;
-    PLK_TRY(msm_finish(ctx, ctx->msm_stream ? ctx->msm_stream : ctx->stream, &j));
+    PLK_TRY(msm_finish(ctx, nullptr, &j));
     memcpy(out->x, j.x.l, 32); memcpy(out->y, j.y.l, 32); memcpy(out->z, j.z.l, 32);
     return PLK_OK;
 }
@@ -771,16 +796,17 @@ int32_t plk_msm_g1(plk_ctx *ctx, const plk_fr *scalars, uint64_t n, uint64_t bas
 int32_t plk_set_kernel_timing(plk_ctx *ctx, int32_t on) {
     if (!ctx) { set_error("null ctx"); return PLK_ERR_ARG; }
     PLK_HIP(hipSetDevice(ctx->device));
-    if (on && !ctx->ev[0]) { PLK_HIP(hipEventCreate(&ctx->ev[0])); PLK_HIP(hipEventCreate(&ctx->ev[1])); }
     ctx->ev_on = on != 0;
     return PLK_OK;
 }
 
 int32_t plk_msm_last_kernel_ms(plk_ctx *ctx, float *accumulate_ms) {
     if (!ctx || !accumulate_ms) { set_error("plk_msm_last_kernel_ms: bad argument"); return PLK_ERR_ARG; }
-    if (!ctx->ev_on || !ctx->ev[0]) { set_error("kernel timing is off (plk_set_kernel_timing)"); return PLK_ERR_ARG; }
-    PLK_HIP(hipEventSynchronize(ctx->ev[1]));
-    PLK_HIP(hipEventElapsedTime(accumulate_ms, ctx->ev[0], ctx->ev[1]));
+    if (!ctx->ev_on || ctx->msm_fin == 0) { set_error("kernel timing is off (plk_set_kernel_timing) or no commitment finished yet"); return PLK_ERR_ARG; }
+    plk_ctx::MsmSlot &S = ctx->slot[(ctx->msm_fin - 1) & 1];                  // the commitment finished last
+    if (!S.ev[0]) { set_error("the last commitment was enqueued with kernel timing off"); return PLK_ERR_ARG; }
+    PLK_HIP(hipEventSynchronize(S.ev[1]));
+    PLK_HIP(hipEventElapsedTime(accumulate_ms, S.ev[0], S.ev[1]));
     return PLK_OK;
 }
 

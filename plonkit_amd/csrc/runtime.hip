@@ -2,6 +2,7 @@
 // (The reference's counterpart is bellman_ce::worker::Worker + Crs held in SetupForProver,
 //  src/plonk.rs:41-55; here the resource is one MI355X, its stream and its HBM-resident tables.)
 #include "ctx.h"
+#include <cstdlib>
 #include "ntt.h"
 #include "msm.h"
 #include <cstring>
@@ -71,6 +72,9 @@ int32_t plk_device_count(void) {
 }
 
 int32_t plk_create(int32_t device, plk_ctx **out) {
+    // two commitments may be in flight on two streams (MsmSlot): ask for enough hardware queues that they do not
+    // share one (HIP's default is 4 per device; no effect if the runtime is already initialised by the host program)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     if (!out) { set_error("plk_create: null out"); return PLK_ERR_ARG; }
     *out = nullptr;
     int n = 0;
@@ -104,11 +108,16 @@ void plk_destroy(plk_ctx *ctx) {
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
     for (void *p : ctx->coset_allocs) (void)hipFree(p);
     ctx->tables.release(); ctx->ntt_scratch.release(); ctx->srs_own.release(); ctx->srs_w.release(); ctx->lag.own.release(); ctx->lag.w.release();
-    ctx->msm_a.release(); ctx->msm_b.release(); ctx->msm_c.release(); ctx->msm_d.release(); ctx->msm_e.release(); ctx->msm_f.release();
+    for (auto &S : ctx->slot) {
+        S.a.release(); S.b.release(); S.c.release(); S.d.release(); S.e.release(); S.f.release();
+        if (S.pinned) (void)hipHostFree(S.pinned);
+        if (S.stream) (void)hipStreamDestroy(S.stream);
+        if (S.ready) (void)hipEventDestroy(S.ready);
+        if (S.ev[0]) { (void)hipEventDestroy(S.ev[0]); (void)hipEventDestroy(S.ev[1]); }
+    }
     ctx->stage.release(); ctx->poly_tmp.release(); ctx->poly_tmp2.release(); ctx->prove_ws.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned2) (void)hipHostFree(ctx->pinned2);
-    if (ctx->ev[0]) { (void)hipEventDestroy(ctx->ev[0]); (void)hipEventDestroy(ctx->ev[1]); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

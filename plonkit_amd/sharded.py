@@ -43,17 +43,18 @@ class ShardedMsm:
         return combine_partials(partial, self.dist, self.device)
 
     def commit_stream(self, batches, n, base_offset=0, stream=None):
-        """Generator over a sequence of scalar vectors: commitment k is exchanged (all_gather + host EC sum)
-        while the GPU already runs the kernels of commitment k+1 — the exchange step of SURVEY.md §8(e)
-        ("what matters is overlapping ... MSM k+1 with MSM k") costs no GPU idle time."""
+        """Generator over a sequence of scalar vectors.  The library keeps two commitments in flight (two scratch
+        sets, two streams): k+1 is enqueued before k is finished, so the latency-bound bucket reduction of k, its
+        host Horner and its exchange (all_gather + host EC sum) all overlap the accumulation of k+1 — the overlap
+        SURVEY.md §8(e) asks for.  The scalars of a commitment must stay untouched until it has been yielded."""
         it = iter(batches)
         cur = next(it, None)
         if cur is None:
             return
         self.ctx.msm_enqueue_dev(cur, n, base_offset, stream=stream)
         while cur is not None:
-            partial = self.ctx.msm_finish()                    # waits for commitment k, host Horner over the windows
             cur = next(it, None)
-            if cur is not None:
-                self.ctx.msm_enqueue_dev(cur, n, base_offset, stream=stream)   # k+1 starts before k is exchanged
+            if cur is not None:                                # two commitments in flight: k+1 is accumulating while
+                self.ctx.msm_enqueue_dev(cur, n, base_offset, stream=stream)   # k reduces its buckets and is exchanged
+            partial = self.ctx.msm_finish()                    # waits for commitment k, host Horner over the windows
             yield combine_partials(partial, self.dist, self.device)

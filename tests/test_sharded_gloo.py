@@ -95,8 +95,8 @@ def _stream_worker(rank, world, port, n_per_rank, q):
         msm = ShardedMsm(shard, dist, None)
         got = list(msm.commit_stream((v[lo:hi] for v in vecs), n_per_rank))
         ok = all(np.array_equal(g, ol.msm(srs, v, threads=2)) for g, v in zip(got, vecs))
-        # commitment k+1 is enqueued before commitment k is exchanged
-        ok = ok and shard.log == ["enqueue", "finish", "enqueue", "finish", "enqueue", "finish"]
+        # two in flight: commitment k+1 is enqueued before commitment k is finished and exchanged
+        ok = ok and shard.log == ["enqueue", "enqueue", "finish", "enqueue", "finish", "finish"]
         q.put((rank, bool(ok), len(got)))
     finally:
         dist.destroy_process_group()
