@@ -58,6 +58,19 @@ static int32_t commit_many(plk_ctx *ctx, const Fr *const *coefs, uint32_t count,
     return PLK_OK;
 }
 
+// split form: the commitment's kernels run on their own stream (msm.hip, MsmSlot), so independent work issued on
+// ctx->stream between begin and end fills the SIMDs that the bucket-reduction phase leaves idle
+static int32_t commit_begin(plk_ctx *ctx, const Fr *const *vecs, uint32_t count, uint64_t n, bool lagrange = false) {
+    SrsSlotSwap active(ctx, lagrange);
+    return msm_enqueue_batch(ctx, vecs, count, n, 0, ctx->stream);
+}
+static int32_t commit_end(plk_ctx *ctx, uint32_t count, HAffine *out) {
+    HJac j[8];
+    PLK_TRY(msm_finish_batch(ctx, nullptr, j));
+    for (uint32_t k = 0; k < count; k++) out[k] = jac_to_affine(j[k]);
+    return PLK_OK;
+}
+
 struct Arena {
     DevBuf *buf; size_t off = 0;
     template <class T> T *take(size_t count) {
@@ -329,7 +342,9 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     const bool use_lagrange = ctx->lag.pts != nullptr;
     if (use_lagrange && ctx->lag.n != N) { set_error("Lagrange-form key has a different size than the circuit's domain"); return PLK_ERR_SRS; }
     HAffine wire_c[4];
-    PLK_TRY(commit_many(ctx, use_lagrange ? w_vals : w_coef, 4, N, wire_c, use_lagrange));
+    PLK_TRY(commit_begin(ctx, use_lagrange ? w_vals : w_coef, 4, N, use_lagrange));
+    for (int j = 0; j < 4; j++) PLK_TRY(lde4_dev(ctx, w_coef[j], log_n, ext[j], st));      // round-3 work that needs no challenge
+    PLK_TRY(commit_end(ctx, 4, wire_c));
     RollingKeccak tr;
     for (const HFr &x : inputs) tr.absorb_fr(x);
     for (int j = 0; j < 4; j++) tr.absorb_g1(wire_c[j]);
@@ -357,7 +372,14 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
         PLK_TRY(ntt_dev(ctx, z_coef, log_n, true, nullptr, st));
     }
     HAffine z_c;
-    { const Fr *zp = use_lagrange ? t1 : z_coef; PLK_TRY(commit_many(ctx, &zp, 1, N, &z_c, use_lagrange)); }
+    { const Fr *zp = use_lagrange ? t1 : z_coef; PLK_TRY(commit_begin(ctx, &zp, 1, N, use_lagrange)); }
+    // while z is being committed: its extension, the public-input polynomial, and (first proof only) the constant vectors
+    PLK_TRY(lde4_dev(ctx, z_coef, log_n, ext[4], st));
+    PLK_HIP(hipMemsetAsync(pi_coef, 0, N * sizeof(Fr), st));
+    if (!inputs.empty()) PLK_HIP(hipMemcpyAsync(pi_coef, inputs.data(), inputs.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
+    PLK_TRY(ntt_dev(ctx, pi_coef, log_n, true, nullptr, st));
+    PLK_TRY(lde4_dev(ctx, pi_coef, log_n, ext[16], st));
+    PLK_TRY(commit_end(ctx, 1, &z_c));
     tr.absorb_g1(z_c);
     const HFr alpha = tr.challenge();
     lap();                                                                    // [2] round 2
@@ -365,8 +387,6 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     // ---- round 3: quotient on the coset 7*<omega_4N>: 18 x LDE, fused point-wise kernel, coset iNTT(4N)
     const HFr coset = HFr::from_u64(7);
     {
-        for (int j = 0; j < 4; j++) PLK_TRY(lde4_dev(ctx, w_coef[j], log_n, ext[j], st));
-        PLK_TRY(lde4_dev(ctx, z_coef, log_n, ext[4], st));
         if (!S->lde_ready) {
             PLK_TRY(S->lde_store.reserve(13 * MB));
             Arena LA{&S->lde_store};
@@ -391,11 +411,6 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
         }
         for (int k = 0; k < 11; k++) ext[5 + k] = S->lde[k];
         ext[17] = S->lde[11];
-        PLK_HIP(hipMemsetAsync(pi_coef, 0, N * sizeof(Fr), st));
-        if (!inputs.empty()) PLK_HIP(hipMemcpyAsync(pi_coef, inputs.data(), inputs.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
-        PLK_TRY(ntt_dev(ctx, pi_coef, log_n, true, nullptr, st));
-        PLK_TRY(lde4_dev(ctx, pi_coef, log_n, ext[16], st));
-
         QuotientArgs qa;
         qa.out = t_ext;
         for (int j = 0; j < 4; j++) { qa.w[j] = ext[j]; qa.sigma[j] = ext[12 + j]; qa.beta_k[j] = to_dev(beta * kk[j]); }
