@@ -70,19 +70,20 @@ __device__ __forceinline__ uint32_t extract_bits(const uint32_t *k, uint32_t pos
 }
 
 // Step 1: every scalar leaves Montgomery form once and is recoded into W signed c-bit digits in
-// [-2^(c-1), 2^(c-1)), stored as int16 per (commitment, window): digits[(m*W + w)*n + i].
-__global__ void __launch_bounds__(MSM_THREADS) msm_digits(ScalarSet set, MsmParams p, int16_t *digits) {
+// [-2^(c-1), 2^(c-1)] (c = 17: +-65536), stored as int32 per (commitment, window): digits[(m*W + w)*n + i].
+__global__ void __launch_bounds__(MSM_THREADS) msm_digits(ScalarSet set, MsmParams p, int32_t *digits) {
     const uint32_t i = blockIdx.x * MSM_THREADS + threadIdx.x, m = blockIdx.y;
     if (i >= p.n) return;
     Fr k = to_canonical(load_fp(set.v[m] + i));
     uint32_t carry = 0;
     const uint32_t half = 1u << (p.c - 1);
-    int16_t *out = digits + (size_t)m * p.windows * p.n + i;
+    int32_t *out = digits + (size_t)m * p.windows * p.n + i;
     for (uint32_t w = 0; w < p.windows; w++) {
         uint32_t v = extract_bits(k.l, w * p.c, p.c) + carry;
         int32_t d;
-        if (v >= half) { d = (int32_t)v - (int32_t)(1u << p.c); carry = 1; } else { d = (int32_t)v; carry = 0; }
-        out[(size_t)w * p.n] = (int16_t)d;
+        // the top window is left unsigned: it holds 254 - (W-1)*c bits plus a carry, at most 2^(c-1) — a valid bucket
+        if (v >= half && w + 1 < p.windows) { d = (int32_t)v - (int32_t)(1u << p.c); carry = 1; } else { d = (int32_t)v; carry = 0; }
+        out[(size_t)w * p.n] = d;
     }
 }
 
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_digits(ScalarSet set, MsmPara
 // one global reservation per (block, bin), then every bin's run is copied out contiguously — full
 // 64-256 B bursts instead of 4-byte scattered stores (the first version wrote 13x its payload to HBM).
 template <bool SCATTER>
-__global__ void __launch_bounds__(MSM_THREADS) msm_partition(const int16_t *digits, MsmParams p, uint32_t *hist_or_cursor,
+__global__ void __launch_bounds__(MSM_THREADS) msm_partition(const int32_t *digits, MsmParams p, uint32_t *hist_or_cursor,
                                                               const uint32_t *bin_start, uint32_t *entries) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *lcnt = reinterpret_cast<uint32_t *>(smem);               // [nbins]
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_partition(const int16_t *digi
     const uint32_t tid = threadIdx.x, gw = blockIdx.y;
     const uint32_t first = blockIdx.x * DIGIT_CHUNK;
     const uint32_t last = first + DIGIT_CHUNK < p.n ? first + DIGIT_CHUNK : p.n;
-    const int16_t *dg = digits + (size_t)gw * p.n;
+    const int32_t *dg = digits + (size_t)gw * p.n;
     const uint32_t w = gw % p.windows, set = (gw / p.windows) * p.groups + w % p.groups;    // bucket set of this window
     const uint32_t copy_tag = (w / p.groups) << p.nbits;                                     // which table copy its points come from
     hist_or_cursor += set * p.nbins;
@@ -223,12 +224,12 @@ __global__ void __launch_bounds__(256) srs_to_w_kernel(G1Affine *out, const G1Af
 }
 
 // ------------------------------------------------------------- shifted copies of the bases
-// The SRS is a fixed base: copy k of the table holds 2^(16k) * P_i (affine, W domain), built once per SRS
-// (15 x 16 doublings per point and one batched inversion per copy; 64 MB per copy at 2^20 points).
-// With all 16 copies resident a 2^20-term commitment has ONE bucket set instead of 16: the reduction
+// The SRS is a fixed base: copy k of the table holds 2^(17k) * P_i (affine, W domain), built once per SRS
+// (14 x 17 doublings per point and one batched inversion per copy; 64 MB per copy at 2^20 points).
+// With all 15 copies resident a 2^20-term commitment has ONE bucket set instead of 15: the reduction
 // kernels and the host Horner shrink accordingly, the accumulate kernel gathers from a 1 GB table in
 // HBM instead of a cache-resident 64 MB one (measured: no difference, it is bound by the multiplier).
-constexpr uint32_t COPY_SHIFT = 16, MAX_COPIES = 16, NORM_K = 32;
+constexpr uint32_t COPY_SHIFT = 17, MAX_COPIES = 15, NORM_K = 32;    // 15 windows of 17 bits cover the 254-bit scalars
 
 __global__ void __launch_bounds__(256) srs_shift_kernel(const G1Affine *prev, G1Xyzz *out, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -270,8 +271,8 @@ __global__ void __launch_bounds__(256) srs_normalise_kernel(const G1Xyzz *in, Fq
     }
 }
 
-// All 16 copies or none: a commitment that can only address `copies` < 16 of them ((copy, index) must fit the
-// 24-bit field of an entry) uses every (16/copies)-th copy, so the full table serves every size.
+// All 15 copies or none: a commitment that can only address 5 or 3 of them ((copy, index) must fit the 24-bit
+// field of an entry) uses every 3rd or 5th copy, so the full table serves every size.
 static uint32_t table_copies_for(uint64_t srs_n) {           // the table may take up to 32 GiB of the 288 GB
     return (uint64_t)MAX_COPIES * srs_n * sizeof(G1Affine) <= (32ull << 30) ? MAX_COPIES : 1;
 }
@@ -334,7 +335,11 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_accumulate(const G1Affine 
     while (bhi - blo > 1) { uint32_t mid = (blo + bhi) >> 1; if (task_start[mid] <= task) blo = mid; else bhi = mid; }
     const uint32_t bin = blo, slice = task - task_start[bin];
     const uint32_t bs = bin_start[bin], be = bin_start[bin + 1];
-    const uint32_t s = bs + slice * CHUNK, e = (s + CHUNK < be) ? s + CHUNK : be, nc = e - s;
+    // a bin that needs k tasks is cut into k EQUAL slices (not CHUNK, CHUNK, ..., remainder): with ~6 tasks per
+    // workgroup slot a mix of full and quarter-size tasks left the last full ones running alone (measured at 2^21:
+    // 3.7 ms instead of 2.6 ms for the same additions)
+    const uint32_t k_bin = task_start[bin + 1] - task_start[bin], per = (be - bs + k_bin - 1) / k_bin;
+    const uint32_t s = bs + slice * per < be ? bs + slice * per : be, e = (s + per < be) ? s + per : be, nc = e - s;
 
     if (tid < FINE) { cnt[tid] = 0; cursor[tid] = 0; }
     __syncthreads();
@@ -501,24 +506,42 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_task_reduce(const XyzzW *p
 // full additions issued from one inlined call site (operands in registers, see msm_task_reduce); the
 // shift by 2^FINE_BITS and the final addition are left to the host Horner, which doubles anyway.
 // Results are exported in the library's external form (canonical, R = 2^256).
+// 256 threads; with 512 coarse bins (c = 17) thread t serves bins t and t + 256:  sum_c c*D_c =
+// sum_t t*(D_t + D_{t+256}) + 256 * sum_t D_{t+256}, the last sum being a third workgroup (role 2) whose weight
+// 2^8 is again left to the host.
 constexpr uint32_t THREADS_LOG = 8;
 static_assert((1u << THREADS_LOG) == MSM_THREADS, "THREADS_LOG");
-__global__ void __launch_bounds__(MSM_THREADS, 2) msm_window_sums(const XyzzW *task_out, const uint32_t *task_start, G1Xyzz *window_out, uint32_t nbins) {
+__global__ void __launch_bounds__(MSM_THREADS, 2) msm_window_sums(const XyzzW *task_out, const uint32_t *task_start, G1Xyzz *window_out, uint32_t nbins, uint32_t roles) {
     __shared__ __attribute__((aligned(16))) XyzzW sh[MSM_THREADS];
     const uint32_t tid = threadIdx.x, w = blockIdx.x, role = blockIdx.y;
+    const uint32_t halves = (nbins + MSM_THREADS - 1) / MSM_THREADS;            // 1 or 2
+    uint32_t u = role == 2 ? 1 : 0;
+    const uint32_t u_end = role == 2 ? 2 : halves;
     uint32_t t = 0, t_end = 0;
-    if (tid < nbins) { t = task_start[w * nbins + tid]; t_end = task_start[w * nbins + tid + 1]; }
+    auto open_bin = [&]() {                                   // next non-empty bin of this thread
+        for (; u < u_end; u++) {
+            const uint32_t bin = tid + MSM_THREADS * u;
+            if (bin >= nbins) continue;
+            t = task_start[w * nbins + bin]; t_end = task_start[w * nbins + bin + 1];
+            if (t < t_end) return;
+        }
+        t = t_end = 0;
+    };
+    open_bin();
     XyzzW X = xyzzw_identity();
-    const uint32_t scan_steps = role ? THREADS_LOG : 0, usteps = scan_steps + THREADS_LOG;
+    const uint32_t scan_steps = role == 1 ? THREADS_LOG : 0, usteps = scan_steps + THREADS_LOG;
     uint32_t ustep = 0;
     for (;;) {
         const bool lockstep = __syncthreads_and(t >= t_end);  // (also the barrier that lets sh be rewritten)
         if (lockstep && ustep == usteps) break;
         XyzzW O = xyzzw_identity();
         if (!lockstep) {
-            if (t < t_end) { O = load_xyzzw(task_out + 2 * (size_t)t + role); t++; }
+            if (t < t_end) {
+                O = load_xyzzw(task_out + 2 * (size_t)t + (role ? 1 : 0));
+                if (++t == t_end) { u++; open_bin(); }
+            }
         } else {
-            if (role && ustep == scan_steps && tid == 0) X = xyzzw_identity();    // sum_c c*D_c = sum_{k>=1} suffix_k
+            if (role == 1 && ustep == scan_steps && tid == 0) X = xyzzw_identity();    // sum_t t*E_t = sum_{k>=1} suffix_k
             sh[tid] = X;
             __syncthreads();
             if (ustep < scan_steps) {                          // inclusive suffix scan over the bins
@@ -532,7 +555,7 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_window_sums(const XyzzW *t
         }
         xyzzw_add(X, O);                                      // the one addition site of the kernel
     }
-    if (tid == 0) store_xyzz(window_out + 2 * w + role, xyzzw_export(X));
+    if (tid == 0) store_xyzz(window_out + (size_t)roles * w + role, xyzzw_export(X));
 }
 
 // ------------------------------------------------------------------- tiny inputs: no buckets
@@ -566,7 +589,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_naive(const G1Affine *bases, 
 static uint32_t pick_window_bits(uint64_t n) {
     if (n < (1u << 17)) return 13;
     if (n < (1u << 19)) return 15;                            // measured: 2^18 1.27 ms (c=15) vs 1.40 ms (c=16)
-    return 16;
+    return 17;                                                // 15 windows; 2^16 buckets = 512 coarse bins x 128
 }
 
 int32_t ensure_pinned(plk_ctx *ctx, size_t bytes);
@@ -605,7 +628,8 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     if (c_bits == COPY_SHIFT) {
         copies = table_copies_for(ctx->srs_n);
         PLK_TRY(ensure_base_table(ctx, copies, stream));
-        while (copies > 1 && ((uint64_t)copies << nbits) > (1ull << 24)) copies >>= 1;     // 24-bit (copy, index) field of an entry
+        while (copies > 1 && (MAX_COPIES % copies != 0 || ((uint64_t)copies << nbits) > (1ull << 24))) copies--;   // a divisor of 15 that fits the 24-bit (copy, index) field of an entry
+        { const char *e = getenv("PLK_MSM_COPIES"); if (e && atoi(e) >= 1 && (uint32_t)atoi(e) <= copies && MAX_COPIES % atoi(e) == 0) copies = (uint32_t)atoi(e); }   // tuning probe
     } else PLK_TRY(ensure_base_table(ctx, 1, stream));
     const G1Affine *bases = ctx->srs_w.as<G1Affine>() + base_offset;
     S.pending_parts = 0;
@@ -629,7 +653,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     p.n = (uint32_t)n;
     p.c = c_bits;
     p.windows = 254 / p.c + 1;
-    p.groups = p.windows / copies;                            // copies > 1 only for c = 16: 16 windows, copies | 16
+    p.groups = p.windows / copies;                            // copies > 1 only for c = 17: 15 windows, copies | 15
     p.nbits = nbits;
     p.copy_stride = copies > 1 ? (uint32_t)(p.groups * ctx->srs_n) : 0;
     p.coarse_bits = p.c - 1 - FINE_BITS;
@@ -644,7 +668,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     PLK_TRY(S.b.reserve((size_t)total_windows * n * sizeof(uint32_t)));                   // entries
     PLK_TRY(S.c.reserve((size_t)max_tasks * 2 * sizeof(XyzzW) + (size_t)max_tasks * META_PER_TASK * 4));  // per-task (S, T) + bucket offsets
     PLK_TRY(S.e.reserve((size_t)max_tasks * SLOTS_PER_TASK * sizeof(XyzzW)));             // lane partial sums
-    PLK_TRY(S.d.reserve((size_t)2 * total_sets * sizeof(G1Xyzz)));                     // per window: sum S, sum c*D
+    PLK_TRY(S.d.reserve((size_t)3 * total_sets * sizeof(G1Xyzz)));                     // per window: sum S, sum c*D
     uint32_t *hist = S.a.as<uint32_t>(), *bin_start = hist + total_bins, *task_start = bin_start + total_bins + 1;
     uint32_t *entries = S.b.as<uint32_t>();
     XyzzW *task_out = S.c.as<XyzzW>();
@@ -653,8 +677,8 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     G1Xyzz *window_out = S.d.as<G1Xyzz>();
 
     PLK_HIP(hipMemsetAsync(hist, 0, total_bins * sizeof(uint32_t), stream));
-    PLK_TRY(S.f.reserve((size_t)total_windows * n * sizeof(int16_t)));
-    int16_t *digits = S.f.as<int16_t>();
+    PLK_TRY(S.f.reserve((size_t)total_windows * n * sizeof(int32_t)));
+    int32_t *digits = S.f.as<int32_t>();
     hipLaunchKernelGGL(msm_digits, dim3((uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS), batch), dim3(MSM_THREADS), 0, stream, set, p, digits);
     const uint32_t pblocks = (uint32_t)((n + DIGIT_CHUNK - 1) / DIGIT_CHUNK);
     const size_t plds_count = (size_t)p.nbins * sizeof(uint32_t);
@@ -665,9 +689,9 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(msm_partition<false>, dim3(pblocks, total_windows), dim3(MSM_THREADS), plds_count, stream, (const int16_t *)digits, p, hist, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(msm_partition<false>, dim3(pblocks, total_windows), dim3(MSM_THREADS), plds_count, stream, (const int32_t *)digits, p, hist, (const uint32_t *)nullptr, (uint32_t *)nullptr);
     hipLaunchKernelGGL(msm_scan_bins, dim3(1), dim3(1024), 0, stream, hist, bin_start, task_start, total_bins);
-    hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks, total_windows), dim3(MSM_THREADS), plds_scatter, stream, (const int16_t *)digits, p, hist, (const uint32_t *)bin_start, entries);
+    hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks, total_windows), dim3(MSM_THREADS), plds_scatter, stream, (const int32_t *)digits, p, hist, (const uint32_t *)bin_start, entries);
     if (ctx->ev_on) PLK_HIP(hipEventRecord(S.ev[0], stream));
     hipLaunchKernelGGL(msm_accumulate, dim3(max_tasks), dim3(MSM_THREADS), CHUNK * sizeof(uint32_t), stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
                        (const uint32_t *)task_start, partials, task_meta, p);
@@ -676,10 +700,12 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
                        partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
     hipLaunchKernelGGL(msm_task_reduce, dim3((max_tasks * RL + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
                        (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
-    hipLaunchKernelGGL(msm_window_sums, dim3(total_sets, 2), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins);
+    const uint32_t roles = p.nbins > MSM_THREADS ? 3 : 2;       // points per bucket set left for the host
+    hipLaunchKernelGGL(msm_window_sums, dim3(total_sets, roles), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins, roles);
     PLK_HIP(hipGetLastError());
-    PLK_TRY(slot_pinned(S, (size_t)2 * total_sets * sizeof(G1Xyzz)));
-    PLK_HIP(hipMemcpyAsync(S.pinned, window_out, (size_t)2 * total_sets * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
+    PLK_TRY(slot_pinned(S, (size_t)roles * total_sets * sizeof(G1Xyzz)));
+    PLK_HIP(hipMemcpyAsync(S.pinned, window_out, (size_t)roles * total_sets * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
+    S.roles = roles;
     S.windows = p.groups;
     S.c_bits = p.c;
     ctx->msm_enq++;
@@ -713,13 +739,20 @@ int32_t msm_finish_batch(plk_ctx *ctx, hipStream_t, host::HJac *out) {
     for (uint32_t m = 0; m < S.batch; m++) {
         HJac acc = HJac::inf();
         if (S.windows) {
-            // per window the device leaves (sum S, sum c*D); W_w = sum S + 2^FINE_BITS * sum c*D
-            const uint64_t *raw = reinterpret_cast<const uint64_t *>(S.pinned) + (size_t)32 * m * S.windows;
+            // per bucket set the device leaves (sum S, sum_t t*E_t [, sum of the D of bins >= 256]);
+            // W = sum S + 2^FINE_BITS * (sum_t t*E_t + 2^8 * upper)
+            const size_t per = (size_t)16 * S.roles;
+            const uint64_t *raw = reinterpret_cast<const uint64_t *>(S.pinned) + per * m * S.windows;
             for (int w = (int)S.windows - 1; w >= 0; w--) {
                 for (uint32_t i = 0; i < S.c_bits; i++) acc = jac_double(acc);
-                HJac d = xyzz_host_to_jac(raw + 32 * w + 16);
+                HJac d = xyzz_host_to_jac(raw + per * w + 16);
+                if (S.roles == 3) {
+                    HJac up = xyzz_host_to_jac(raw + per * w + 32);
+                    for (uint32_t i = 0; i < THREADS_LOG; i++) up = jac_double(up);
+                    d = jac_add(d, up);
+                }
                 for (uint32_t i = 0; i < FINE_BITS; i++) d = jac_double(d);
-                acc = jac_add(acc, jac_add(xyzz_host_to_jac(raw + 32 * w), d));
+                acc = jac_add(acc, jac_add(xyzz_host_to_jac(raw + per * w), d));
             }
         } else {
             const uint64_t *raw = reinterpret_cast<const uint64_t *>(S.pinned) + (size_t)16 * m * S.pending_parts;
