@@ -32,11 +32,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 ALGO_BYTES_PER_TERM = 96         # 64 B base + 32 B scalar
 # PMC traffic of msm_accumulate for ONE 2^20-term launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-# separate passes, profiles/r01_pmc_traffic_v2.txt, median of the single-commitment launches):
-# 1,091,894 KB fetched (16.8 M gathers of one 64-byte point each from the 1 GiB fixed-base table
-# = 1.07 GB, + 67 MB of sorted entries: the counter is consistent with 64 B per gather, i.e. no
-# over-fetch) + 132,115 KB written (lane partial sums).  Only valid for --log-n 20, N=1.
-PMC_TRAFFIC_BYTES_2POW20 = (1091894 + 132115) * 1024
+# separate passes, profiles/r01_pmc_traffic_v3.txt, median of the single-commitment launches):
+# 1,034,100 KB fetched (15.7 M gathers of one 64-byte point each from the 0.94 GiB fixed-base table
+# = 1.007 GB, + 63 MB of sorted entries: the counter is consistent with 64 B per gather, i.e. no
+# over-fetch) + 63,146 KB written (lane partial sums).  Only valid for --log-n 20, N=1.
+PMC_TRAFFIC_BYTES_2POW20 = (1034100 + 63146) * 1024
+MSM_WINDOWS = 15                # 17-bit signed windows over the 254-bit scalars: mixed additions per term
 VALU_PEAK_GMADD = 15.6           # tools/ubench_w: isolated mixed-addition loop, G additions/s (profiles/r01_ubench_w.txt)
 
 
@@ -171,16 +172,16 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": PMC_TRAFFIC_BYTES_2POW20 if (args.log_n == 20) else None,
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes": ALGO_BYTES_PER_TERM * n,
-                         "valu": {"achieved_gmadd_s": round(n * (254 // 16 + 1) / (k_ms * 1e-3) / 1e9, 2),
+                         "valu": {"achieved_gmadd_s": round(n * MSM_WINDOWS / (k_ms * 1e-3) / 1e9, 2),
                                   "peak_gmadd_s": VALU_PEAK_GMADD,
-                                  "frac": round(n * (254 // 16 + 1) / (k_ms * 1e-3) / 1e9 / VALU_PEAK_GMADD, 3)},
+                                  "frac": round(n * MSM_WINDOWS / (k_ms * 1e-3) / 1e9 / VALU_PEAK_GMADD, 3)},
                          "note": "commitments are pipelined two deep, so this kernel runs beside the bucket reduction of the previous "
-                                 "commitment and its HIP-event duration (kernel_ms) equals the step time; alone it takes 1.35-1.40 ms "
+                                 "commitment and its HIP-event duration (kernel_ms) equals the step time; alone it takes about 1.3 ms "
                                  "(profiles/r01_bench_final_kernel_stats.csv).  "
                                  "The kernel is bound by v_mad_u64_u32 issue, not HBM (SURVEY.md §8d): `valu` compares its "
                                  "mixed-addition rate with the same loop measured in isolation (tools/ubench_w); `traffic` "
-                                 "is 12x the algorithmic bytes because Pippenger gathers one 64-byte point per (term, window): "
-                                 "16 windows, each from its own shifted copy of the SRS (1 GiB fixed-base table in HBM)"},
+                                 "is 11x the algorithmic bytes because Pippenger gathers one 64-byte point per (term, window): "
+                                 "15 windows, each from its own shifted copy of the SRS (0.94 GiB fixed-base table in HBM)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb, ref, s_host = cpu_baseline(ctx, min(args.cpu_log_n, args.log_n), 1234)

@@ -14,6 +14,7 @@ for r in rows:
     k=r["Kernel_Name"].split("(")[0]
     if sys.argv[2] in k: agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,d in agg.items():
-    for c,v in d.items(): print("%-40s %-24s n=%d mean=%.4e"%(k[:40], c, len(v), sum(v)/len(v)))
+    for c,v in d.items():
+        v=sorted(v); print("%-40s %-24s n=%d min=%.4e median=%.4e mean=%.4e max=%.4e"%(k[:40], c, len(v), v[0], v[len(v)//2], sum(v)/len(v), v[-1]))
 PY
 rm -rf $d $d.log
