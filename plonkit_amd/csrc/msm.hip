@@ -4,24 +4,29 @@
 // kate_commitment::commit_using_monomials — the 11 commitments of prove_by_steps
 // (src/plonk.rs:152-159) and the 11 of make_verification_key (src/plonk.rs:122-124).
 // The result is the same group element; the schedule is MI355X-first, not bellman's:
-//   * signed c-bit windows (c <= 16): 2^(c-1) buckets per window, W = floor(254/c)+1 windows.
-//   * scalars are taken out of Montgomery form once and recoded into int16 signed digits per window.
-//   * two-level bucket sort without a global sort: (1) a coarse partition by (window, top bits of
-//     the bucket index): per (window, 16K-scalar chunk) workgroup an LDS counting sort, one global
-//     reservation per (block, bin) and contiguous copy-out of every bin's run;
-//     (2) each workgroup then owns one coarse bin = 128 consecutive buckets, counting-sorts its
-//     entries inside LDS and accumulates them — two lanes per bucket (ranked by population so that
-//     a wave walks runs of equal length) keep XYZZ accumulators in registers, SRS points are
-//     gathered as 64-byte affine records from the resident SRS (Infinity-Cache sized at 2^20).
-//     All field arithmetic is the carry-free 9x29-bit layer (field29.cuh / ec29.cuh).
-//   * a bucket that is hot inside a task (repeated scalars: all-ones, all -1) is sliced over all
-//     256 lanes; the slices are folded with wave64 shuffle trees in the reduce kernel.
-//   * per-task T = sum B_f and S = sum (f+1) B_f (running sums + 16-lane shuffle scan), then per
-//     window sum_t S_t + 128 * sum_c c * D_c; the last 255 doublings (Horner over windows) run on
-//     the host, where one serial EC chain is 20x faster than on a GPU lane.
-//   * up to 8 commitments over the same bases share every kernel launch (batch dimension).
-// No MFMA (256-bit modular integers), bound by v_mad_u64_u32 issue; HBM sees the algorithmic
-// 96 B/term, the per-window gathers (64 B x W per term) come out of the Infinity Cache.
+//   * signed c-bit windows, W = floor(254/c)+1 of them, top window unsigned: c = 17 (15 windows, 2^16 buckets)
+//     from 2^19 terms, 15 / 13 below; scalars leave Montgomery form once and are recoded into int32 digits.
+//   * the SRS is a FIXED base: a resident table holds 15 shifted copies 2^(17k) * P_i (0.94 GiB at 2^20 points,
+//     built once per SRS).  Window w takes its point from copy w, so that all windows drop into ONE bucket set
+//     (3 or 5 sets above 2^20 terms, where an entry can only address 5 or 3 copies) and the host Horner shrinks
+//     to 17 * (sets - 1) doublings.
+//   * two-level bucket sort without a global sort: (1) a coarse partition by the top bits of the bucket index:
+//     per (window, 16K-scalar chunk) workgroup an LDS counting sort, one global reservation per (block, bin) and
+//     contiguous copy-out of every bin's run; (2) a coarse bin (128 consecutive buckets) is cut into equal tasks
+//     of <= 16384 entries; a workgroup counting-sorts its task inside LDS and cuts the sorted run into 256 EQUAL
+//     pieces, one per lane: one flat loop of mixed additions with XYZZ accumulators in registers, a bucket boundary
+//     inside a piece only flushes the accumulator (PRIMARY / HEAD / TAIL slots).  Points are gathered as 64-byte
+//     affine records.  All field arithmetic is the carry-free 9x29-bit layer (field29.cuh / ec29.cuh).
+//   * a bucket spread over many lanes (repeated scalars: all-ones, all -1) is folded by a separate small kernel.
+//   * per task T = sum B_f and S = sum (f+1) B_f (running sums + 32-lane shuffle scan), then per bucket set
+//     sum_t S_t and sum_c c * D_c; the remaining shifts (2^7, 2^8) and the Horner over the sets run on the host,
+//     where one serial EC chain is 20x faster than on a GPU lane.  The reduce kernels are chains of full
+//     additions issued from one inlined call site each.
+//   * up to 8 commitments over the same bases share every kernel launch (batch dimension), and two commitments
+//     (or batches) may be in flight on two streams with their own scratch: the latency-bound reduction of one
+//     overlaps the accumulation of the next.
+// No MFMA (256-bit modular integers), bound by v_mad_u64_u32 issue; HBM sees the algorithmic 96 B/term plus the
+// per-window gathers (64 B x W per term) from the table.
 #include "ctx.h"
 #include "ec.cuh"
 #include "ec29.cuh"
