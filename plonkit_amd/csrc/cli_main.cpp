@@ -8,10 +8,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <chrono>
 #include <map>
 #include <string>
 #include <vector>
 #include <sys/stat.h>
+#include <unistd.h>
 
 static bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 static bool ends_with(const std::string &s, const char *suf) { size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
@@ -22,6 +24,17 @@ static std::vector<uint8_t> slurp(const std::string &p, const char *what) {
 }
 static void spit(const std::string &p, const uint8_t *d, size_t n) { std::ofstream f(p, std::ios::binary); f.write((const char *)d, (std::streamsize)n); }
 static void die(const char *what, int32_t rc) { fprintf(stderr, "%s: %s (status %d)\n", what, plk_last_error(), rc); exit(101); }   // Rust panic exit code
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static double g_t0 = 0;
+// PLK_CLI_TIMING=1: phase times on stderr (whole-CLI measurement of DESIGN.md §4)
+static void phase(const char *what) {
+    if (!getenv("PLK_CLI_TIMING")) return;
+    double t = now_s();
+    if (g_t0 == 0) g_t0 = t;
+    static double last = 0; if (last == 0) last = t;
+    fprintf(stderr, "[timing] %-28s +%.3f s (%.3f)\n", what, t - last, t - g_t0);
+    last = t;
+}
 #define CK(what, expr) do { int32_t _rc = (expr); if (_rc != PLK_OK) die(what, _rc); } while (0)
 
 struct Args {
@@ -79,7 +92,7 @@ static void load_key(plk_ctx *ctx, const std::string &path, uint8_t g2[256], boo
     else CK("srs upload", plk_srs_upload(ctx, pts.data(), n));
 }
 
-int main(int argc, char **argv) {
+static int run(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "plonkit (MI355X) — subcommands: analyse setup dump-lagrange prove export-verification-key verify\n"); return 2; }
     std::string cmd = argv[1];
     if (cmd == "analyse") {
@@ -148,21 +161,27 @@ int main(int argc, char **argv) {
         Args a = parse(argc, argv, {{"m", "srs_monomial_form"}, {"l", "srs_lagrange_form"}, {"c", "circuit"}, {"w", "witness"},
                                     {"p", "proof"}, {"j", "proofjson"}, {"i", "publicjson"}, {"t", "transcript"}});
         if (a.get("transcript", "keccak") != "keccak") { fprintf(stderr, "not implemented: transcript '%s' (only keccak; rescue needs franklin-crypto)\n", a.get("transcript").c_str()); return 101; }
+        phase("start");
         std::string wf = a.get("witness", "witness.wtns");
         plk_circuit *c = load_circuit(resolve_circuit(a), &wf);
+        phase("load circuit + witness");
         plk_ctx *ctx = open_ctx();
+        phase("plk_create (HIP init)");
         uint8_t g2[256];
         load_key(ctx, a.get("srs_monomial_form"), g2);
+        phase("load key (parse + upload)");
         // a Lagrange-form key (-l) changes how the witness commitments are computed (commit_using_values), never the
         // proof bytes (src/plonk.rs:138-146); an empty or missing option means "monomial only" as in the reference
         if (!a.get("srs_lagrange_form", "").empty()) { uint8_t g2l[256]; load_key(ctx, a.get("srs_lagrange_form"), g2l, true); }
         plk_setup *s = nullptr;
         CK("prepare err", plk_setup_prepare(ctx, c, &s));
+        phase("setup_prepare");
         fprintf(stderr, "Proving...\n");
         std::vector<uint8_t> buf(1 << 16); uint64_t len = 0;
         int32_t rc = plk_prove(ctx, s, c, buf.data(), buf.size(), &len);
         if (rc == PLK_ERR_UNSAT) { fprintf(stderr, "must satisfy: %s\n", plk_last_error()); return 101; }
         if (rc != PLK_OK) die("prove", rc);
+        phase("prove");
         std::string out = a.get("proof", "proof.bin");
         refuse_duplicate(a, out, "proof");
         spit(out, buf.data(), len);
@@ -180,4 +199,13 @@ int main(int argc, char **argv) {
         return 2;
     }
     return 0;
+}
+
+// Every output file is written and closed inside run(); the process then leaves without tearing down the HIP
+// runtime and freeing gigabytes of device memory one buffer at a time (0.25 s at the 2^20 domain) — the
+// driver reclaims everything at exit.
+int main(int argc, char **argv) {
+    int rc = run(argc, argv);
+    fflush(stdout); fflush(stderr);
+    _exit(rc);
 }
