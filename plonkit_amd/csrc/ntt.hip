@@ -6,18 +6,23 @@
 // the coset generator 7 are those of SURVEY.md A.2/A.4.
 //
 // Design (MI355X-first, not a translation of bellman's thread-split FFT):
-//   * n = 2^log_n is factored into p <= 4 digits of <= 9 bits: n = R1*R2*..*Rp (mixed-radix
-//     Cooley-Tukey, "four-step" generalised).  Pass i transforms digit i for every combination of
-//     the other digits; between passes the element (k_i, m) is multiplied by omega_L^(k_i*m).
-//   * A workgroup owns a tile of 2048 elements = R rows x C adjacent columns (C*32 B contiguous
-//     per row, >= 128 B), stages it in LDS as two 16-byte planes (conflict-free ds_read_b128 for
-//     lane-contiguous columns) and runs the log2(R) butterfly stages there: HBM sees exactly one
-//     read and one write of the vector per pass (p = 3 at 2^20..2^27).
-//   * Bit reversal never touches LDS: passes 1..p-1 run DIT and fetch their rows in bit-reversed
-//     order (a row is its own memory segment, so the order is free); the last pass runs DIF on
-//     contiguous rows and scatters whole C-element segments to the digit-reversed output index.
-//   * coset shift (g^i on load), 1/n and g^-i (on store) are fused into the first / last pass;
-//     powers come from two-level tables (base^(lo + 2^14*hi)), one multiply per use.
+//   * n = 2^log_n is factored into p <= 3 digits of <= 10 bits: n = R1*R2*..*Rp (mixed-radix Cooley-Tukey,
+//     "four-step" generalised): two passes up to 2^20, three beyond.  Pass i transforms digit i for every
+//     combination of the other digits; between passes the element (k_i, m) is multiplied by omega_L^(k_i*m).
+//   * A workgroup (512 threads) owns a tile of 2048 elements = R rows x C adjacent columns (C*32 B contiguous
+//     per row), stages it in LDS as 9 x 29-bit limbs in two 16-byte planes and one 4-byte plane, and runs the
+//     log2(R) butterfly stages there two at a time (radix 4 in registers): HBM sees exactly one read and one
+//     write of the vector per pass.
+//   * Every pass is DIT.  Passes 1..p-1 fetch their rows in bit-reversed order (a row is its own memory segment,
+//     so the order is free); the last pass reads contiguous rows, bit-reverses them with its LDS scatter and
+//     writes whole C-element segments to the digit-reversed output index.
+//   * All butterfly arithmetic is the carry-free 9 x 29-bit lazy layer (field29.cuh): data words are re-sliced,
+//     never converted; only the constants (twiddles, coset powers, 1/n) live in its 2^261 domain.
+//   * coset shift (g^i on load), 1/n and g^-i (on store) are fused into the first / last pass; powers come
+//     from two-level tables (base^(lo + 2^14*hi)), one multiply per use — none when the low part is zero
+//     (sub-transforms of <= 2^14 points).  A zero-padded input (LDE) is read in place: indices beyond the
+//     coefficient count are neither loaded nor scaled.  Outputs are made canonical by a quotient-estimate
+//     reduction, not by a product.
 //   * No MFMA: this is 256-bit modular integer arithmetic, bound by v_mad_u64_u32 issue.
 #include "ctx.h"
 #include "ntt.h"
