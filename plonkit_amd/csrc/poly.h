@@ -22,11 +22,17 @@ struct CheckArgs {
 // are stored pre-scaled (2^261: q_a..q_d, q_dnext, sigma_j, L0, the coset points x; 2^266: q_m, which meets a
 // product of two wires) and the host scales the challenges, so that every term lands on 2^256 by itself:
 //   alpha_pp = alpha * 2^281 (meets z * four 2^256 factors), alpha2_w = alpha^2 * 2^261, zh_inv_w = 2^261 / Z_H.
+constexpr uint32_t QUOTIENT_MAX_DIRECT_PI = 8;
 struct QuotientArgs {
     Fr *out;
     const Fr *w[4], *z, *q[7], *sigma[4], *pi, *l0, *x;
     Fr beta, gamma, alpha_pp, alpha2_w, beta_k[4], zh_inv_w[4];
     uint32_t m, log_m;                  // m = 4N
+    // public inputs: PI(x) = sum_i in_i * L_i(x) and L_i(x) = L_0(x / omega^i), i.e. on the coset
+    // PI[j] = sum_i in_i * L0[j - 4i]: with few inputs the kernel forms it from the cached L0 vector and no
+    // PI polynomial is interpolated or extended (pi == nullptr); otherwise pi is its extension.
+    uint32_t num_pi;
+    Fr pi_in[QUOTIENT_MAX_DIRECT_PI];
 };
 int32_t scale_const(Fr *out, const Fr *in, const Fr &c_s, uint32_t n, hipStream_t s);            // out_i = in_i * c (one W-layer product), canonical
 int32_t coset_points_w(Fr *out, const PowTable &tw_w, uint32_t log_m, const Fr &c_s, uint32_t m, hipStream_t s);   // out_i = c * omega_m^i

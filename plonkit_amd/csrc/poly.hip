@@ -179,7 +179,9 @@ __global__ void __launch_bounds__(PT) k_quotient(QuotientArgs a) {
     const FrW9 w01 = mulw(w[0], w[1]);                           // scale 2^251; q_m is stored with 2^266
     const FrW9 f1 = mulsum3w(ldw(a.q[0] + i), w[0], ldw(a.q[1] + i), w[1], ldw(a.q[2] + i), w[2]);
     const FrW9 f2 = mulsum3w(ldw(a.q[3] + i), w[3], ldw(a.q[4] + i), w01, ldw(a.q[6] + i), ldw(a.w[3] + nxt));
-    FrW9 g = addn(addn(f1, f2), addn(ldw(a.q[5] + i), ldw(a.pi + i)));
+    FrW9 g = addn(addn(f1, f2), ldw(a.q[5] + i));
+    if (a.pi) g = addn(g, ldw(a.pi + i));
+    else for (uint32_t k = 0; k < a.num_pi; k++) g = addn(g, mulw(ldw(a.l0 + ((i - 4 * k) & (a.m - 1))), cw(a.pi_in[k])));
     const FrW9 x = ldw(a.x + i), z = ldw(a.z + i), gamma = cw(a.gamma), beta = cw(a.beta);
     FrW9 pa = z, pb = ldw(a.z + nxt);
 #pragma unroll

@@ -375,10 +375,13 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     { const Fr *zp = use_lagrange ? t1 : z_coef; PLK_TRY(commit_begin(ctx, &zp, 1, N, use_lagrange)); }
     // while z is being committed: its extension, the public-input polynomial, and (first proof only) the constant vectors
     PLK_TRY(lde4_dev(ctx, z_coef, log_n, ext[4], st));
-    PLK_HIP(hipMemsetAsync(pi_coef, 0, N * sizeof(Fr), st));
-    if (!inputs.empty()) PLK_HIP(hipMemcpyAsync(pi_coef, inputs.data(), inputs.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
-    PLK_TRY(ntt_dev(ctx, pi_coef, log_n, true, nullptr, st));
-    PLK_TRY(lde4_dev(ctx, pi_coef, log_n, ext[16], st));
+    const bool direct_pi = inputs.size() <= QUOTIENT_MAX_DIRECT_PI;       // few inputs: PI comes from the cached L0 vector inside the quotient kernel
+    if (!direct_pi) {
+        PLK_HIP(hipMemsetAsync(pi_coef, 0, N * sizeof(Fr), st));
+        PLK_HIP(hipMemcpyAsync(pi_coef, inputs.data(), inputs.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
+        PLK_TRY(ntt_dev(ctx, pi_coef, log_n, true, nullptr, st));
+        PLK_TRY(lde4_dev(ctx, pi_coef, log_n, ext[16], st));
+    }
     PLK_TRY(commit_end(ctx, 1, &z_c));
     tr.absorb_g1(z_c);
     const HFr alpha = tr.challenge();
@@ -416,7 +419,9 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
         for (int j = 0; j < 4; j++) { qa.w[j] = ext[j]; qa.sigma[j] = ext[12 + j]; qa.beta_k[j] = to_dev(beta * kk[j]); }
         qa.z = ext[4];
         for (int k = 0; k < 7; k++) qa.q[k] = ext[5 + k];
-        qa.pi = ext[16]; qa.l0 = ext[17]; qa.x = S->lde[12];
+        qa.pi = direct_pi ? nullptr : ext[16]; qa.l0 = ext[17]; qa.x = S->lde[12];
+        qa.num_pi = direct_pi ? (uint32_t)inputs.size() : 0;
+        for (uint32_t k = 0; k < qa.num_pi; k++) qa.pi_in[k] = to_dev(inputs[k]);
         const HFr two5 = HFr::from_u64(1u << 5), two25 = HFr::from_u64(1u << 25);
         qa.beta = to_dev(beta); qa.gamma = to_dev(gamma);
         qa.alpha_pp = to_dev(alpha * two25); qa.alpha2_w = to_dev(alpha * alpha * two5);

@@ -204,3 +204,46 @@ def test_prove_with_lagrange_key_gives_the_same_proof(ctx, log_n):
         setup.prove(circ)
     ctx.srs_lagrange_clear()
     assert setup.prove(circ) == want
+
+
+def _multi_input_circuit(n_pub, n_extra):
+    """x_1 = u*v, x_{i+1} = x_i*u for the public inputs, then a private chain t_{j+1} = t_j*v to fill the domain;
+    every constraint is cA*a * cB*b = cC*c (one gate, inside the pinned transpilation subset)."""
+    u, v = 3, 5
+    wit = [1]
+    pub = [u * v % R_MOD]
+    for _ in range(n_pub - 1):
+        pub.append(pub[-1] * u % R_MOD)
+    wit += pub                                   # wires 1..n_pub
+    iu, iv = len(wit), len(wit) + 1
+    wit += [u, v]
+    cons = [({str(iu): "1"}, {str(iv): "1"}, {"1": "1"})]
+    for i in range(1, n_pub):
+        cons.append(({str(i): "1"}, {str(iu): "1"}, {str(i + 1): "1"}))
+    prev = iv
+    for _ in range(n_extra):
+        wit.append(wit[prev] * v % R_MOD)
+        cons.append(({str(prev): "1"}, {str(iv): "1"}, {str(len(wit) - 1): "1"}))
+        prev = len(wit) - 1
+    r1cs = {"n8": 32, "prime": str(R_MOD), "nVars": len(wit), "nOutputs": 0, "nPubInputs": n_pub, "nPrvInputs": 2,
+            "nLabels": len(wit), "nConstraints": len(cons), "constraints": [list(c) for c in cons]}
+    return json.dumps(r1cs).encode(), json.dumps([str(x) for x in wit]).encode()
+
+
+@pytest.mark.parametrize("n_pub", [3, 8, 11])
+def test_several_public_inputs(ctx, n_pub, golden_crs):
+    """3 and 8 public inputs take the quotient kernel's direct PI path (PI from the cached L0 extension, shifted by
+    4 positions per input), 11 the interpolated-polynomial path; both must give the oracle's proof bytes"""
+    import plonkit_amd as pa
+    r1cs_b, wit_b = _multi_input_circuit(n_pub, 40)
+    circ = pa.Circuit(r1cs_b, True, wit_b, True)
+    r1cs, wit = po.load_r1cs_json(json.loads(r1cs_b)), [int(x) for x in json.loads(wit_b)]
+    ctx.srs_upload(golden_crs.g1)
+    ctx.srs_lagrange_clear()
+    setup = pa.SetupForProver(ctx, circ)
+    S = po.setup(r1cs)
+    proof = setup.prove(circ)
+    assert proof == po.write_proof(po.prove(r1cs, wit, golden_crs, S))
+    vk = setup.verification_key_bytes(golden_crs.g2_raw)
+    assert pa.verify(vk, proof)
+    assert len(po.read_proof(proof).inputs) == n_pub
