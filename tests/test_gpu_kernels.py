@@ -200,3 +200,32 @@ def test_msm_above_2pow20_on_a_fresh_context(log_n):
     assert np.array_equal(c.msm(s), _trapdoor(ol.fr_ints(s)))
     assert np.array_equal(c.msm(s[: n // 2 + 7], base_offset=5), ol.g1_mul(_trapdoor(ol.fr_ints(s[: n // 2 + 7])), pow(42, 5, R_MOD)))
     c.close()
+
+
+def test_two_commitments_in_flight(ctx, srs16):
+    """plk_msm_g1_enqueue_dev / plk_msm_g1_finish are a FIFO of depth two (two scratch sets, two streams): results come
+    back in order and equal the one-at-a-time results; a third enqueue is refused until something is finished;
+    batches and single commitments may alternate."""
+    import torch
+    import plonkit_amd as pa
+    from plonkit_amd.sharded import ShardedMsm
+    ctx.srs_upload(srs16)
+    n = 1 << 16
+    dev = torch.device("cuda:0")
+    vecs = [torch.from_numpy(_rand_fr(n, 500 + k).view(np.int64)).to(dev) for k in range(5)]
+    torch.cuda.synchronize()
+    single = [np.asarray(ctx.msm_dev(v, n)) for v in vecs]
+    ctx.msm_enqueue_dev(vecs[0], n)
+    ctx.msm_enqueue_dev(vecs[1], n)
+    with pytest.raises(pa.PlkError):
+        ctx.msm_enqueue_dev(vecs[2], n)
+    a = pa.g1_sum_jacobian(ctx.msm_finish())
+    ctx.msm_enqueue_dev(vecs[2], n)
+    b = pa.g1_sum_jacobian(ctx.msm_finish())
+    c = pa.g1_sum_jacobian(ctx.msm_finish())
+    assert np.array_equal(a, single[0]) and np.array_equal(b, single[1]) and np.array_equal(c, single[2])
+    with pytest.raises(pa.PlkError):
+        ctx.msm_finish()                                          # nothing in flight
+    got = list(ShardedMsm(ctx, None, dev).commit_stream(iter(vecs), n))
+    assert len(got) == 5 and all(np.array_equal(g, s) for g, s in zip(got, single))
+    assert all(np.array_equal(np.asarray(g), s) for g, s in zip(ctx.msm_batch_dev(vecs, n), single))
