@@ -229,3 +229,39 @@ def test_two_commitments_in_flight(ctx, srs16):
     got = list(ShardedMsm(ctx, None, dev).commit_stream(iter(vecs), n))
     assert len(got) == 5 and all(np.array_equal(g, s) for g, s in zip(got, single))
     assert all(np.array_equal(np.asarray(g), s) for g, s in zip(ctx.msm_batch_dev(vecs, n), single))
+
+
+@pytest.fixture(scope="module")
+def srs19_ctx():
+    import plonkit_amd as pa
+    c = pa.Context(0)
+    c.srs_generate(1 << 19, 0, 42)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("kind", ["ones", "minus_one", "witness_like", "small", "top_bits"])
+def test_msm_17bit_windows_scalar_distributions(srs19_ctx, kind):
+    """the same distributions on the path commitments of >= 2^19 terms take: 15 windows of 17 bits against the 15
+    shifted table copies, one bucket set, hot buckets folded by msm_fold_hot (repeated scalars), unsigned top window
+    (scalars just below r), two commitments (a batch of two) sharing the kernels"""
+    n = 1 << 19
+    rng = random.Random(23)
+    if kind == "ones":
+        ks = [1] * n
+    elif kind == "minus_one":
+        ks = [R_MOD - 1] * n
+    elif kind == "witness_like":
+        ks = [0 if rng.random() < 0.5 else (rng.randrange(1 << 16) if rng.random() < 0.5 else rng.randrange(R_MOD)) for _ in range(n)]
+    elif kind == "small":
+        ks = [rng.randrange(4) for _ in range(n)]
+    else:
+        ks = [R_MOD - 1 - rng.randrange(1 << 20) for _ in range(n)]           # top window at its maximum, carries everywhere
+    s = ol.fr_vec(ks)
+    want = _trapdoor(ks)
+    assert np.array_equal(srs19_ctx.msm(s), want)
+    import torch
+    d = torch.from_numpy(s.view(np.int64)).to("cuda:0")
+    torch.cuda.synchronize()
+    pair = srs19_ctx.msm_batch_dev([d, d], n)
+    assert np.array_equal(np.asarray(pair[0]), want) and np.array_equal(np.asarray(pair[1]), want)
