@@ -35,6 +35,7 @@ constexpr uint32_t POW_TAB = 1u << POW_SPLIT;
 struct PowTable {
     const Fr *lo = nullptr;
     const Fr *hi = nullptr;
+    const uint32_t *hi_sliced = nullptr;     // optional: the hi table as 9 x 29-bit limbs, 48 B per entry (NTT stage twiddles)
 };
 
 // grows-only device buffer

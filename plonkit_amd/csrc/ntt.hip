@@ -77,8 +77,15 @@ struct LdsTile {
 };
 
 // omega_R^i (i < R/2) straight out of the hi table: omega_{2^28}^(i << (28 - log_r)), low part 0
+// (read from the pre-sliced copy of the table: 3 x 16 bytes, no 8x32 -> 9x29 re-slicing — the butterfly kernels
+//  are bound by instruction issue, and the re-slicing was ~7 % of a radix-4 group)
 __device__ __forceinline__ FrW9 small_tw(const PowTable &t, uint32_t i, uint32_t log_r) {
-    return ldw(t.hi + (i << (POW_SPLIT - log_r)));
+    const u32x4 *p = reinterpret_cast<const u32x4 *>(t.hi_sliced) + 3 * (size_t)(i << (POW_SPLIT - log_r));
+    const u32x4 a = p[0], b = p[1], c = p[2];
+    FrW9 r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = c.x;
+    return r;
 }
 
 // log2(R) DIT stages over an LDS tile of R rows x C columns (element (i, c) at i*pitch + c), input rows in
@@ -237,10 +244,19 @@ __global__ void table_to_w(Fr *out, const Fr *in, uint32_t n) {
     if (i < n) store_fp(out + i, pack<FrParams>(csub_p(w_from_s(unpack<FrW>(load_fp(in + i))))));
 }
 
-// allocates [lo | hi] in the external domain followed by [lo | hi] in the W domain
+// the W-domain hi table once more as 9 x 29-bit limbs padded to 48 bytes per entry
+__global__ void table_slice(uint32_t *out, const Fr *in_w, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const FrW9 v = unpack<FrW>(load_fp(in_w + i));
+    for (int k = 0; k < 9; k++) out[12 * (size_t)i + k] = v.l[k];
+    for (int k = 9; k < 12; k++) out[12 * (size_t)i + k] = 0;
+}
+
+// allocates [lo | hi] in the external domain followed by [lo | hi] in the W domain and the sliced W-domain hi table
 static int32_t make_pow_table(plk_ctx *ctx, const Fr &base, PowTable *out, PowTable *out_w, void **alloc_out) {
     Fr *buf = nullptr;
-    PLK_HIP(hipMalloc(&buf, sizeof(Fr) * 4 * POW_TAB));
+    PLK_HIP(hipMalloc(&buf, sizeof(Fr) * 4 * POW_TAB + (size_t)48 * POW_TAB));
     hipLaunchKernelGGL(fill_pow_table, dim3(2 * POW_TAB / 256), dim3(256), 0, ctx->stream, buf, buf + POW_TAB, base);
     hipLaunchKernelGGL(table_to_w, dim3(2 * POW_TAB / 256), dim3(256), 0, ctx->stream, buf + 2 * POW_TAB, (const Fr *)buf, 2 * POW_TAB);
     PLK_HIP(hipGetLastError());
@@ -248,6 +264,10 @@ static int32_t make_pow_table(plk_ctx *ctx, const Fr &base, PowTable *out, PowTa
     out->hi = buf + POW_TAB;
     out_w->lo = buf + 2 * POW_TAB;
     out_w->hi = buf + 3 * POW_TAB;
+    uint32_t *sliced = reinterpret_cast<uint32_t *>(buf + 4 * POW_TAB);
+    hipLaunchKernelGGL(table_slice, dim3(POW_TAB / 256), dim3(256), 0, ctx->stream, sliced, (const Fr *)(buf + 3 * POW_TAB), POW_TAB);
+    PLK_HIP(hipGetLastError());
+    out_w->hi_sliced = sliced;
     if (alloc_out) *alloc_out = buf;
     return PLK_OK;
 }
