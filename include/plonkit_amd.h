@@ -99,6 +99,17 @@ int32_t plk_g1_intt(plk_ctx *ctx, const plk_g1_affine *in_host, uint32_t log_n, 
 /* same, from the first 2^log_n points of the resident SRS into a device buffer (64 B per point) */
 int32_t plk_g1_intt_srs_dev(plk_ctx *ctx, uint32_t log_n, void *out_dev, void *stream);
 
+/* ---- multi-GPU commitments inside plk_prove / plk_setup_write_vk (the MSM shards, everything else
+ *      is replicated).  One process per GPU; rank r keeps only the SRS points [first_index, first_index + plk_srs_size)
+ *      resident (plk_srs_upload of its slice, or plk_srs_generate(ctx, n, first_index, tau)), computes every
+ *      commitment over that index range and hands the `count` (<= 8) Jacobian partial sums to `combine`, which must
+ *      replace them in place by the sums over all ranks — an all_gather of 96 bytes per commitment over RCCL and a
+ *      host EC sum (plonkit_amd/sharded.py: ShardedProver); EC addition is not an RCCL reduction op.  All ranks then
+ *      hold the same commitments, derive the same challenges and produce the same proof bytes as a single GPU.
+ *      combine == NULL switches back to single-GPU commitments.  A Lagrange-form key, if used, is sliced the same way. */
+typedef int32_t (*plk_combine_fn)(void *user, plk_g1_jacobian *sums, uint32_t count);
+int32_t plk_set_commit_shard(plk_ctx *ctx, uint64_t first_index, plk_combine_fn combine, void *user);
+
 /* ---- Lagrange-form key: Crs<E, CrsForLagrangeForm> (L_i(tau)*G, i < N), the optional `-l` key of `plonkit prove`
  *      (src/bin/main.rs:384-391; src/plonk.rs:138-146: with it, prove() commits the witness and grand-product
  *      polynomials from their evaluations — commit_using_values — instead of their coefficients).  A second resident

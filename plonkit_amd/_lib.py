@@ -5,6 +5,7 @@ pointers (ints / torch tensors).  Nothing here computes: every function forwards
 a missing library or a missing GPU raises — there is no Python or CPU fallback.
 """
 import ctypes
+import sys
 import os
 
 import numpy as np
@@ -115,6 +116,25 @@ class Context:
 
     def srs_size(self):
         return lib().plk_srs_size(self._h)
+
+    # multi-GPU commitments of the prover: this rank's SRS slice starts at global index `first_index`; `combine`
+    # receives a writable uint64[count, 12] array of Jacobian partial sums and must replace it by the all-ranks sums
+    def set_commit_shard(self, first_index, combine):
+        if combine is None:
+            self._combine_cb = None
+            _check(lib().plk_set_commit_shard(self._h, ctypes.c_uint64(0), None, None))
+            return
+        proto = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32)
+
+        def trampoline(_user, ptr, count):
+            try:
+                combine(np.ctypeslib.as_array(ptr, shape=(count, 12)))
+                return 0
+            except Exception as exc:                                  # never let an exception cross the C boundary
+                sys.stderr.write("commit combiner failed: %r\n" % (exc,))
+                return 4
+        self._combine_cb = proto(trampoline)                          # keep the callback object alive
+        _check(lib().plk_set_commit_shard(self._h, ctypes.c_uint64(first_index), self._combine_cb, None))
 
     # Lagrange-form key (`prove -l`): second resident SRS used by prove() for commit_using_values
     def srs_lagrange_upload(self, bases):

@@ -96,6 +96,11 @@ struct plk_ctx {
     size_t pinned2_cap = 0;
     std::vector<double> timings;
     bool ev_on = false;                      // record the per-slot event bracket around msm_accumulate
+    // multi-GPU commitments of the prover (plk_set_commit_shard): global index of the first resident SRS point and
+    // the caller's all-ranks combiner for the Jacobian partial sums
+    uint64_t shard_first = 0;
+    plk_combine_fn combine = nullptr;
+    void *combine_user = nullptr;
 };
 
 namespace plk {

@@ -34,40 +34,44 @@ static HFr host_omega(uint32_t log_n) {
     HFr h; memcpy(h.l, w.l, 32); return h;
 }
 
-// KZG commitment of N coefficients resident on the device
-static int32_t commit(plk_ctx *ctx, const Fr *coef, uint64_t n, HAffine *out) {
-    PLK_TRY(msm_enqueue(ctx, coef, n, 0, ctx->stream));
-    HJac j;
-    PLK_TRY(msm_finish(ctx, ctx->stream, &j));
-    *out = jac_to_affine(j);
-    return PLK_OK;
-}
-
-// several commitments over the same SRS prefix in one pass of the MSM kernels.  lagrange = commit_using_values:
-// the vectors are evaluations over the domain and the bases the resident Lagrange-form key (same group element).
-static int32_t commit_many(plk_ctx *ctx, const Fr *const *coefs, uint32_t count, uint64_t n, HAffine *out, bool lagrange = false) {
-    SrsSlotSwap active(ctx, lagrange);
-    for (uint32_t done = 0; done < count;) {
-        uint32_t b = count - done > 8 ? 8 : count - done;
-        PLK_TRY(msm_enqueue_batch(ctx, coefs + done, b, n, 0, ctx->stream));
-        HJac j[8];
-        PLK_TRY(msm_finish_batch(ctx, ctx->stream, j));
-        for (uint32_t k = 0; k < b; k++) out[done + k] = jac_to_affine(j[k]);
-        done += b;
-    }
-    return PLK_OK;
-}
-
-// split form: the commitment's kernels run on their own stream (msm.hip, MsmSlot), so independent work issued on
-// ctx->stream between begin and end fills the SIMDs that the bucket-reduction phase leaves idle
+// KZG commitments of vectors resident on the device: up to 8 over the same SRS prefix share one pass of the MSM
+// kernels.  lagrange = commit_using_values: the vectors are evaluations over the domain and the bases the resident
+// Lagrange-form key (same group element).
+//
+// Split form: the commitment's kernels run on their own stream (msm.hip, MsmSlot), so independent work issued on
+// ctx->stream between begin and end fills the SIMDs that the bucket-reduction phase leaves idle.
+//
+// Multi-GPU (plk_set_commit_shard): this rank holds the SRS points [first, first + srs_n) only, commits that index
+// range of every vector and hands the Jacobian partial sums to the caller's combiner (all_gather + EC sum over RCCL).
 static int32_t commit_begin(plk_ctx *ctx, const Fr *const *vecs, uint32_t count, uint64_t n, bool lagrange = false) {
     SrsSlotSwap active(ctx, lagrange);
-    return msm_enqueue_batch(ctx, vecs, count, n, 0, ctx->stream);
+    if (!ctx->combine) return msm_enqueue_batch(ctx, vecs, count, n, 0, ctx->stream);
+    const uint64_t lo = ctx->shard_first < n ? ctx->shard_first : n;
+    const uint64_t hi = ctx->shard_first + ctx->srs_n < n ? ctx->shard_first + ctx->srs_n : n;
+    const Fr *shifted[8];
+    for (uint32_t k = 0; k < count; k++) shifted[k] = vecs[k] + lo;
+    return msm_enqueue_batch(ctx, shifted, count, hi > lo ? hi - lo : 0, 0, ctx->stream);
 }
 static int32_t commit_end(plk_ctx *ctx, uint32_t count, HAffine *out) {
     HJac j[8];
     PLK_TRY(msm_finish_batch(ctx, nullptr, j));
+    if (ctx->combine) {
+        plk_g1_jacobian raw[8];
+        for (uint32_t k = 0; k < count; k++) { memcpy(raw[k].x, j[k].x.l, 32); memcpy(raw[k].y, j[k].y.l, 32); memcpy(raw[k].z, j[k].z.l, 32); }
+        const int32_t rc = ctx->combine(ctx->combine_user, raw, count);
+        if (rc != PLK_OK) { set_error("commitment combiner (plk_set_commit_shard) failed"); return rc; }
+        for (uint32_t k = 0; k < count; k++) { memcpy(j[k].x.l, raw[k].x, 32); memcpy(j[k].y.l, raw[k].y, 32); memcpy(j[k].z.l, raw[k].z, 32); }
+    }
     for (uint32_t k = 0; k < count; k++) out[k] = jac_to_affine(j[k]);
+    return PLK_OK;
+}
+static int32_t commit_many(plk_ctx *ctx, const Fr *const *coefs, uint32_t count, uint64_t n, HAffine *out, bool lagrange = false) {
+    for (uint32_t done = 0; done < count;) {
+        uint32_t b = count - done > 8 ? 8 : count - done;
+        PLK_TRY(commit_begin(ctx, coefs + done, b, n, lagrange));
+        PLK_TRY(commit_end(ctx, b, out + done));
+        done += b;
+    }
     return PLK_OK;
 }
 
@@ -248,7 +252,7 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     if (!ctx || !S || !c || !proof_out || !len) { set_error("plk_prove: bad argument"); return PLK_ERR_ARG; }
     if (!c->has_witness) { set_error("plk_prove: circuit has no witness"); return PLK_ERR_ARG; }
     PLK_HIP(hipSetDevice(ctx->device));
-    if (!ctx->srs || ctx->srs_n < S->N) { set_error("SRS too small for this circuit"); return PLK_ERR_SRS; }
+    if (!ctx->srs || (!ctx->combine && ctx->srs_n < S->N)) { set_error("SRS too small for this circuit"); return PLK_ERR_SRS; }
     ctx->timings.clear();
     double t_prev = now_ms();
     auto lap = [&]() { double t = now_ms(); ctx->timings.push_back(t - t_prev); t_prev = t; };
@@ -340,7 +344,7 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     // with a Lagrange-form key of the domain's size resident (`prove -l`, src/plonk.rs:138-146) the witness and
     // grand-product polynomials are committed from their evaluations, as bellman's prove() does; same proof bytes
     const bool use_lagrange = ctx->lag.pts != nullptr;
-    if (use_lagrange && ctx->lag.n != N) { set_error("Lagrange-form key has a different size than the circuit's domain"); return PLK_ERR_SRS; }
+    if (use_lagrange && (ctx->combine ? ctx->lag.n != ctx->srs_n : ctx->lag.n != N)) { set_error("Lagrange-form key has a different size than the circuit's domain"); return PLK_ERR_SRS; }
     HAffine wire_c[4];
     PLK_TRY(commit_begin(ctx, use_lagrange ? w_vals : w_coef, 4, N, use_lagrange));
     for (int j = 0; j < 4; j++) PLK_TRY(lde4_dev(ctx, w_coef[j], log_n, ext[j], st));      // round-3 work that needs no challenge

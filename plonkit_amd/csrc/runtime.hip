@@ -151,6 +151,14 @@ int32_t plk_srs_set_dev(plk_ctx *ctx, const void *bases_dev, uint64_t n) {
 
 uint64_t plk_srs_size(const plk_ctx *ctx) { return ctx ? ctx->srs_n : 0; }
 
+int32_t plk_set_commit_shard(plk_ctx *ctx, uint64_t first_index, plk_combine_fn combine, void *user) {
+    if (!ctx) { set_error("plk_set_commit_shard: bad argument"); return PLK_ERR_ARG; }
+    ctx->shard_first = combine ? first_index : 0;
+    ctx->combine = combine;
+    ctx->combine_user = user;
+    return PLK_OK;
+}
+
 // Lagrange-form key (Crs<E, CrsForLagrangeForm>): second resident SRS, see include/plonkit_amd.h
 int32_t plk_srs_lagrange_upload(plk_ctx *ctx, const plk_g1_affine *bases, uint64_t n) {
     if (!ctx || !bases || n == 0) { set_error("plk_srs_lagrange_upload: bad argument"); return PLK_ERR_ARG; }

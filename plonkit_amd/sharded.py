@@ -58,3 +58,53 @@ class ShardedMsm:
                 self.ctx.msm_enqueue_dev(cur, n, base_offset, stream=stream)   # k reduces its buckets and is exchanged
             partial = self.ctx.msm_finish()                    # waits for commitment k, host Horner over the windows
             yield combine_partials(partial, self.dist, self.device)
+
+
+# Montgomery form of 1 in Fq (R mod q): the Z coordinate of an affine point written back as Jacobian
+_FQ_ONE = np.array([0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f], dtype=np.uint64)
+
+
+class ShardedProver:
+    """Multi-GPU prove: one process per GPU, the SRS split into contiguous slices, NTTs and
+    point-wise work replicated, every commitment of plk_prove / make_verification_key computed as the sum over ranks of
+    MSM(slice of the scalars, slice of the SRS).  Installs the combiner of plk_set_commit_shard: one all_gather of
+    96 bytes per commitment (a batch of up to 8 per call) and a host EC sum.  Every rank ends with the same proof bytes
+    as a single GPU would produce.
+
+        sp = ShardedProver(ctx, dist, device, n_total)      # ctx holds SRS points [first, first + local) only
+        setup = SetupForProver(ctx, circuit); proof = setup.prove(circuit)
+    """
+
+    def __init__(self, ctx, dist, device=None, first_index=None, n_local=None):
+        self.ctx, self.dist, self.device = ctx, dist, device
+        rank = dist.get_rank() if dist is not None else 0
+        n_local = ctx.srs_size() if n_local is None else n_local
+        self.first = rank * n_local if first_index is None else first_index
+        ctx.set_commit_shard(self.first, self._combine)
+
+    def close(self):
+        self.ctx.set_commit_shard(0, None)
+
+    def _combine(self, sums):
+        """sums: uint64[count, 12] (this rank's partial sums) -> overwritten with the sums over all ranks"""
+        count = sums.shape[0]
+        if self.dist is None or self.dist.get_world_size() == 1:
+            parts = sums.reshape(1, count, 12).copy()
+        else:
+            world = self.dist.get_world_size()
+            t = torch.from_numpy(sums.view(np.int64).copy())
+            if self.device is not None:
+                t = t.to(self.device)
+            out = torch.empty((world, count, 12), dtype=torch.int64, device=t.device)
+            if t.device.type != "cpu" and hasattr(self.dist, "all_gather_into_tensor"):
+                self.dist.all_gather_into_tensor(out, t)
+            else:
+                self.dist.all_gather(list(out.unbind(0)), t)
+            parts = out.cpu().numpy().view(np.uint64)
+        for k in range(count):
+            a = _lib.g1_sum_jacobian(np.ascontiguousarray(parts[:, k, :]))
+            if not a.any():
+                sums[k, :] = 0                                         # infinity: Z = 0
+            else:
+                sums[k, 0:8] = a
+                sums[k, 8:12] = _FQ_ONE
