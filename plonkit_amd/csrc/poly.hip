@@ -149,6 +149,29 @@ int32_t scan(plk_ctx *ctx, Fr *out, const Fr *in, uint32_t n, bool mult, bool re
     return PLK_OK;
 }
 
+// ------------------------------------------------------------------- witness temporaries
+struct DevWitnessTerm { uint32_t var, pad; uint32_t coeff[8]; };      // == circuit.h WitnessTerm (uint32 + HFr, 8-byte aligned)
+struct DevWitnessOp { uint32_t first, count; uint32_t constant[8]; }; // == circuit.h WitnessOp
+__device__ __forceinline__ Fr fr_of(const uint32_t *w) { Fr r; for (int i = 0; i < 8; i++) r.l[i] = w[i]; return r; }
+static_assert(sizeof(DevWitnessTerm) == 40 && sizeof(DevWitnessOp) == 40, "layout of the uploaded records");
+__global__ void __launch_bounds__(PT) k_eval_witness_ops(Fr *values, const DevWitnessOp *ops, const DevWitnessTerm *terms, uint32_t n_ops, uint32_t first_tmp) {
+    uint32_t i = blockIdx.x * PT + threadIdx.x;
+    if (i >= n_ops) return;
+    const uint32_t first = ops[i].first, count = ops[i].count;
+    Fr acc = fr_of(ops[i].constant);
+    for (uint32_t k = 0; k < count; k++) {
+        const uint32_t var = terms[first + k].var;
+        if (var) acc = add(acc, mul(fr_of(terms[first + k].coeff), load_fp(values + var)));      // id 0 is the dummy (zero)
+    }
+    store_fp(values + first_tmp + i, acc);
+}
+int32_t eval_witness_ops(Fr *values, const void *ops_dev, const void *terms_dev, uint32_t n_ops, uint32_t first_tmp, hipStream_t s) {
+    if (!n_ops) return PLK_OK;
+    hipLaunchKernelGGL(k_eval_witness_ops, dim3((n_ops + PT - 1) / PT), dim3(PT), 0, s, values, (const DevWitnessOp *)ops_dev, (const DevWitnessTerm *)terms_dev, n_ops, first_tmp);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+
 // ----------------------------------------------------------------------------- quotient
 __device__ __forceinline__ FrW9 ldw(const Fr *p) { return unpack<FrW>(load_fp(p)); }
 __device__ __forceinline__ FrW9 cw(const Fr &c) { return unpack<FrW>(c); }

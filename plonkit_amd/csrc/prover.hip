@@ -102,6 +102,7 @@ struct plk_setup {
     uint64_t num_circuit_vars = 0;         // circom wires; temporaries follow
     std::vector<plk::WitnessOp> ops;       // linear forms defining the transpiler's temporaries
     bool ops_independent = false;          // no temporary reads another temporary -> order-free evaluation
+    plk::DevBuf ops_dev, terms_dev;        // the same records on the device (only when ops_independent): evaluated there
     std::vector<plk::WitnessTerm> op_terms;
 };
 
@@ -114,7 +115,7 @@ void plk_circuit_unregister(plk_circuit *c) {
 extern "C" {
 
 uint64_t plk_setup_domain_size(const plk_setup *s) { return s ? s->N : 0; }
-void plk_setup_free(plk_setup *s) { if (s) { s->store.release(); s->lde_store.release(); delete s; } }
+void plk_setup_free(plk_setup *s) { if (s) { s->store.release(); s->lde_store.release(); s->ops_dev.release(); s->terms_dev.release(); delete s; } }
 
 int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
     if (!ctx || !c || !out) { set_error("plk_setup_prepare: bad argument"); return PLK_ERR_ARG; }
@@ -135,6 +136,17 @@ int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
     S->ops.swap(T.ops); S->op_terms.swap(T.op_terms);
     S->ops_independent = true;
     for (const WitnessTerm &t : S->op_terms) if (t.var >= c->r1cs.num_variables) { S->ops_independent = false; break; }
+    static_assert(sizeof(WitnessOp) == 40 && sizeof(WitnessTerm) == 40, "records are uploaded as they are (poly.hip)");
+    if (S->ops_independent && !S->ops.empty()) {                     // temporaries will be evaluated on the device
+        int32_t rc2 = S->ops_dev.reserve(S->ops.size() * sizeof(WitnessOp));
+        if (rc2 == PLK_OK) rc2 = S->terms_dev.reserve(S->op_terms.size() * sizeof(WitnessTerm) + 8);
+        if (rc2 != PLK_OK) { delete S; return rc2; }
+        if (hipMemcpy(S->ops_dev.p, S->ops.data(), S->ops.size() * sizeof(WitnessOp), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(S->terms_dev.p, S->op_terms.data(), S->op_terms.size() * sizeof(WitnessTerm), hipMemcpyHostToDevice) != hipSuccess) {
+            S->ops_dev.release(); S->terms_dev.release(); delete S;
+            return hip_fail(hipGetLastError(), "H2D witness ops", __FILE__, __LINE__);
+        }
+    }
     std::vector<Gate> rows;
     rows.reserve(S->n_real);
     for (uint64_t i = 1; i <= S->num_inputs; i++) {                 // one gate per public input, first rows, q_a = -1
@@ -269,10 +281,11 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
         if (hipHostRegister((void *)c->witness.data(), c->witness.size() * sizeof(HFr), hipHostRegisterDefault) == hipSuccess) c->witness_registered = true;
         else (void)hipGetLastError();                                        // not fatal: the copy is just slower
     }
-    PLK_TRY(ensure_pinned2(ctx, (n_tmp + 1) * sizeof(HFr)));
+    const bool tmp_on_device = S->ops_independent && (S->ops_dev.p || S->ops.empty());
+    PLK_TRY(ensure_pinned2(ctx, (tmp_on_device ? 1 : n_tmp + 1) * sizeof(HFr)));
     HFr *tmp_vals = reinterpret_cast<HFr *>(ctx->pinned2);
     const HFr *wit = c->witness.data();
-    {
+    if (!tmp_on_device) {
         const size_t n_ops = S->ops.size();
         auto value_of = [&](uint32_t v) -> HFr { return v == 0 ? HFr::zero() : (v < ncv ? wit[v] : tmp_vals[v - ncv]); };
         auto eval_range = [&](size_t lo, size_t hi) {
@@ -320,7 +333,8 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     uint32_t *d_flag = A.take<uint32_t>(64);
     PLK_HIP(hipMemcpyAsync(d_values, wit, ncv * sizeof(Fr), hipMemcpyHostToDevice, st));
     PLK_HIP(hipMemsetAsync(d_values, 0, sizeof(Fr), st));
-    if (n_tmp) PLK_HIP(hipMemcpyAsync(d_values + ncv, tmp_vals, n_tmp * sizeof(Fr), hipMemcpyHostToDevice, st));
+    if (n_tmp && tmp_on_device) PLK_TRY(eval_witness_ops(d_values, S->ops_dev.p, S->terms_dev.p, (uint32_t)S->ops.size(), (uint32_t)ncv, st));
+    else if (n_tmp) PLK_HIP(hipMemcpyAsync(d_values + ncv, tmp_vals, n_tmp * sizeof(Fr), hipMemcpyHostToDevice, st));
     std::vector<HFr> inputs(wit + 1, wit + 1 + S->num_inputs);
     {   // is_satisfied_using_one_shot_check (src/plonk.rs:137) on the device
         CheckArgs ca;

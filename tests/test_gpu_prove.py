@@ -247,3 +247,32 @@ def test_several_public_inputs(ctx, n_pub, golden_crs):
     vk = setup.verification_key_bytes(golden_crs.g2_raw)
     assert pa.verify(vk, proof)
     assert len(po.read_proof(proof).inputs) == n_pub
+
+
+def test_long_linear_combinations_take_the_host_witness_path(ctx, golden_crs):
+    """constraints whose linear combinations need chains of temporaries (a temporary defined from another one):
+    the prover then evaluates the temporaries on the host in allocation order instead of in the device kernel.
+    Transpilation of such constraints is unpinned, so parity is with the oracle and soundness with
+    the host verifier."""
+    import plonkit_amd as pa
+    rng = po.Xoshiro256ss(7)
+    wit = [1, 0] + [rng.fr() for _ in range(12)]
+    lc = [(i, rng.fr()) for i in range(2, 12)]
+    s = sum(c * wit[i] for i, c in lc) % R_MOD
+    wit.append(s * wit[13] % R_MOD)
+    wit[1] = wit[-1]
+    cons = [(lc + [(0, 5)], [(13, 1)], [(14, 1), (13, 5)]), ([(1, 1)], [(0, 1)], [(14, 1)]),
+            ([(3, 1), (0, R_MOD - 1)], [(3, 1), (0, 2)], [(15, 1)])]
+    wit.append((wit[3] - 1) * (wit[3] + 2) % R_MOD)
+    r1cs = po.R1CS(2, len(wit) - 2, len(wit), cons)
+    as_json = {"n8": 32, "prime": str(R_MOD), "nVars": len(wit), "nOutputs": 0, "nPubInputs": 1, "nPrvInputs": len(wit) - 2,
+               "nLabels": len(wit), "nConstraints": len(cons),
+               "constraints": [[{str(i): str(c) for i, c in lcx} for lcx in con] for con in cons]}
+    circ = pa.Circuit(json.dumps(as_json).encode(), True, json.dumps([str(x) for x in wit]).encode(), True)
+    ctx.srs_upload(golden_crs.g1)
+    ctx.srs_lagrange_clear()
+    setup = pa.SetupForProver(ctx, circ)
+    S = po.setup(po.load_r1cs_json(as_json))
+    proof = setup.prove(circ)
+    assert proof == po.write_proof(po.prove(po.load_r1cs_json(as_json), wit, golden_crs, S))
+    assert pa.verify(setup.verification_key_bytes(golden_crs.g2_raw), proof)
