@@ -106,6 +106,7 @@ void plk_destroy(plk_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+    for (auto &S : ctx->slot) if (S.stream) (void)hipStreamSynchronize(S.stream);     // commitments still in flight
     for (void *p : ctx->coset_allocs) (void)hipFree(p);
     ctx->tables.release(); ctx->ntt_scratch.release(); ctx->srs_own.release(); ctx->srs_w.release(); ctx->lag.own.release(); ctx->lag.w.release();
     for (auto &S : ctx->slot) {
@@ -125,6 +126,7 @@ void plk_destroy(plk_ctx *ctx) {
 int32_t plk_synchronize(plk_ctx *ctx) {
     if (!ctx) { set_error("null ctx"); return PLK_ERR_ARG; }
     PLK_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &S : ctx->slot) if (S.stream) PLK_HIP(hipStreamSynchronize(S.stream));
     return PLK_OK;
 }
 
