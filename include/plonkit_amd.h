@@ -74,7 +74,9 @@ int32_t plk_lde4(plk_ctx *ctx, const plk_fr *coeffs_host, uint32_t log_n, plk_fr
 int32_t plk_lde4_dev(plk_ctx *ctx, const void *coeffs_dev, uint32_t log_n, void *out_4n_dev, void *stream);
 
 /* ---- kate_commitment::commit_using_monomials -> multiexp::dense_multiexp (src/plonk.rs:122-124 and
- *      the 11 commitments of prove): sum_i scalars[i] * srs[base_offset + i], scalars Montgomery Fr. */
+ *      the 11 commitments of prove): sum_i scalars[i] * srs[base_offset + i], scalars Montgomery Fr.
+ *      One pass of the kernels takes up to 2^24 terms; plk_msm_g1, _dev and _partial_dev (and plk_prove) cut longer
+ *      vectors into successive pieces themselves, the _batch_dev and _enqueue_dev entry points return PLK_ERR_SIZE. */
 int32_t plk_msm_g1(plk_ctx *ctx, const plk_fr *scalars_host, uint64_t n, uint64_t base_offset, plk_g1_affine *out);
 int32_t plk_msm_g1_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, plk_g1_affine *out, void *stream);
 /* `count` commitments of equal length against the same bases in one pass of the kernels (the 4 wire /

@@ -9,6 +9,7 @@
 #include <map>
 #include "../../include/plonkit_amd.h"
 #include "field.cuh"
+#include "hostmath.h"
 
 namespace plk {
 
@@ -101,6 +102,7 @@ struct plk_ctx {
     uint64_t shard_first = 0;
     plk_combine_fn combine = nullptr;
     void *combine_user = nullptr;
+    std::vector<plk::host::HJac> commit_pieces;   // partial sums of a commitment longer than one MSM call (prover.hip)
 };
 
 namespace plk {

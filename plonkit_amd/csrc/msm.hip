@@ -623,7 +623,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     hipStream_t stream = S.stream;
     if (!ctx->srs) { set_error("msm: no SRS uploaded (plk_srs_upload)"); return PLK_ERR_SRS; }
     if (base_offset + n > ctx->srs_n) { set_error("msm: SRS too small for this commitment"); return PLK_ERR_SRS; }
-    if (n >= (1ull << 24) + 1) { set_error("msm: more than 2^24 terms per call (shard the commitment)"); return PLK_ERR_SIZE; }
+    if (n >= (1ull << 24) + 1) { set_error("msm: more than 2^24 terms in one pass (plk_msm_g1 / plk_msm_g1_dev / plk_prove split longer commitments; the enqueue and batch entry points do not)"); return PLK_ERR_SIZE; }
     if (batch < 1 || batch > MSM_MAX_BATCH) { set_error("msm: batch must be 1..8"); return PLK_ERR_ARG; }
     // resident table of the SRS in the 2^261 domain of the lazy field layer; large commitments use its shifted copies
     uint32_t nbits = 1;
@@ -794,8 +794,21 @@ int32_t plk_msm_g1_finish(plk_ctx *ctx, plk_g1_jacobian *out) {
 }
 
 int32_t plk_msm_g1_partial_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, plk_g1_jacobian *out, void *stream) {
-    PLK_TRY(plk_msm_g1_enqueue_dev(ctx, scalars_dev, n, base_offset, stream));
-    return plk_msm_g1_finish(ctx, out);
+    constexpr uint64_t PIECE = 1ull << 24;                    // one pass of the kernels takes at most 2^24 terms
+    if (n <= PIECE) {
+        PLK_TRY(plk_msm_g1_enqueue_dev(ctx, scalars_dev, n, base_offset, stream));
+        return plk_msm_g1_finish(ctx, out);
+    }
+    if (!ctx || !scalars_dev || !out) { set_error("plk_msm_g1: bad argument"); return PLK_ERR_ARG; }
+    host::HJac acc = host::HJac::inf();
+    for (uint64_t off = 0; off < n; off += PIECE) {           // longer commitments: successive SRS ranges, summed on the host
+        host::HJac j;
+        PLK_TRY(msm_enqueue(ctx, (const Fr *)scalars_dev + off, n - off < PIECE ? n - off : PIECE, base_offset + off, stream ? (hipStream_t)stream : ctx->stream));
+        PLK_TRY(msm_finish(ctx, nullptr, &j));
+        acc = host::jac_add(acc, j);
+    }
+    memcpy(out->x, acc.x.l, 32); memcpy(out->y, acc.y.l, 32); memcpy(out->z, acc.z.l, 32);
+    return PLK_OK;
 }
 
 int32_t plk_msm_g1_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, plk_g1_affine *out, void *stream) {

@@ -43,18 +43,43 @@ static HFr host_omega(uint32_t log_n) {
 //
 // Multi-GPU (plk_set_commit_shard): this rank holds the SRS points [first, first + srs_n) only, commits that index
 // range of every vector and hands the Jacobian partial sums to the caller's combiner (all_gather + EC sum over RCCL).
+// One MSM call takes at most 2^24 terms (24-bit index field of a bucket entry): longer vectors (domains 2^25, 2^26 —
+// SETUP_MAX_POW2 of the reference is 26) are committed in pieces against successive SRS ranges, summed on the host.
+static uint64_t msm_piece_terms() {
+    static const uint64_t v = [] { const char *e = getenv("PLK_MSM_MAX_TERMS"); uint64_t x = e ? strtoull(e, nullptr, 10) : 0; return x >= 4096 && x <= (1ull << 24) ? x : (1ull << 24); }();
+    return v;                                                 // (the environment override exists for the tests)
+}
 static int32_t commit_begin(plk_ctx *ctx, const Fr *const *vecs, uint32_t count, uint64_t n, bool lagrange = false) {
     SrsSlotSwap active(ctx, lagrange);
-    if (!ctx->combine) return msm_enqueue_batch(ctx, vecs, count, n, 0, ctx->stream);
-    const uint64_t lo = ctx->shard_first < n ? ctx->shard_first : n;
-    const uint64_t hi = ctx->shard_first + ctx->srs_n < n ? ctx->shard_first + ctx->srs_n : n;
+    uint64_t lo = 0, hi = n;
+    if (ctx->combine) {
+        lo = ctx->shard_first < n ? ctx->shard_first : n;
+        hi = ctx->shard_first + ctx->srs_n < n ? ctx->shard_first + ctx->srs_n : n;
+        if (hi < lo) hi = lo;
+    }
+    const uint64_t first_base = ctx->combine ? 0 : lo, piece = msm_piece_terms();
+    ctx->commit_pieces.clear();
     const Fr *shifted[8];
-    for (uint32_t k = 0; k < count; k++) shifted[k] = vecs[k] + lo;
-    return msm_enqueue_batch(ctx, shifted, count, hi > lo ? hi - lo : 0, 0, ctx->stream);
+    // all pieces but the last are finished here; the last one stays in flight so that the caller can overlap it
+    for (uint64_t off = 0;; off += piece) {
+        const uint64_t len = hi - lo - off < piece ? hi - lo - off : piece;
+        for (uint32_t k = 0; k < count; k++) shifted[k] = vecs[k] + lo + off;
+        PLK_TRY(msm_enqueue_batch(ctx, shifted, count, len, first_base + off, ctx->stream));
+        if (off + len >= hi - lo) break;
+        HJac j[8];
+        PLK_TRY(msm_finish_batch(ctx, nullptr, j));
+        if (ctx->commit_pieces.empty()) ctx->commit_pieces.assign(j, j + count);
+        else for (uint32_t k = 0; k < count; k++) ctx->commit_pieces[k] = jac_add(ctx->commit_pieces[k], j[k]);
+    }
+    return PLK_OK;
 }
 static int32_t commit_end(plk_ctx *ctx, uint32_t count, HAffine *out) {
     HJac j[8];
     PLK_TRY(msm_finish_batch(ctx, nullptr, j));
+    if (!ctx->commit_pieces.empty()) {
+        for (uint32_t k = 0; k < count; k++) j[k] = jac_add(j[k], ctx->commit_pieces[k]);
+        ctx->commit_pieces.clear();
+    }
     if (ctx->combine) {
         plk_g1_jacobian raw[8];
         for (uint32_t k = 0; k < count; k++) { memcpy(raw[k].x, j[k].x.l, 32); memcpy(raw[k].y, j[k].y.l, 32); memcpy(raw[k].z, j[k].z.l, 32); }

@@ -276,3 +276,26 @@ def test_long_linear_combinations_take_the_host_witness_path(ctx, golden_crs):
     proof = setup.prove(circ)
     assert proof == po.write_proof(po.prove(po.load_r1cs_json(as_json), wit, golden_crs, S))
     assert pa.verify(setup.verification_key_bytes(golden_crs.g2_raw), proof)
+
+
+def test_commitments_longer_than_one_msm_call(ctx):
+    """domains above 2^24 (the reference allows 2^26) are committed in pieces of at most 2^24 terms against successive
+    SRS ranges; with PLK_MSM_MAX_TERMS=4096 the same code path cuts a 2^14-term commitment into four pieces — same
+    verification key and proof bytes as the one-piece run (the override is read once per process, hence the subprocess)"""
+    import subprocess
+    import sys
+    import plonkit_amd as pa
+    n = 1 << 14
+    circ = pa.Circuit.synthetic(n - 2)
+    ctx.srs_generate(n, 0, 42)
+    ctx.srs_lagrange_clear()
+    setup = pa.SetupForProver(ctx, circ)
+    want = setup.verification_key_bytes(pa.crs42_g2_bytes()).hex() + setup.prove(circ).hex()
+    code = ("import sys; sys.path.insert(0, %r); import plonkit_amd as pa; c = pa.Context(0); c.srs_generate(%d, 0, 42); "
+            "k = pa.Circuit.synthetic(%d); s = pa.SetupForProver(c, k); "
+            "print(s.verification_key_bytes(pa.crs42_g2_bytes()).hex() + s.prove(k).hex())") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n, n - 2)
+    env = dict(os.environ, PLK_MSM_MAX_TERMS="4096")
+    got = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert got.returncode == 0, got.stderr[-2000:]
+    assert got.stdout.strip().splitlines()[-1] == want
