@@ -42,7 +42,7 @@ def kernel_table(ctx, device):
     g = torch.Generator(device=device)
     g.manual_seed(1)
     with torch.cuda.stream(st):
-        for log_n in (20, 22, 24):
+        for log_n in (20, 22, 24, 26):                      # 2^24 / 2^26: the shapes of the recursive prover
             n = 1 << log_n
             t = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device=device, generator=g)
             t[:, 3] &= (1 << 60) - 1
@@ -70,4 +70,22 @@ def kernel_table(ctx, device):
         e1.synchronize()
         ms = e0.elapsed_time(e1) / 5
         out["lde4_2^20"] = {"ms": round(ms, 4), "algorithmic_GBs": round(160 * n / ms / 1e6, 1), "hbm_frac": round(160 * n / ms / 1e6 / 8000.0, 4)}
+        del c, o
+    # one 2^24-term commitment (config 5; SRS of 2^24 points generated on the GPU, its 15-copy table is 15 GiB)
+    import time
+    keep = ctx.srs_size()
+    n = 1 << 24
+    ctx.srs_generate(n, 0, 42)
+    s = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device=device, generator=g)
+    s[:, 3] &= (1 << 60) - 1
+    torch.cuda.synchronize()
+    ctx.msm_dev(s, n); ctx.msm_dev(s, n)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ctx.msm_dev(s, n)
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    out["msm_2^24"] = {"ms": round(ms, 3), "Mscalar_mul_s": round(n / ms / 1e3, 1), "algorithmic_GBs": round(96 * n / ms / 1e6, 1)}
+    del s
+    if keep:
+        ctx.srs_generate(keep, 0, 42)
     return out
