@@ -2,64 +2,126 @@
 //   Crs::<Bn256, CrsForLagrangeForm>::from_powers(&mono, n.next_power_of_two(), &Worker)
 //   (src/plonk.rs:179-185; driven from src/bin/main.rs:360-381).
 // in[j] = tau^j * G  ->  out[i] = L_i(tau) * G, the Lagrange-basis SRS of the size-N domain.
-// Radix-2 DIT over group elements: a butterfly is (A, B) -> (A + w*B, A - w*B) where w*B is a full
-// 254-bit scalar multiplication, so the kernel is bound by v_mad_u64_u32 issue (about 4000 modular
-// multiplications per butterfly) and HBM traffic (128 B XYZZ per point per stage) is negligible;
-// one lane per butterfly, XYZZ coordinates between stages, a single Fermat inversion per point at
-// the end.  1/N is folded into the bit-reversing load pass.
+// Radix-2 DIT over group elements: a butterfly is (A, B) -> (A + w*B, A - w*B) where w*B is a full 254-bit scalar
+// multiplication, so the kernel is bound by v_mad_u64_u32 issue and HBM traffic (144 B per point per stage) is
+// negligible.  One lane per butterfly, XYZZ coordinates on the 9 x 29-bit layer between stages, a single Fermat
+// inversion per point at the end; 1/N is folded into the bit-reversing load pass.
+//
+// Scalar multiplication on a SIMT machine: with double-and-add (or any sparse recoding) some lane of the wave has a
+// non-zero digit at nearly every bit, so the whole wave pays one addition per bit.  Fixed signed 3-bit windows make
+// all lanes add at the same 85 positions: 255 doublings + 85 additions per multiplication (3500 products instead of
+// 5800 at wave level); the window table {1,2,3,4}*B of every lane lives in LDS, limb-major (conflict-free).
 #include "ctx.h"
 #include "ec.cuh"
+#include "ec29.cuh"
 #include "ntt.h"
 
 namespace plk {
 
+constexpr int G1NTT_THREADS = 256;
+constexpr int G1NTT_TABLE = 4;                                     // |digit| <= 4
+constexpr size_t G1NTT_LDS = (size_t)G1NTT_TABLE * 36 * G1NTT_THREADS * sizeof(uint32_t);   // 147456 B: one workgroup per CU
+
 __device__ __forceinline__ uint32_t brev32(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
-// k * p, k canonical (non-Montgomery) 8x32 limbs, MSB-first double-and-add
-__device__ __noinline__ G1Xyzz xyzz_mul_scalar(const G1Xyzz &p, const Fr &k) {
-    G1Xyzz acc = xyzz_identity();
-    if (is_inf(p)) return acc;
-    int top = 253;
-    while (top >= 0 && !((k.l[top >> 5] >> (top & 31)) & 1)) top--;
-    for (int bit = top; bit >= 0; bit--) {
-        acc = xyzz_double(acc);
-        if ((k.l[bit >> 5] >> (bit & 31)) & 1) xyzz_add(acc, p);
+// rarely executed additions / doublings go through one out-of-line copy each (code size); the loop has its own inlined sites
+__device__ __noinline__ void g1_add_call(XyzzW *a, const XyzzW *b) { XyzzW t = *a; xyzzw_add(t, *b); *a = t; }
+__device__ __noinline__ void g1_double_call(XyzzW *a) { XyzzW t = *a; *a = xyzzw_double(t); }
+
+__device__ __forceinline__ void lds_put(uint32_t *tab, int e, const XyzzW &p) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&p);
+#pragma unroll
+    for (int k = 0; k < 36; k++) tab[(e * 36 + k) * G1NTT_THREADS + threadIdx.x] = w[k];
+}
+__device__ __forceinline__ XyzzW lds_get(const uint32_t *tab, int e) {
+    XyzzW p;
+    uint32_t *w = reinterpret_cast<uint32_t *>(&p);
+#pragma unroll
+    for (int k = 0; k < 36; k++) w[k] = tab[(e * 36 + k) * G1NTT_THREADS + threadIdx.x];
+    return p;
+}
+
+// k * b for a canonical (non-Montgomery) scalar k < 2^254.  Signed 3-bit windows, digits in [-3, 4], low to high:
+// v = window + carry; v <= 4 -> digit v; v >= 5 -> digit v - 8, carry 1 (the top window holds <= 3, so no carry leaves it).
+__device__ __forceinline__ XyzzW g1_mul_scalar(const XyzzW &b, const Fr &k, uint32_t *tab) {
+    if (is_inf(b)) return xyzzw_identity();
+    {   // table: b, 2b, 3b, 4b
+        XyzzW t = b, t2 = b;
+        lds_put(tab, 0, t);
+        g1_double_call(&t2);
+        lds_put(tab, 1, t2);
+        t = t2; g1_add_call(&t, &b);
+        lds_put(tab, 2, t);
+        g1_double_call(&t2);
+        lds_put(tab, 3, t2);
+    }
+    uint32_t dig[11];                                             // 85 digits x 4 bits: bit 3 = negative, bits 0-2 = magnitude
+#pragma unroll
+    for (int i = 0; i < 11; i++) dig[i] = 0;
+    uint32_t carry = 0;
+    for (int w = 0; w < 85; w++) {
+        const uint32_t pos = 3 * w, limb = pos >> 5, off = pos & 31;
+        uint64_t two = k.l[limb];
+        if (limb + 1 < 8) two |= (uint64_t)k.l[limb + 1] << 32;
+        uint32_t v = ((uint32_t)(two >> off) & 7u) + carry;
+        uint32_t code;
+        if (v >= 5) { code = 8u | (8u - v); carry = 1; } else { code = v; carry = 0; }
+        dig[w >> 3] |= code << (4 * (w & 7));
+    }
+    XyzzW acc = xyzzw_identity();
+    for (int w = 84; w >= 0; w--) {
+        for (int r = 0; r < 3; r++) acc = xyzzw_double(acc);      // one inlined doubling site (identity passes through)
+        const uint32_t code = (dig[w >> 3] >> (4 * (w & 7))) & 15u, mag = code & 7u;
+        XyzzW t = xyzzw_identity();
+        if (mag) {
+            t = lds_get(tab, (int)mag - 1);
+            if (code & 8u) t.y = sub6(w_zero<FqW>(), t.y);         // 6p - y: y < 6p by the bounds of ec29.cuh
+        }
+        xyzzw_add(acc, t);                                        // the one inlined addition site (identity operand: no-op)
     }
     return acc;
 }
 
-// pts[bitrev(i)] = n_inv * in[i]
-__global__ void __launch_bounds__(256) g1ntt_load(G1Xyzz *pts, const G1Affine *in, uint32_t log_n, Fr n_inv_canon) {
+// pts[bitrev(i)] = n_inv * in[i]   (in: affine, external form; pts: XYZZ on the 29-bit layer)
+__global__ void __launch_bounds__(G1NTT_THREADS, 1) g1ntt_load(XyzzW *pts, const G1Affine *in, uint32_t log_n, Fr n_inv_canon) {
+    extern __shared__ uint32_t g1tab[];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (1u << log_n)) return;
-    G1Xyzz p = xyzz_from_affine(load_affine(in + i));
-    store_xyzz(pts + brev32(i, log_n), xyzz_mul_scalar(p, n_inv_canon));
+    const G1Affine a = load_affine(in + i);
+    XyzzW p = xyzzw_identity();
+    if (!is_inf(a)) {
+        p.x = csub_p(w_from_s(unpack<FqW>(a.x))); p.y = csub_p(w_from_s(unpack<FqW>(a.y)));
+        p.zz = w_one<FqW>(); p.zzz = w_one<FqW>();
+    }
+    store_xyzzw(pts + brev32(i, log_n), g1_mul_scalar(p, n_inv_canon, g1tab));
 }
 
 // one DIT stage with half-size h = 2^s
-__global__ void __launch_bounds__(256) g1ntt_stage(G1Xyzz *pts, uint32_t log_n, uint32_t s, PowTable tw_inv) {
+__global__ void __launch_bounds__(G1NTT_THREADS, 1) g1ntt_stage(XyzzW *pts, uint32_t log_n, uint32_t s, PowTable tw_inv) {
+    extern __shared__ uint32_t g1tab[];
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= (1u << (log_n - 1))) return;
     uint32_t h = 1u << s, jl = j & (h - 1);
     uint32_t i0 = ((j >> s) << (s + 1)) | jl, i1 = i0 + h;
-    G1Xyzz a = load_xyzz(pts + i0), b = load_xyzz(pts + i1);
+    XyzzW a = load_xyzzw(pts + i0), b = load_xyzzw(pts + i1);
     if (jl) {
         // omega_N^-(jl * N / 2h)
         uint32_t e = (jl << (log_n - s - 1)) << (MAX_LOG_N - log_n);
         Fr w = mul(load_fp(tw_inv.lo + (e & (POW_TAB - 1))), load_fp(tw_inv.hi + (e >> POW_SPLIT)));
-        b = xyzz_mul_scalar(b, to_canonical(w));
+        b = g1_mul_scalar(b, to_canonical(w), g1tab);
     }
-    G1Xyzz lo = a, nb = xyzz_neg(b);
-    xyzz_add(lo, b);
-    xyzz_add(a, nb);
-    store_xyzz(pts + i0, lo);
-    store_xyzz(pts + i1, a);
+    XyzzW lo = a, nb = b;
+    nb.y = sub6(w_zero<FqW>(), b.y);
+    g1_add_call(&lo, &b);
+    g1_add_call(&a, &nb);
+    store_xyzzw(pts + i0, lo);
+    store_xyzzw(pts + i1, a);
 }
 
-__global__ void __launch_bounds__(256) g1ntt_to_affine(G1Affine *out, const G1Xyzz *pts, uint32_t n) {
+__global__ void __launch_bounds__(256) g1ntt_to_affine(G1Affine *out, const XyzzW *pts, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    G1Xyzz p = load_xyzz(pts + i);
+    G1Xyzz p = xyzzw_export(load_xyzzw(pts + i));                // back to the external form (canonical, R = 2^256)
     G1Affine a;
     if (is_inf(p)) { a.x = Fq::zero(); a.y = Fq::zero(); }
     else {
@@ -75,13 +137,19 @@ int32_t g1_intt_dev(plk_ctx *ctx, const G1Affine *in, uint32_t log_n, G1Affine *
     if (log_n > 26) { set_error("g1_intt: size exceeds 2^26"); return PLK_ERR_SIZE; }
     PLK_TRY(ntt_init_tables(ctx));
     const uint32_t n = 1u << log_n;
-    PLK_TRY(ctx->slot[0].c.reserve((size_t)n * sizeof(G1Xyzz)));
-    G1Xyzz *pts = ctx->slot[0].c.as<G1Xyzz>();
+    PLK_TRY(ctx->slot[0].c.reserve((size_t)n * sizeof(XyzzW)));
+    XyzzW *pts = ctx->slot[0].c.as<XyzzW>();
     Fr n_inv = to_canonical(ctx->n_inv[log_n]);
-    hipLaunchKernelGGL(g1ntt_load, dim3((n + 255) / 256), dim3(256), 0, st, pts, in, log_n, n_inv);
+    static bool attr_set = false;
+    if (!attr_set) {
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_load), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(g1ntt_load, dim3((n + G1NTT_THREADS - 1) / G1NTT_THREADS), dim3(G1NTT_THREADS), G1NTT_LDS, st, pts, in, log_n, n_inv);
     for (uint32_t s = 0; s < log_n; s++)
-        hipLaunchKernelGGL(g1ntt_stage, dim3((n / 2 + 255) / 256), dim3(256), 0, st, pts, log_n, s, ctx->tw_inv);
-    hipLaunchKernelGGL(g1ntt_to_affine, dim3((n + 255) / 256), dim3(256), 0, st, out, (const G1Xyzz *)pts, n);
+        hipLaunchKernelGGL(g1ntt_stage, dim3((n / 2 + G1NTT_THREADS - 1) / G1NTT_THREADS), dim3(G1NTT_THREADS), G1NTT_LDS, st, pts, log_n, s, ctx->tw_inv);
+    hipLaunchKernelGGL(g1ntt_to_affine, dim3((n + 255) / 256), dim3(256), 0, st, out, (const XyzzW *)pts, n);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
 }
