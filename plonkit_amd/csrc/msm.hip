@@ -241,9 +241,12 @@ __global__ void __launch_bounds__(256) srs_shift_kernel(const G1Affine *prev, G1
     if (i >= n) return;
     const G1Affine p = load_affine(prev + i);
     G1Xyzz r = xyzz_identity();
-    if (!is_inf(p)) {
-        r = xyzz_double_affine(p);
-        for (uint32_t k = 1; k < COPY_SHIFT; k++) r = xyzz_double(r);
+    if (!is_inf(p)) {                                         // COPY_SHIFT doublings on the 29-bit layer, one inlined site
+        XyzzW a;
+        a.x = csub_p(w_from_s(unpack<FqW>(p.x))); a.y = csub_p(w_from_s(unpack<FqW>(p.y)));
+        a.zz = w_one<FqW>(); a.zzz = w_one<FqW>();
+        for (uint32_t k = 0; k < COPY_SHIFT; k++) a = xyzzw_double(a);
+        r = xyzzw_export(a);
     }
     store_xyzz(out + i, r);
 }
