@@ -594,9 +594,12 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_naive(const G1Affine *bases, 
 // ------------------------------------------------------------------------------ host side
 // Window widths are chosen among those whose top window still has many bits (254 = 19*13 + 7 = 16*15 + 14 = 15*16 + 14):
 // a top window of 1-2 bits would put every term into two or three buckets of a single bin.
-static uint32_t pick_window_bits(uint64_t n) {
+static uint32_t pick_window_bits(uint64_t n, bool have_table) {
+    // with the table of shifted copies every size is best served by 17-bit windows and one bucket set (measured
+    // against 13/15-bit windows without it: 2^12 0.50 vs 0.64 ms, 2^14 0.58 vs 0.95, 2^16 0.62 vs 0.98, 2^18 0.87 vs 1.12)
+    if (have_table) return COPY_SHIFT;
     if (n < (1u << 17)) return 13;
-    if (n < (1u << 19)) return 15;                            // measured: 2^18 1.27 ms (c=15) vs 1.40 ms (c=16)
+    if (n < (1u << 19)) return 15;
     return 17;                                                // 15 windows; 2^16 buckets = 512 coarse bins x 128
 }
 
@@ -631,7 +634,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     // resident table of the SRS in the 2^261 domain of the lazy field layer; large commitments use its shifted copies
     uint32_t nbits = 1;
     while ((1ull << nbits) < n) nbits++;
-    const uint32_t c_bits = n >= 4096 ? pick_window_bits(n) : 0;
+    const uint32_t c_bits = n >= 4096 ? pick_window_bits(n, table_copies_for(ctx->srs_n) > 1) : 0;
     uint32_t copies = 1;
     if (c_bits == COPY_SHIFT) {
         copies = table_copies_for(ctx->srs_n);
