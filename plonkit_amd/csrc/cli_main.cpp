@@ -17,10 +17,21 @@
 
 static bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 static bool ends_with(const std::string &s, const char *suf) { size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
-static std::vector<uint8_t> slurp(const std::string &p, const char *what) {
-    std::ifstream f(p, std::ios::binary);
+static std::vector<uint8_t> slurp(const std::string &p, const char *what) {           // one read() of the whole file
+    FILE *f = fopen(p.c_str(), "rb");
     if (!f) { fprintf(stderr, "%s: cannot open %s\n", what, p.c_str()); exit(101); }
-    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    std::vector<uint8_t> data;
+    struct stat st;
+    if (fstat(fileno(f), &st) == 0 && st.st_size > 0) {
+        data.resize((size_t)st.st_size);
+        size_t got = fread(data.data(), 1, data.size(), f);
+        data.resize(got);
+    } else {                                                                            // not a regular file: stream it
+        uint8_t buf[1 << 16];
+        for (size_t got; (got = fread(buf, 1, sizeof buf, f)) > 0;) data.insert(data.end(), buf, buf + got);
+    }
+    fclose(f);
+    return data;
 }
 static void spit(const std::string &p, const uint8_t *d, size_t n) { std::ofstream f(p, std::ios::binary); f.write((const char *)d, (std::streamsize)n); }
 static void die(const char *what, int32_t rc) { fprintf(stderr, "%s: %s (status %d)\n", what, plk_last_error(), rc); exit(101); }   // Rust panic exit code

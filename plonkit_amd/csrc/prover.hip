@@ -146,8 +146,12 @@ int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
     if (!ctx || !c || !out) { set_error("plk_setup_prepare: bad argument"); return PLK_ERR_ARG; }
     *out = nullptr;
     PLK_HIP(hipSetDevice(ctx->device));
+    const bool timing = getenv("PLK_CLI_TIMING") != nullptr;     // phase times of the setup on stderr (tools/cli_scale.sh)
+    double t_last = now_ms();
+    auto mark = [&](const char *what) { if (timing) { double t = now_ms(); fprintf(stderr, "[timing]   setup: %-22s +%.3f s\n", what, (t - t_last) / 1e3); t_last = t; } };
     Transpiled T;
     if (!transpile(c->r1cs, nullptr, &T)) return PLK_ERR_UNSAT;
+    mark("transpile");
     plk_setup *S = new plk_setup();
     S->num_inputs = c->r1cs.num_inputs - 1;
     S->num_gates = T.gates.size();
@@ -183,6 +187,7 @@ int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
     rows.insert(rows.end(), T.gates.begin(), T.gates.end());
     std::vector<Gate>().swap(T.gates);
 
+    mark("rows");
     Arena A{&S->store};
     size_t total = 22 * ((N * sizeof(Fr) + 255) & ~(size_t)255) + 4 * ((N * 4 + 255) & ~(size_t)255);
     int32_t rc = S->store.reserve(total);
@@ -206,6 +211,7 @@ int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
             if ((rc = ntt_dev(ctx, S->sel_coef[k], log_n, true, nullptr, st)) != PLK_OK) return fail(rc);
         }
     }
+    mark("selectors (7 iNTT)");
     // wire -> variable index table and the permutation (rotate-left over each variable's occurrences)
     {
         std::vector<uint32_t> vars(N);
@@ -243,6 +249,7 @@ int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
         }
     }
     if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
+    mark("permutation (4 iNTT)");
     *out = S;
     return PLK_OK;
 }
