@@ -146,7 +146,9 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        import datetime
+        # a rank that fails must not leave the others waiting for the default 10 minutes in a collective
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=180))
 
     import plonkit_amd as pa
     from plonkit_amd.sharded import ShardedMsm
