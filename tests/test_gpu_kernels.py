@@ -265,3 +265,14 @@ def test_msm_17bit_windows_scalar_distributions(srs19_ctx, kind):
     torch.cuda.synchronize()
     pair = srs19_ctx.msm_batch_dev([d, d], n)
     assert np.array_equal(np.asarray(pair[0]), want) and np.array_equal(np.asarray(pair[1]), want)
+
+
+def test_msm_differential_fuzz():
+    """tools/msm_fuzz.py: random lengths (1 .. 2^17 - 3, around the 4096 threshold), SRS offsets, batch sizes, scalar
+    distributions and call styles (single, batched, two in flight) against the tau = 42 trapdoor answer"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "msm_fuzz.py"), "24", "11"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "mismatches: 0" in r.stdout
