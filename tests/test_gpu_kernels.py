@@ -2,6 +2,7 @@
 
 Covers the reference's kernels on this path: Polynomial::{fft,ifft,coset_fft,icoset_fft}, coset_lde(4)
 and commit_using_monomials/dense_multiexp (call sites src/plonk.rs:104,122-124,132-176)."""
+import os
 import random
 
 import numpy as np
