@@ -299,3 +299,14 @@ def test_commitments_longer_than_one_msm_call(ctx):
     got = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert got.returncode == 0, got.stderr[-2000:]
     assert got.stdout.strip().splitlines()[-1] == want
+
+
+def test_prove_differential_fuzz():
+    """tools/prove_fuzz.py: random synthetic circuits (1 .. 2000 constraints, random seeds): verification key and proof
+    bytes equal the oracle's and the host verifier accepts"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "prove_fuzz.py"), "12", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "mismatches: 0" in r.stdout
