@@ -375,7 +375,7 @@ bool transpile(const R1cs &r, const std::vector<HFr> *witness, Transpiled *out) 
                 else { B.lc_as_gates(cl, cc, true, &cv, &ccoef); uint32_t v[4] = {av, bv, cv, 0}; q[2] = -ccoef; B.gate(v, q); }
             }
         }
-        out->stats.push_back({std::to_string(idx), (uint64_t)(out->gates.size() - g0)});
+        if (out->collect_stats) out->stats.push_back({std::to_string(idx), (uint64_t)(out->gates.size() - g0)});
         out->num_hints++;
     }
     return true;

@@ -44,7 +44,8 @@ struct WitnessOp { uint32_t first, count; HFr constant; };
 struct Transpiled {
     std::vector<Gate> gates;            // without the public-input gates
     std::vector<HFr> values;            // per variable id; empty when there is no witness
-    std::vector<ConstraintStat> stats;
+    std::vector<ConstraintStat> stats;  // per-constraint gate counts (plonk::analyse); skipped when collect_stats is false
+    bool collect_stats = true;
     uint64_t num_hints = 0;
     uint64_t num_vars = 0;              // including temporaries
     std::vector<WitnessOp> ops;         // one per temporary, in allocation order

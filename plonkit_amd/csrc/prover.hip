@@ -150,6 +150,7 @@ int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
     double t_last = now_ms();
     auto mark = [&](const char *what) { if (timing) { double t = now_ms(); fprintf(stderr, "[timing]   setup: %-22s +%.3f s\n", what, (t - t_last) / 1e3); t_last = t; } };
     Transpiled T;
+    T.collect_stats = false;                                     // a million std::string names are only wanted by `analyse`
     if (!transpile(c->r1cs, nullptr, &T)) return PLK_ERR_UNSAT;
     mark("transpile");
     plk_setup *S = new plk_setup();
@@ -176,17 +177,16 @@ int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
             return hip_fail(hipGetLastError(), "H2D witness ops", __FILE__, __LINE__);
         }
     }
-    std::vector<Gate> rows;
-    rows.reserve(S->n_real);
-    for (uint64_t i = 1; i <= S->num_inputs; i++) {                 // one gate per public input, first rows, q_a = -1
+    // rows of the trace: one gate per public input first (q_a = -1), then the transpiler's gates — viewed in place
+    std::vector<Gate> input_rows;
+    for (uint64_t i = 1; i <= S->num_inputs; i++) {
         Gate g; g.v[0] = (uint32_t)i; g.v[1] = g.v[2] = g.v[3] = 0;
         for (int k = 0; k < 7; k++) g.q[k] = HFr::zero();
         g.q[0] = -HFr::one();
-        rows.push_back(g);
+        input_rows.push_back(g);
     }
-    rows.insert(rows.end(), T.gates.begin(), T.gates.end());
-    std::vector<Gate>().swap(T.gates);
-
+    const size_t n_in = input_rows.size(), n_rows = n_in + T.gates.size();
+    auto row = [&](uint64_t r) -> const Gate & { return r < n_in ? input_rows[r] : T.gates[r - n_in]; };
     mark("rows");
     Arena A{&S->store};
     size_t total = 22 * ((N * sizeof(Fr) + 255) & ~(size_t)255) + 4 * ((N * 4 + 255) & ~(size_t)255);
@@ -204,7 +204,7 @@ int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
     {
         std::vector<HFr> col(N);
         for (int k = 0; k < 7; k++) {
-            for (uint64_t r = 0; r < N; r++) col[r] = r < rows.size() ? rows[r].q[k] : HFr::zero();
+            for (uint64_t r = 0; r < N; r++) col[r] = r < n_rows ? row(r).q[k] : HFr::zero();
             if (hipMemcpyAsync(S->sel_vals[k], col.data(), N * sizeof(Fr), hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D selector", __FILE__, __LINE__));
             if (hipMemcpyAsync(S->sel_coef[k], S->sel_vals[k], N * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "D2D selector", __FILE__, __LINE__));
             if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
@@ -216,16 +216,16 @@ int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
     {
         std::vector<uint32_t> vars(N);
         for (int j = 0; j < 4; j++) {
-            for (uint64_t r = 0; r < N; r++) vars[r] = r < rows.size() ? rows[r].v[j] : 0;
+            for (uint64_t r = 0; r < N; r++) vars[r] = r < n_rows ? row(r).v[j] : 0;
             if (hipMemcpyAsync(S->gate_vars[j], vars.data(), N * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D vars", __FILE__, __LINE__));
             if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
         }
         std::vector<uint32_t> cnt(T.num_vars + 1, 0);
-        for (const Gate &g : rows) for (int j = 0; j < 4; j++) if (g.v[j]) cnt[g.v[j] + 1]++;
+        for (uint64_t r = 0; r < n_rows; r++) { const Gate &g = row(r); for (int j = 0; j < 4; j++) if (g.v[j]) cnt[g.v[j] + 1]++; }
         for (size_t v = 1; v < cnt.size(); v++) cnt[v] += cnt[v - 1];              // cnt[v] = start of v's list
         std::vector<uint32_t> pos(cnt.back()), fill(cnt.begin(), cnt.end() - 1);
-        for (uint64_t r = 0; r < rows.size(); r++)
-            for (int j = 0; j < 4; j++) { uint32_t v = rows[r].v[j]; if (v) pos[fill[v]++] = ((uint32_t)j << 30) | (uint32_t)r; }
+        for (uint64_t r = 0; r < n_rows; r++)
+            for (int j = 0; j < 4; j++) { uint32_t v = row(r).v[j]; if (v) pos[fill[v]++] = ((uint32_t)j << 30) | (uint32_t)r; }
         std::vector<uint32_t> sig((size_t)4 * N);
         for (int j = 0; j < 4; j++) for (uint64_t r = 0; r < N; r++) sig[(size_t)j * N + r] = ((uint32_t)j << 30) | (uint32_t)r;
         for (size_t v = 1; v < T.num_vars; v++) {
