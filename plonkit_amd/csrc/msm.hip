@@ -96,8 +96,9 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_digits(ScalarSet set, MsmPara
 // histogram in LDS -> global.  SCATTER: the chunk's entries are counting-sorted by coarse bin inside LDS,
 // one global reservation per (block, bin), then every bin's run is copied out contiguously — full
 // 64-256 B bursts instead of 4-byte scattered stores (the first version wrote 13x its payload to HBM).
+constexpr int PART_THREADS = 1024;                 // partition workgroups: 16 waves hide the LDS-atomic latency (2^20-term commitment, back to back: 1.53 ms with 256 threads, 1.48 with 512, 1.45 with 1024)
 template <bool SCATTER>
-__global__ void __launch_bounds__(MSM_THREADS) msm_partition(const int32_t *digits, MsmParams p, uint32_t *hist_or_cursor,
+__global__ void __launch_bounds__(PART_THREADS) msm_partition(const int32_t *digits, MsmParams p, uint32_t *hist_or_cursor,
                                                               const uint32_t *bin_start, uint32_t *entries) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *lcnt = reinterpret_cast<uint32_t *>(smem);               // [nbins]
@@ -111,15 +112,15 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_partition(const int32_t *digi
     const uint32_t w = gw % p.windows, set = (gw / p.windows) * p.groups + w % p.groups;    // bucket set of this window
     const uint32_t copy_tag = (w / p.groups) << p.nbits;                                     // which table copy its points come from
     hist_or_cursor += set * p.nbins;
-    for (uint32_t b = tid; b < p.nbins; b += MSM_THREADS) lcnt[b] = 0;
+    for (uint32_t b = tid; b < p.nbins; b += PART_THREADS) lcnt[b] = 0;
     __syncthreads();
-    for (uint32_t i = first + tid; i < last; i += MSM_THREADS) {
+    for (uint32_t i = first + tid; i < last; i += PART_THREADS) {
         int32_t d = dg[i];
         if (d) { uint32_t mg = (uint32_t)(d < 0 ? -d : d) - 1; atomicAdd(&lcnt[mg >> FINE_BITS], 1u); }
     }
     __syncthreads();
     if (!SCATTER) {
-        for (uint32_t b = tid; b < p.nbins; b += MSM_THREADS) if (lcnt[b]) atomicAdd(&hist_or_cursor[b], lcnt[b]);
+        for (uint32_t b = tid; b < p.nbins; b += PART_THREADS) if (lcnt[b]) atomicAdd(&hist_or_cursor[b], lcnt[b]);
         return;
     }
     bin_start += set * p.nbins;
@@ -133,13 +134,13 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_partition(const int32_t *digi
         if (tid == 63) lstart[p.nbins] = v;
     }
     __syncthreads();
-    for (uint32_t b = tid; b < p.nbins; b += MSM_THREADS) {
+    for (uint32_t b = tid; b < p.nbins; b += PART_THREADS) {
         uint32_t cnt = lcnt[b];
         gbase[b] = cnt ? bin_start[b] + atomicAdd(&hist_or_cursor[b], cnt) : 0;
         lcnt[b] = 0;                                                   // reused as the in-bin cursor
     }
     __syncthreads();
-    for (uint32_t i = first + tid; i < last; i += MSM_THREADS) {
+    for (uint32_t i = first + tid; i < last; i += PART_THREADS) {
         int32_t d = dg[i];
         if (d) {
             uint32_t mg = (uint32_t)(d < 0 ? -d : d) - 1, bin = mg >> FINE_BITS;
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_partition(const int32_t *digi
     }
     __syncthreads();
     const uint32_t wave = tid >> 6, lane = tid & 63;
-    for (uint32_t b = wave; b < p.nbins; b += MSM_THREADS / 64) {
+    for (uint32_t b = wave; b < p.nbins; b += PART_THREADS / 64) {
         const uint32_t s0 = lstart[b], len = lstart[b + 1] - s0, g0 = gbase[b];
         for (uint32_t k = lane; k < len; k += 64) entries[g0 + k] = staged[s0 + k];
     }
@@ -700,9 +701,9 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(msm_partition<false>, dim3(pblocks, total_windows), dim3(MSM_THREADS), plds_count, stream, (const int32_t *)digits, p, hist, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(msm_partition<false>, dim3(pblocks, total_windows), dim3(PART_THREADS), plds_count, stream, (const int32_t *)digits, p, hist, (const uint32_t *)nullptr, (uint32_t *)nullptr);
     hipLaunchKernelGGL(msm_scan_bins, dim3(1), dim3(1024), 0, stream, hist, bin_start, task_start, total_bins);
-    hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks, total_windows), dim3(MSM_THREADS), plds_scatter, stream, (const int32_t *)digits, p, hist, (const uint32_t *)bin_start, entries);
+    hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks, total_windows), dim3(PART_THREADS), plds_scatter, stream, (const int32_t *)digits, p, hist, (const uint32_t *)bin_start, entries);
     if (ctx->ev_on) PLK_HIP(hipEventRecord(S.ev[0], stream));
     hipLaunchKernelGGL(msm_accumulate, dim3(max_tasks), dim3(MSM_THREADS), CHUNK * sizeof(uint32_t), stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
                        (const uint32_t *)task_start, partials, task_meta, p);
