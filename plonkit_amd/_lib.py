@@ -273,9 +273,15 @@ class Circuit:
 
     def analyse(self):
         """plonk::analyse (src/plonk.rs:72-93) as the serde_json string of src/tests.rs:14"""
-        buf = ctypes.create_string_buffer(1 << 20)
-        _check(lib().plk_circuit_analyse(self._h, buf, ctypes.c_uint64(len(buf))))
-        return buf.value.decode()
+        size = 1 << 20
+        while True:                                                   # ~40 bytes per constraint: grow until it fits
+            buf = ctypes.create_string_buffer(size)
+            rc = lib().plk_circuit_analyse(self._h, buf, ctypes.c_uint64(size))
+            if rc == 0:
+                return buf.value.decode()
+            if size >= (1 << 31) or "too small" not in last_error():
+                _check(rc)
+            size <<= 3
 
     def close(self):
         if self._h:
