@@ -170,3 +170,17 @@ def test_cli_analyse_and_flag_surface(golden_dir, tmp_path):
     assert subprocess.call([cli, "setup", "-p", "10"], stderr=subprocess.DEVNULL) == 2
     assert subprocess.call([cli, "prove", "--bogus", "1"], stderr=subprocess.DEVNULL) == 2
     assert subprocess.call([cli, "frobnicate"], stderr=subprocess.DEVNULL) == 2
+
+
+def test_synthetic_circuit_generator_is_stable():
+    """the bench / test circuits (xoshiro256** seeded "plonkit", alternating 1-gate and 2-gate constraints)
+    are pinned by the hash of their exported .r1cs / .wtns bytes: speed-ups of the generator must not change them"""
+    import hashlib
+    import plonkit_amd as pa
+    want = {10: ("c1191a9442e55454", "a850a41ba6eaf55c"), 1000: ("4a6613f2f4da1a8a", "268bb47514331dc6"),
+            (1 << 16) - 2: ("3e937a93121ddf50", "8d3846310dbc619f")}
+    for n, (h_r1cs, h_wtns) in want.items():
+        c = pa.Circuit.synthetic(n)
+        assert hashlib.sha1(c.export("r1cs")).hexdigest()[:16] == h_r1cs, n
+        assert hashlib.sha1(c.export("wtns")).hexdigest()[:16] == h_wtns, n
+        c.close()
