@@ -641,7 +641,8 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
         copies = table_copies_for(ctx->srs_n);
         PLK_TRY(ensure_base_table(ctx, copies, stream));
         while (copies > 1 && (MAX_COPIES % copies != 0 || ((uint64_t)copies << nbits) > (1ull << 24))) copies--;   // a divisor of 15 that fits the 24-bit (copy, index) field of an entry
-        { const char *e = getenv("PLK_MSM_COPIES"); if (e && atoi(e) >= 1 && (uint32_t)atoi(e) <= copies && MAX_COPIES % atoi(e) == 0) copies = (uint32_t)atoi(e); }   // tuning probe
+        static const int probe_copies = [] { const char *e = getenv("PLK_MSM_COPIES"); return e ? atoi(e) : 0; }();   // tuning probe, read once
+        if (probe_copies >= 1 && (uint32_t)probe_copies <= copies && MAX_COPIES % probe_copies == 0) copies = (uint32_t)probe_copies;
     } else PLK_TRY(ensure_base_table(ctx, 1, stream));
     const G1Affine *bases = ctx->srs_w.as<G1Affine>() + base_offset;
     S.pending_parts = 0;
@@ -671,7 +672,8 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     p.coarse_bits = p.c - 1 - FINE_BITS;
     p.nbins = 1u << p.coarse_bits;
     p.batch = batch;
-    { const char *dbg = getenv("PLK_MSM_DEBUG"); p.debug = dbg ? (uint32_t)atoi(dbg) : 0; }
+    static const uint32_t probe_debug = [] { const char *e = getenv("PLK_MSM_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();   // experiments only, read once
+    p.debug = probe_debug;
     ScalarSet set{};
     for (uint32_t m = 0; m < batch; m++) set.v[m] = scalars_dev[m];
     const uint32_t total_sets = batch * p.groups, total_bins = total_sets * p.nbins, total_windows = batch * p.windows;
