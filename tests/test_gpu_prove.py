@@ -310,3 +310,40 @@ def test_prove_differential_fuzz():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "prove_fuzz.py"), "12", "3"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout
+
+
+def test_unsatisfied_witness_is_refused(ctx, golden_dir, golden_crs, tmp_path):
+    """SetupForProver::prove first checks is_satisfied (src/plonk.rs:137, `expect("must satisfy")`): a witness that
+    violates a constraint gives PLK_ERR_UNSAT from the library and exit status 101 from the CLI, and no proof file"""
+    import subprocess
+    import plonkit_amd as pa
+    r1cs = open(os.path.join(golden_dir, "circuit.r1cs.json"), "rb").read()
+    wit = json.loads(open(os.path.join(golden_dir, "witness.json")).read())
+    bad = list(wit)
+    bad[2] = str((int(bad[2]) + 1) % R_MOD)
+    circ = pa.Circuit(r1cs, True, json.dumps(bad).encode(), True)
+    ctx.srs_upload(golden_crs.g1)
+    ctx.srs_lagrange_clear()
+    setup = pa.SetupForProver(ctx, circ)                          # the setup does not depend on the witness
+    with pytest.raises(pa.PlkError) as e:
+        setup.prove(circ)
+    assert e.value.code == 5 and "must satisfy" in str(e.value)
+    good = pa.Circuit(r1cs, True, json.dumps(wit).encode(), True)
+    assert setup.prove(good) == open(os.path.join(golden_dir, "proof.bin"), "rb").read()
+    # the same through the CLI
+    cli = os.path.join(os.path.dirname(pa.lib_path()), "plonkit")
+    key, badw, proof = str(tmp_path / "k.key"), str(tmp_path / "bad.json"), str(tmp_path / "p.bin")
+    open(key, "wb").write(open(os.path.join(golden_dir, "setup_2pow10.key"), "rb").read())
+    open(badw, "w").write(json.dumps(bad))
+    rc = subprocess.call([cli, "prove", "-m", key, "-c", os.path.join(golden_dir, "circuit.r1cs.json"), "-w", badw, "-p", proof], stderr=subprocess.DEVNULL)
+    assert rc == 101 and not os.path.exists(proof)
+    # a synthetic circuit large enough for the device-side evaluation of the temporaries
+    big = pa.Circuit.synthetic((1 << 12) - 2)
+    ctx.srs_generate(1 << 12, 0, 42)
+    s2 = pa.SetupForProver(ctx, big)
+    wt = bytearray(big.export("wtns"))
+    wt[-1] ^= 1                                                    # flip a bit of the last witness value
+    broken = pa.Circuit(big.export("r1cs"), False, bytes(wt), False)
+    with pytest.raises(pa.PlkError) as e2:
+        s2.prove(broken)
+    assert e2.value.code == 5
