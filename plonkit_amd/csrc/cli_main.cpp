@@ -91,6 +91,57 @@ static plk_circuit *load_circuit(const std::string &cf, const std::string *wf) {
     CK("load circuit", plk_circuit_load(r.data(), r.size(), ends_with(cf, "json"), wf ? w.data() : nullptr, w.size(), wf && ends_with(*wf, "json"), &c));
     return c;
 }
+// proof.json / public.json of `prove` (src/bin/main.rs:410-424): bellman_vk_codegen::serialize_proof gives the public
+// inputs and the 33 words of the Solidity verifier's deserialize_proof (contrib/template.sol:864-951: the proof.bin
+// fields in the same order, without the length words, G1 as (x, y), infinity as (0, 0)), printed by
+// serde_json::to_string_pretty.  UNPINNED: the crate is not in the reference tree and no fixture holds these files; the
+// number format written here is web3's U256 one ("0x" + hex without leading zeros), which ethers accepts.
+static std::string hex_word(const uint8_t *be32) {
+    static const char *d = "0123456789abcdef";
+    std::string s = "0x";
+    bool started = false;
+    for (int i = 0; i < 32; i++) {
+        const int hi = be32[i] >> 4, lo = be32[i] & 15;
+        if (started || hi) { s += d[hi]; started = true; }
+        if (started || lo) { s += d[lo]; started = true; }
+    }
+    if (!started) s += '0';
+    return s;
+}
+static std::string json_array(const std::vector<std::string> &items) {
+    if (items.empty()) return "[]";
+    std::string s = "[\n";
+    for (size_t i = 0; i < items.size(); i++) s += "  \"" + items[i] + "\"" + (i + 1 < items.size() ? ",\n" : "\n");
+    return s + "]";
+}
+static bool proof_words(const uint8_t *p, size_t len, std::vector<std::string> *inputs, std::vector<std::string> *words) {
+    size_t off = 0;
+    auto u64 = [&](uint64_t *v) { if (off + 8 > len) return false; *v = 0; for (int i = 0; i < 8; i++) *v = (*v << 8) | p[off + i]; off += 8; return true; };
+    auto fr = [&](std::vector<std::string> *dst) { if (off + 32 > len) return false; dst->push_back(hex_word(p + off)); off += 32; return true; };
+    auto g1 = [&]() {
+        if (off + 64 > len) return false;
+        static const uint8_t zero[32] = {0};
+        const bool inf = (p[off] & 0x40) != 0;
+        words->push_back(hex_word(inf ? zero : p + off)); words->push_back(hex_word(inf ? zero : p + off + 32));
+        off += 64; return true;
+    };
+    uint64_t n, k;
+    if (!u64(&n) || !u64(&k)) return false;
+    for (uint64_t i = 0; i < k; i++) if (!fr(inputs)) return false;
+    if (!u64(&k) || k != 4) return false;
+    for (int i = 0; i < 4; i++) if (!g1()) return false;
+    if (!g1()) return false;
+    if (!u64(&k) || k != 4) return false;
+    for (int i = 0; i < 4; i++) if (!g1()) return false;
+    if (!u64(&k) || k != 4) return false;
+    for (int i = 0; i < 4; i++) if (!fr(words)) return false;
+    if (!u64(&k) || k != 1) return false;
+    for (int i = 0; i < 4; i++) if (!fr(words)) return false;      // d(z*omega), z(z*omega), t(z), r(z)
+    if (!u64(&k) || k != 3) return false;
+    for (int i = 0; i < 3; i++) if (!fr(words)) return false;
+    return g1() && g1() && off == len;
+}
+
 static plk_ctx *open_ctx() { plk_ctx *ctx = nullptr; CK("plk_create", plk_create(0, &ctx)); return ctx; }
 static void load_key(plk_ctx *ctx, const std::string &path, uint8_t g2[256], bool lagrange = false) {
     const char *what = lagrange ? "read key_lagrange_form err" : "read key_monomial_form err";
@@ -197,6 +248,16 @@ static int run(int argc, char **argv) {
         refuse_duplicate(a, out, "proof");
         spit(out, buf.data(), len);
         fprintf(stderr, "Proof saved to %s\n", out.c_str());
+        std::vector<std::string> inputs, words;
+        if (!proof_words(buf.data(), len, &inputs, &words)) { fprintf(stderr, "serialize_proof: malformed proof\n"); return 101; }
+        std::string pj = a.get("proofjson", "proof.json"), ij = a.get("publicjson", "public.json");
+        refuse_duplicate(a, pj, "proof json");
+        refuse_duplicate(a, ij, "input json");
+        std::string ps = json_array(words), is = json_array(inputs);
+        spit(pj, reinterpret_cast<const uint8_t *>(ps.data()), ps.size());
+        fprintf(stderr, "Proof json saved to %s\n", pj.c_str());
+        spit(ij, reinterpret_cast<const uint8_t *>(is.data()), is.size());
+        fprintf(stderr, "Public input json saved to %s\n", ij.c_str());
     } else if (cmd == "verify") {                                    // src/bin/main.rs:425-437 (no GPU involved)
         Args a = parse(argc, argv, {{"p", "proof"}, {"v", "vk"}, {"t", "transcript"}});
         if (a.get("transcript", "keccak") != "keccak") { fprintf(stderr, "not implemented: transcript '%s' (only keccak; rescue needs franklin-crypto)\n", a.get("transcript").c_str()); return 101; }

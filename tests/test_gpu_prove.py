@@ -163,20 +163,28 @@ def test_cli_end_to_end_golden(ctx, golden_dir, golden_crs, tmp_path):
     vk, proof = str(tmp_path / "vk.bin"), str(tmp_path / "proof.bin")
     subprocess.check_call([cli, "export-verification-key", "-m", key, "-c", circ, "-v", vk], stderr=subprocess.DEVNULL)
     assert open(vk, "rb").read() == open(os.path.join(golden_dir, "vk.bin"), "rb").read()
-    subprocess.check_call([cli, "prove", "-m", key, "-c", circ, "-w", wit, "-p", proof], stderr=subprocess.DEVNULL)
+    pj, ij = str(tmp_path / "proof.json"), str(tmp_path / "public.json")
+    subprocess.check_call([cli, "prove", "-m", key, "-c", circ, "-w", wit, "-p", proof, "-j", pj, "-i", ij], stderr=subprocess.DEVNULL)
     assert open(proof, "rb").read() == open(os.path.join(golden_dir, "proof.bin"), "rb").read()
+    # proof.json / public.json (format unpinned): the 33 words of the Solidity verifier and the inputs
+    P = po.read_proof(open(proof, "rb").read())
+    words, pub = [int(x, 16) for x in json.load(open(pj))], [int(x, 16) for x in json.load(open(ij))]
+    assert pub == P.inputs and len(words) == 33
+    assert words[16 + 2:16 + 2 + 4] == P.wire_values_at_z and words[-8:-4] == [P.linearization_polynomial_at_z] + P.permutation_polynomials_at_z
     subprocess.check_call([cli, "verify", "-p", proof, "-v", vk], stderr=subprocess.DEVNULL)
-    subprocess.check_call([cli, "prove", "-m", key, "-c", circ, "-w", wit, "-p", proof, "--overwrite"], stderr=subprocess.DEVNULL)
-    assert subprocess.call([cli, "prove", "-m", key, "-c", circ, "-w", wit, "-p", proof], stderr=subprocess.DEVNULL) == 101
+    subprocess.check_call([cli, "prove", "-m", key, "-c", circ, "-w", wit, "-p", proof, "-j", pj, "-i", ij, "--overwrite"], stderr=subprocess.DEVNULL)
+    assert subprocess.call([cli, "prove", "-m", key, "-c", circ, "-w", wit, "-p", proof, "-j", pj, "-i", ij], stderr=subprocess.DEVNULL) == 101
+    assert subprocess.call([cli, "prove", "-m", key, "-c", circ, "-w", wit, "-p", str(tmp_path / "fresh.bin"), "-j", pj, "-i", str(tmp_path / "pub2.json")],
+                           stderr=subprocess.DEVNULL) == 101             # duplicate proof json file
     lag = str(tmp_path / "lagrange.key")
     subprocess.check_call([cli, "dump-lagrange", "-m", key, "-l", lag, "-c", circ], stderr=subprocess.DEVNULL)
     L = po.read_crs(open(lag, "rb").read())
     assert L.g1.shape[0] == 8 and np.array_equal(L.g1, ol.g1_intt(golden_crs.g1[:8], 3))
     # prove -l: witness commitments from evaluations against the Lagrange-form key; identical proof bytes
     proof_l = str(tmp_path / "proof_l.bin")
-    subprocess.check_call([cli, "prove", "-m", key, "-l", lag, "-c", circ, "-w", wit, "-p", proof_l], stderr=subprocess.DEVNULL)
+    subprocess.check_call([cli, "prove", "-m", key, "-l", lag, "-c", circ, "-w", wit, "-p", proof_l, "-j", pj, "-i", ij, "--overwrite"], stderr=subprocess.DEVNULL)
     assert open(proof_l, "rb").read() == open(os.path.join(golden_dir, "proof.bin"), "rb").read()
-    assert subprocess.call([cli, "prove", "-m", key, "-l", key, "-c", circ, "-w", wit, "-p", str(tmp_path / "x.bin")],
+    assert subprocess.call([cli, "prove", "-m", key, "-l", key, "-c", circ, "-w", wit, "-p", str(tmp_path / "x.bin"), "-j", pj, "-i", ij, "--overwrite"],
                            stderr=subprocess.DEVNULL) == 101          # a 1024-point key is not the 8-point Lagrange key
 
 
@@ -335,7 +343,8 @@ def test_unsatisfied_witness_is_refused(ctx, golden_dir, golden_crs, tmp_path):
     key, badw, proof = str(tmp_path / "k.key"), str(tmp_path / "bad.json"), str(tmp_path / "p.bin")
     open(key, "wb").write(open(os.path.join(golden_dir, "setup_2pow10.key"), "rb").read())
     open(badw, "w").write(json.dumps(bad))
-    rc = subprocess.call([cli, "prove", "-m", key, "-c", os.path.join(golden_dir, "circuit.r1cs.json"), "-w", badw, "-p", proof], stderr=subprocess.DEVNULL)
+    rc = subprocess.call([cli, "prove", "-m", key, "-c", os.path.join(golden_dir, "circuit.r1cs.json"), "-w", badw, "-p", proof,
+                          "-j", str(tmp_path / "pj.json"), "-i", str(tmp_path / "ij.json")], stderr=subprocess.DEVNULL)
     assert rc == 101 and not os.path.exists(proof)
     # a synthetic circuit large enough for the device-side evaluation of the temporaries
     big = pa.Circuit.synthetic((1 << 12) - 2)

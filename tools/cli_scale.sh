@@ -14,6 +14,6 @@ print("%-28s %8.3f s  (+ %.3f s writing %d MB)" % ("synthetic circuit (host)", t
 PY
 TAG="setup -p $L (crs_42 on GPU)"; t $CLI setup -p $L -m $D/key.bin --overwrite
 TAG="export-verification-key"; t $CLI export-verification-key -m $D/key.bin -c $D/circuit.r1cs -v $D/vk.bin --overwrite
-TAG="prove (whole CLI)"; PLK_CLI_TIMING=1 $CLI prove -m $D/key.bin -c $D/circuit.r1cs -w $D/witness.wtns -p $D/proof_t.bin --overwrite 2>&1 | grep timing; t $CLI prove -m $D/key.bin -c $D/circuit.r1cs -w $D/witness.wtns -p $D/proof.bin --overwrite
+TAG="prove (whole CLI)"; PLK_CLI_TIMING=1 $CLI prove -m $D/key.bin -c $D/circuit.r1cs -w $D/witness.wtns -p $D/proof_t.bin -j $D/proof.json -i $D/public.json --overwrite 2>&1 | grep timing; t $CLI prove -m $D/key.bin -c $D/circuit.r1cs -w $D/witness.wtns -p $D/proof.bin -j $D/proof.json -i $D/public.json --overwrite
 TAG="verify"; t $CLI verify -p $D/proof.bin -v $D/vk.bin
 ls -la $D | awk '{print $5, $9}' | tail -6
