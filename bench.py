@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the per-GPU commitment size")
     ap.add_argument("--cpu-log-n", type=int, default=20, help="log2 of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--msm-only", action="store_true", help="only the timed commitments (no cpu_baseline / prove / kernels legs): "
+                                                            "the command the rocprofv3 summary under profiles/ is taken from")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -212,13 +214,13 @@ def main():
                                  "is 11x the algorithmic bytes because Pippenger gathers one 64-byte point per (term, window): "
                                  "15 windows, each from its own shifted copy of the SRS (0.94 GiB fixed-base table in HBM)"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.msm_only:
             cb, ref, s_host = cpu_baseline(ctx, min(args.cpu_log_n, args.log_n), 1234)
             got = ctx.msm(s_host)                         # same sample through the HIP path
             cb["matches_gpu"] = bool(np.array_equal(got, ref))
             cb["prove"] = cpu_prove_baseline(ctx, min(16, args.log_n))
             line["cpu_baseline"] = cb
-        if world == 1 and not force_dist:
+        if world == 1 and not force_dist and not args.msm_only:
             from plonkit_amd import prover_bench
             line["prove"] = prover_bench.run(ctx, args.log_n)
             line["kernels"] = prover_bench.kernel_table(ctx, device)
