@@ -1,0 +1,69 @@
+// Host-side check of the 9 x 29-bit lazy field layer and its group law (field29.cuh / ec29.cuh: the PLK_HD functions
+// compile for the host too) against the 8 x 32-bit layer (field.cuh / ec.cuh), which the GPU tests pin to the oracle.
+// Built and run by tests/test_field29_host.py with hipcc; needs no GPU.
+#include "ec29.cuh"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+using namespace plk;
+static uint64_t rs = 88172645463325252ULL;
+static uint32_t rnd() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (uint32_t)(rs >> 16); }
+template <class PR> Fp<PR> rnd_fp() { Fp<PR> a; for (int i = 0; i < 8; i++) a.l[i] = rnd(); a.l[7] &= 0x0fffffff; return a; }   // < 2^252 < p
+static G1Affine to_aff(const G1Xyzz &p) {
+    G1Affine a; if (is_inf(p)) { a.x = Fq::zero(); a.y = Fq::zero(); return a; }
+    Fq i = inv(mul(p.zz, p.zzz)); a.x = mul(p.x, mul(i, p.zzz)); a.y = mul(p.y, mul(i, p.zz)); return a; }
+static AffW aff_to_w(const G1Affine &a) { AffW r; r.x = csub_p(w_from_s(unpack<FqW>(a.x))); r.y = csub_p(w_from_s(unpack<FqW>(a.y))); return r; }
+static G1Xyzz exportw(const XyzzW &p) {
+    if (is_inf(p)) return xyzz_identity();
+    G1Xyzz r; r.x = pack<FqParams>(s_from_w(p.x)); r.y = pack<FqParams>(s_from_w(p.y)); r.zz = pack<FqParams>(s_from_w(p.zz)); r.zzz = pack<FqParams>(s_from_w(p.zzz)); return r; }
+int main() {
+    int bad = 0;
+    for (int it = 0; it < 20000; it++) {
+        Fr a = rnd_fp<FrParams>(), b = rnd_fp<FrParams>();
+        FrW9 aw = w_from_s(unpack<FrW>(a)), bw = w_from_s(unpack<FrW>(b));
+        Fr got = pack<FrParams>(s_from_w(mulw(aw, bw)));
+        if (got != mul(a, b)) { bad++; if (bad < 5) printf("mul mismatch %d\n", it); }
+        // linear use: raw 256-domain data times a W-domain constant
+        Fr got2 = pack<FrParams>(csub_p(mulw(unpack<FrW>(a), bw)));
+        if (got2 != mul(a, b)) { bad++; if (bad < 5) printf("linear mul mismatch %d\n", it); }
+        // lazy add/sub chains
+        FrW9 s = addn(addn(aw, bw), aw);                 // 2a + b
+        FrW9 d = sub2(s, bw);                            // 2a (+2p)
+        FrW9 d2 = sub6(d, addn(addn(aw, aw), aw));       // -a (+6p)
+        Fr want = neg(a);
+        if (pack<FrParams>(s_from_w(d2)) != want) { bad++; if (bad < 5) printf("addsub mismatch %d\n", it); }
+        if (!is_zero_mod_p(sub4(addn(aw, bw), addn(bw, aw)))) { bad++; if (bad < 5) printf("zero test %d\n", it); }
+        if (is_zero_mod_p(sub4(addn(aw, bw), addn(bw, bw))) && a != b) { bad++; if (bad < 5) printf("zero test false positive %d\n", it); }
+    }
+    // dedicated squaring, fused products, cheap canonical reduction — both fields
+    for (int it = 0; it < 20000; it++) {
+        Fq a = rnd_fp<FqParams>(), b = rnd_fp<FqParams>(), c = rnd_fp<FqParams>(), d = rnd_fp<FqParams>(), e = rnd_fp<FqParams>(), f = rnd_fp<FqParams>();
+        FqW9 aw = w_from_s(unpack<FqW>(a)), bw = w_from_s(unpack<FqW>(b)), cw = w_from_s(unpack<FqW>(c)), dw = w_from_s(unpack<FqW>(d)),
+             ew = w_from_s(unpack<FqW>(e)), fw = w_from_s(unpack<FqW>(f));
+        if (pack<FqParams>(s_from_w(sqrw(aw))) != mul(a, a)) { bad++; if (bad < 5) printf("sqrw mismatch %d\n", it); }
+        if (pack<FqParams>(s_from_w(mul2addw(aw, bw, cw, dw))) != add(mul(a, b), mul(c, d))) { bad++; if (bad < 5) printf("mul2addw mismatch %d\n", it); }
+        if (pack<FqParams>(s_from_w(mulsum3w(aw, bw, cw, dw, ew, fw))) != add(add(mul(a, b), mul(c, d)), mul(e, f))) { bad++; if (bad < 5) printf("mulsum3w mismatch %d\n", it); }
+        FqW9 big = addn(addn(addn(aw, bw), addn(cw, dw)), addn(ew, fw));             // < 6.6p, normalised
+        for (int k = 0; k < (it & 3); k++) big = addn(big, big);                      // up to < 53p
+        FqW9 r1 = reduce_small(big), r2 = reduce_full(big);                           // same residue (x * one / R)
+        for (int k = 0; k < 9; k++) if (r1.l[k] != r2.l[k]) { bad++; if (bad < 5) printf("reduce_small mismatch %d\n", it); break; }
+    }
+    printf("field29: %d mismatches\n", bad);
+    // EC: random chain of mixed adds, doubles and full adds against ec.cuh
+    G1Affine g; g.x = from_u64<FqParams>(1); g.y = from_u64<FqParams>(2);
+    G1Xyzz acc = xyzz_identity(); XyzzW accw = xyzzw_identity();
+    G1Affine pts[8]; AffW ptsw[8];
+    { G1Xyzz t = xyzz_from_affine(g); for (int i = 0; i < 8; i++) { pts[i] = to_aff(t); ptsw[i] = aff_to_w(pts[i]); t = xyzz_double(t); xyzz_add_mixed(t, g, false); } }
+    int ebad = 0;
+    for (int it = 0; it < 3000; it++) {
+        int k = rnd() & 7; bool ng = rnd() & 1; int op = rnd() % 10;
+        if (op < 7) { xyzz_add_mixed(acc, pts[k], ng); xyzzw_add_mixed(accw, ptsw[k], ng); }
+        else if (op == 7) { acc = xyzz_double(acc); accw = xyzzw_double(accw); }
+        else if (op == 8) { G1Xyzz o = acc; xyzz_add_mixed(o, pts[k], !ng); xyzz_add(acc, o); XyzzW ow = accw; xyzzw_add_mixed(ow, ptsw[k], !ng); xyzzw_add(accw, ow); }
+        else { /* P + P and P - P through the mixed add */ G1Affine cur = to_aff(acc); AffW cw = aff_to_w(cur); bool n2 = rnd() & 1; xyzz_add_mixed(acc, cur, n2); xyzzw_add_mixed(accw, cw, n2); }
+        G1Affine x = to_aff(acc), y = to_aff(exportw(accw));
+        if (x.x != y.x || x.y != y.y) { ebad++; if (ebad < 5) printf("ec mismatch at %d op %d\n", it, op); }
+    }
+    printf("ec29: %d mismatches\n", ebad);
+    return bad + ebad;
+}

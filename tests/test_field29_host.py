@@ -1,0 +1,21 @@
+"""The lazy 9 x 29-bit field layer and the XYZZ group law built on it (plonkit_amd/csrc/field29.cuh, ec29.cuh) compiled
+for the HOST and compared with the 8 x 32-bit layer on random inputs: products, squarings, fused sums, lazy add/sub
+chains, zero tests, the quotient-estimate reduction, and a random walk of mixed additions / doublings / full additions
+including P + P and P - P.  No GPU involved (hipcc only compiles); the GPU suite pins both layers to the oracle."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_field29_and_ec29_against_the_32_bit_layer(tmp_path):
+    exe = str(tmp_path / "field29_check")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "plonkit_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host", "field29_check.hip"), "-o", exe], stderr=subprocess.DEVNULL)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    assert "field29: 0 mismatches" in r.stdout and "ec29: 0 mismatches" in r.stdout
