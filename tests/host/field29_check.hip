@@ -65,5 +65,18 @@ int main() {
         if (x.x != y.x || x.y != y.y) { ebad++; if (ebad < 5) printf("ec mismatch at %d op %d\n", it, op); }
     }
     printf("ec29: %d mismatches\n", ebad);
+    // known-answer lines for the Python side (checked there with big integers): canonical a, b, a*b through the W layer
+    auto hex = [](const uint32_t *l) { for (int i = 7; i >= 0; i--) printf("%08x", l[i]); };
+    for (int it = 0; it < 40; it++) {
+        Fr a = rnd_fp<FrParams>(), b = rnd_fp<FrParams>();
+        Fr p = pack<FrParams>(s_from_w(mulw(w_from_s(unpack<FrW>(a)), w_from_s(unpack<FrW>(b)))));
+        Fr ac = to_canonical(a), bc = to_canonical(b), pc = to_canonical(p);
+        printf("KAT Fr "); hex(ac.l); printf(" "); hex(bc.l); printf(" "); hex(pc.l); printf("\n");
+        Fq c = rnd_fp<FqParams>(), d = rnd_fp<FqParams>();
+        Fq q = pack<FqParams>(s_from_w(sqrw(w_from_s(unpack<FqW>(c)))));
+        Fq cc = to_canonical(c), qc = to_canonical(q);
+        (void)d;
+        printf("KAT Fq "); hex(cc.l); printf(" "); hex(cc.l); printf(" "); hex(qc.l); printf("\n");
+    }
     return bad + ebad;
 }
