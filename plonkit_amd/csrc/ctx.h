@@ -103,6 +103,7 @@ struct plk_ctx {
     plk_combine_fn combine = nullptr;
     void *combine_user = nullptr;
     std::vector<plk::host::HJac> commit_pieces;   // partial sums of a commitment longer than one MSM call (prover.hip)
+    std::vector<plk::host::HJac> commit_done;     // finished commitments of a batch that is processed one at a time
 };
 
 namespace plk {

@@ -33,6 +33,8 @@ struct QuotientArgs {
     // PI polynomial is interpolated or extended (pi == nullptr); otherwise pi is its extension.
     uint32_t num_pi;
     Fr pi_in[QUOTIENT_MAX_DIRECT_PI];
+    PowTable tw_w;                      // used when x == nullptr: coset points computed on the fly (coset_w = 7 * 2^261)
+    Fr coset_w;
 };
 int32_t scale_const(Fr *out, const Fr *in, const Fr &c_s, uint32_t n, hipStream_t s);            // out_i = in_i * c (one W-layer product), canonical
 int32_t coset_points_w(Fr *out, const PowTable &tw_w, uint32_t log_m, const Fr &c_s, uint32_t m, hipStream_t s);   // out_i = c * omega_m^i

@@ -205,7 +205,13 @@ __global__ void __launch_bounds__(PT) k_quotient(QuotientArgs a) {
     FrW9 g = addn(addn(f1, f2), ldw(a.q[5] + i));
     if (a.pi) g = addn(g, ldw(a.pi + i));
     else for (uint32_t k = 0; k < a.num_pi; k++) g = addn(g, mulw(ldw(a.l0 + ((i - 4 * k) & (a.m - 1))), cw(a.pi_in[k])));
-    const FrW9 x = ldw(a.x + i), z = ldw(a.z + i), gamma = cw(a.gamma), beta = cw(a.beta);
+    FrW9 x;
+    if (a.x) x = ldw(a.x + i);
+    else {                                                        // no cached coset points (largest domains): 7 * omega_4N^i from the table
+        const uint32_t e = i << (MAX_LOG_N - a.log_m);
+        x = mulw(mulw(ldw(a.tw_w.lo + (e & (POW_TAB - 1))), ldw(a.tw_w.hi + (e >> POW_SPLIT))), cw(a.coset_w));
+    }
+    const FrW9 z = ldw(a.z + i), gamma = cw(a.gamma), beta = cw(a.beta);
     FrW9 pa = z, pb = ldw(a.z + nxt);
 #pragma unroll
     for (int j = 0; j < 4; j++) {

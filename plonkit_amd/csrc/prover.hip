@@ -49,6 +49,32 @@ static uint64_t msm_piece_terms() {
     static const uint64_t v = [] { const char *e = getenv("PLK_MSM_MAX_TERMS"); uint64_t x = e ? strtoull(e, nullptr, 10) : 0; return x >= 4096 && x <= (1ull << 24) ? x : (1ull << 24); }();
     return v;                                                 // (the environment override exists for the tests)
 }
+// enqueues the pieces of `cnt` commitments over scalars[lo + ...]; every piece but the last is finished here and summed
+// into ctx->commit_pieces, the last one stays in flight (the caller overlaps it and calls commit_end)
+static int32_t enqueue_pieces(plk_ctx *ctx, const Fr *const *vecs, uint32_t cnt, uint64_t lo, uint64_t hi, uint64_t first_base) {
+    const uint64_t piece = msm_piece_terms();
+    ctx->commit_pieces.clear();
+    const Fr *shifted[8];
+    for (uint64_t off = 0;; off += piece) {
+        const uint64_t len = hi - lo - off < piece ? hi - lo - off : piece;
+        for (uint32_t k = 0; k < cnt; k++) shifted[k] = vecs[k] + lo + off;
+        PLK_TRY(msm_enqueue_batch(ctx, shifted, cnt, len, first_base + off, ctx->stream));
+        if (off + len >= hi - lo) break;
+        HJac j[8];
+        PLK_TRY(msm_finish_batch(ctx, nullptr, j));
+        if (ctx->commit_pieces.empty()) ctx->commit_pieces.assign(j, j + cnt);
+        else for (uint32_t k = 0; k < cnt; k++) ctx->commit_pieces[k] = jac_add(ctx->commit_pieces[k], j[k]);
+    }
+    return PLK_OK;
+}
+static int32_t finish_pieces(plk_ctx *ctx, uint32_t cnt, HJac *j) {
+    PLK_TRY(msm_finish_batch(ctx, nullptr, j));
+    if (!ctx->commit_pieces.empty()) {
+        for (uint32_t k = 0; k < cnt; k++) j[k] = jac_add(j[k], ctx->commit_pieces[k]);
+        ctx->commit_pieces.clear();
+    }
+    return PLK_OK;
+}
 static int32_t commit_begin(plk_ctx *ctx, const Fr *const *vecs, uint32_t count, uint64_t n, bool lagrange = false) {
     SrsSlotSwap active(ctx, lagrange);
     uint64_t lo = 0, hi = n;
@@ -57,29 +83,29 @@ static int32_t commit_begin(plk_ctx *ctx, const Fr *const *vecs, uint32_t count,
         hi = ctx->shard_first + ctx->srs_n < n ? ctx->shard_first + ctx->srs_n : n;
         if (hi < lo) hi = lo;
     }
-    const uint64_t first_base = ctx->combine ? 0 : lo, piece = msm_piece_terms();
-    ctx->commit_pieces.clear();
-    const Fr *shifted[8];
-    // all pieces but the last are finished here; the last one stays in flight so that the caller can overlap it
-    for (uint64_t off = 0;; off += piece) {
-        const uint64_t len = hi - lo - off < piece ? hi - lo - off : piece;
-        for (uint32_t k = 0; k < count; k++) shifted[k] = vecs[k] + lo + off;
-        PLK_TRY(msm_enqueue_batch(ctx, shifted, count, len, first_base + off, ctx->stream));
-        if (off + len >= hi - lo) break;
-        HJac j[8];
-        PLK_TRY(msm_finish_batch(ctx, nullptr, j));
-        if (ctx->commit_pieces.empty()) ctx->commit_pieces.assign(j, j + count);
-        else for (uint32_t k = 0; k < count; k++) ctx->commit_pieces[k] = jac_add(ctx->commit_pieces[k], j[k]);
+    const uint64_t first_base = ctx->combine ? 0 : lo;
+    ctx->commit_done.clear();
+    // at the largest sizes a batch of commitments would need gigabytes of per-task partial-sum slots (2^26 gates: 16 GiB for
+    // four wires, which is what stands between that domain and the 288 GB): one commitment at a time there
+    if (count > 1 && hi - lo >= msm_piece_terms()) {
+        for (uint32_t k = 0; k + 1 < count; k++) {
+            HJac j;
+            PLK_TRY(enqueue_pieces(ctx, vecs + k, 1, lo, hi, first_base));
+            PLK_TRY(finish_pieces(ctx, 1, &j));
+            ctx->commit_done.push_back(j);
+        }
+        return enqueue_pieces(ctx, vecs + count - 1, 1, lo, hi, first_base);
     }
-    return PLK_OK;
+    return enqueue_pieces(ctx, vecs, count, lo, hi, first_base);
 }
 static int32_t commit_end(plk_ctx *ctx, uint32_t count, HAffine *out) {
     HJac j[8];
-    PLK_TRY(msm_finish_batch(ctx, nullptr, j));
-    if (!ctx->commit_pieces.empty()) {
-        for (uint32_t k = 0; k < count; k++) j[k] = jac_add(j[k], ctx->commit_pieces[k]);
-        ctx->commit_pieces.clear();
-    }
+    if (!ctx->commit_done.empty()) {                              // the one-at-a-time path of commit_begin
+        const uint32_t done = (uint32_t)ctx->commit_done.size();
+        for (uint32_t k = 0; k < done; k++) j[k] = ctx->commit_done[k];
+        PLK_TRY(finish_pieces(ctx, 1, j + done));
+        ctx->commit_done.clear();
+    } else PLK_TRY(finish_pieces(ctx, count, j));
     if (ctx->combine) {
         plk_g1_jacobian raw[8];
         for (uint32_t k = 0; k < count; k++) { memcpy(raw[k].x, j[k].x.l, 32); memcpy(raw[k].y, j[k].y.l, 32); memcpy(raw[k].z, j[k].z.l, 32); }
@@ -347,7 +373,8 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     const size_t NB = (N * sizeof(Fr) + 255) & ~(size_t)255, MB = (M * sizeof(Fr) + 255) & ~(size_t)255;
     const size_t TB = ((size_t)2 * POW_TAB * sizeof(Fr) + 255) & ~(size_t)255;
     const size_t VB = (T.num_vars * sizeof(Fr) + 255) & ~(size_t)255;
-    PLK_TRY(ctx->prove_ws.reserve(VB + 16 * NB + 8 * MB + 4 * TB + 8192));
+    const bool direct_pi = S->num_inputs <= QUOTIENT_MAX_DIRECT_PI;       // few inputs: PI comes from the cached L0 vector inside the quotient kernel
+    PLK_TRY(ctx->prove_ws.reserve(VB + 16 * NB + (direct_pi ? 6 : 7) * MB + 4 * TB + 8192));   // 5 extensions (+ PI) + the quotient
     Arena A{&ctx->prove_ws};
     Fr *d_values = A.take<Fr>(T.num_vars);
     Fr *w_vals[4], *w_coef[4];
@@ -356,7 +383,7 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     Fr *r_poly = A.take<Fr>(N), *agg = A.take<Fr>(N), *pi_coef = A.take<Fr>(N), *l0_coef = A.take<Fr>(N);
     Fr *ext[18] = {nullptr};
     for (int k = 0; k < 5; k++) ext[k] = A.take<Fr>(M);          // w0..w3, z
-    ext[16] = A.take<Fr>(M);                                      // PI
+    if (!direct_pi) ext[16] = A.take<Fr>(M);                      // PI
     Fr *t_ext = A.take<Fr>(M);
     Fr *tab[4];
     for (int k = 0; k < 4; k++) tab[k] = A.take<Fr>(2 * POW_TAB);
@@ -425,7 +452,6 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     { const Fr *zp = use_lagrange ? t1 : z_coef; PLK_TRY(commit_begin(ctx, &zp, 1, N, use_lagrange)); }
     // while z is being committed: its extension, the public-input polynomial, and (first proof only) the constant vectors
     PLK_TRY(lde4_dev(ctx, z_coef, log_n, ext[4], st));
-    const bool direct_pi = inputs.size() <= QUOTIENT_MAX_DIRECT_PI;       // few inputs: PI comes from the cached L0 vector inside the quotient kernel
     if (!direct_pi) {
         PLK_HIP(hipMemsetAsync(pi_coef, 0, N * sizeof(Fr), st));
         PLK_HIP(hipMemcpyAsync(pi_coef, inputs.data(), inputs.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
@@ -441,9 +467,13 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     const HFr coset = HFr::from_u64(7);
     {
         if (!S->lde_ready) {
-            PLK_TRY(S->lde_store.reserve(13 * MB));
+            // the coset-point vector is a convenience (one load instead of two loads and two products per point):
+            // above 2^24 gates its 4N * 32 bytes are better spent elsewhere (2^26 would not fit in 288 GB)
+            const bool cache_x = log_n <= 24;
+            PLK_TRY(S->lde_store.reserve((cache_x ? 13 : 12) * MB));
             Arena LA{&S->lde_store};
-            for (int k = 0; k < 13; k++) S->lde[k] = LA.take<Fr>(M);
+            for (int k = 0; k < (cache_x ? 13 : 12); k++) S->lde[k] = LA.take<Fr>(M);
+            if (!cache_x) S->lde[12] = nullptr;
             for (int k = 0; k < 7; k++) PLK_TRY(lde4_dev(ctx, S->sel_coef[k], log_n, S->lde[k], st));
             for (int j = 0; j < 4; j++) PLK_TRY(lde4_dev(ctx, S->sig_coef[j], log_n, S->lde[7 + j], st));
             HFr one = HFr::one();
@@ -458,7 +488,7 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
                 if (k == 5) continue;
                 PLK_TRY(scale_const(S->lde[k], S->lde[k], to_dev(k == 4 ? s10 : s5), (uint32_t)M, st));
             }
-            PLK_TRY(coset_points_w(S->lde[12], ctx->tw_fwd_w, log_m, to_dev(HFr::from_u64(7u << 5)), (uint32_t)M, st));
+            if (S->lde[12]) PLK_TRY(coset_points_w(S->lde[12], ctx->tw_fwd_w, log_m, to_dev(HFr::from_u64(7u << 5)), (uint32_t)M, st));
             PLK_HIP(hipStreamSynchronize(st));
             S->lde_ready = true;
         }
@@ -470,6 +500,7 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
         qa.z = ext[4];
         for (int k = 0; k < 7; k++) qa.q[k] = ext[5 + k];
         qa.pi = direct_pi ? nullptr : ext[16]; qa.l0 = ext[17]; qa.x = S->lde[12];
+        qa.tw_w = ctx->tw_fwd_w; qa.coset_w = to_dev(HFr::from_u64(7u << 5));
         qa.num_pi = direct_pi ? (uint32_t)inputs.size() : 0;
         for (uint32_t k = 0; k < qa.num_pi; k++) qa.pi_in[k] = to_dev(inputs[k]);
         const HFr two5 = HFr::from_u64(1u << 5), two25 = HFr::from_u64(1u << 25);

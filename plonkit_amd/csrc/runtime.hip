@@ -25,7 +25,9 @@ int32_t hip_fail(hipError_t e, const char *what, const char *file, int line) {
 int32_t DevBuf::reserve(size_t bytes) {
     if (bytes <= cap) return PLK_OK;
     if (p) { PLK_HIP(hipFree(p)); p = nullptr; cap = 0; }
-    size_t want = bytes + (bytes >> 3);           // a little slack so that growth is rare
+    size_t slack = bytes >> 3;                    // a little slack so that growth is rare ...
+    if (slack > ((size_t)64 << 20)) slack = (size_t)64 << 20;     // ... but never 12 % of a 100 GB workspace (2^26 domains)
+    size_t want = bytes + slack;
     PLK_HIP(hipMalloc(&p, want));
     cap = want;
     return PLK_OK;
