@@ -319,7 +319,12 @@ class SetupForProver:
         cap = 1 << 16
         out = ctypes.create_string_buffer(cap)
         n = ctypes.c_uint64(0)
-        _check(lib().plk_prove(self.ctx._h, self._h, circuit._h, out, ctypes.c_uint64(cap), ctypes.byref(n)))
+        rc = lib().plk_prove(self.ctx._h, self._h, circuit._h, out, ctypes.c_uint64(cap), ctypes.byref(n))
+        if rc == 1 and n.value > cap:                                 # many public inputs: retry with the reported size
+            cap = n.value
+            out = ctypes.create_string_buffer(cap)
+            rc = lib().plk_prove(self.ctx._h, self._h, circuit._h, out, ctypes.c_uint64(cap), ctypes.byref(n))
+        _check(rc)
         return out.raw[:n.value]
 
     def timings_ms(self):

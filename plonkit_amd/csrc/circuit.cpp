@@ -4,10 +4,10 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <unordered_map>
 
 namespace plk {
-void set_error(const std::string &msg);
 
 // ------------------------------------------------------------------------------- scalars
 bool fr_from_decimal(const std::string &s, HFr *out) {
@@ -68,16 +68,22 @@ bool parse_r1cs_bin(const uint8_t *data, size_t len, R1cs *out) {
     if (field_size != 32) { set_error("This parser only supports 32-byte fields"); return false; }
     if (memcmp(prime, BN254_R_LE, 32) != 0) { set_error("This parser only supports bn256"); return false; }
     r.off = secs[2].first;
+    // a constraint takes at least its three length words: the header cannot announce more than the section holds
+    if ((uint64_t)n_constraints * 12 > secs[2].second) { set_error("InvalidData: constraint count exceeds the constraint section"); return false; }
+    const size_t sec2_end = secs[2].first + secs[2].second;
     out->constraints.clear();
     out->constraints.resize(n_constraints);
     for (uint32_t i = 0; i < n_constraints; i++) {
         Lc *abc[3] = {&out->constraints[i].a, &out->constraints[i].b, &out->constraints[i].c};
         for (int k = 0; k < 3; k++) {
             uint32_t nv = r.u32();
-            if (!r.ok || !r.need((size_t)nv * 36)) { set_error("InvalidData: truncated constraint"); return false; }
+            if (!r.ok || !r.need((size_t)nv * 36) || r.off + (size_t)nv * 36 > sec2_end) { set_error("InvalidData: truncated constraint"); return false; }
             abc[k]->resize(nv);
             for (uint32_t j = 0; j < nv; j++) {
                 (*abc[k])[j].wire = r.u32();
+                // the reference indexes its variable table with the wire id and panics when it is out of range
+                // (src/circom_circuit.rs:107-113); here ids >= n_wires would alias the transpiler's temporaries
+                if ((*abc[k])[j].wire >= n_wires) { set_error("InvalidData: wire index out of range"); return false; }
                 if (!fr_from_le32(data + r.off, &(*abc[k])[j].coeff)) { set_error("InvalidData: coefficient not in field"); return false; }
                 r.off += 32;
             }
@@ -162,7 +168,11 @@ static bool json_parse(const uint8_t *data, size_t len, JVal *out) {
 static bool json_u64(const JVal *v, uint64_t *out) {
     if (!v || (v->t != JVal::NUM && v->t != JVal::STR) || v->s.empty()) return false;
     uint64_t x = 0;
-    for (char c : v->s) { if (c < '0' || c > '9') return false; x = x * 10 + (uint64_t)(c - '0'); }
+    for (char c : v->s) {
+        if (c < '0' || c > '9') return false;
+        if (x > (UINT64_MAX - 9) / 10) return false;                 // does not fit 64 bits
+        x = x * 10 + (uint64_t)(c - '0');
+    }
     *out = x; return true;
 }
 
@@ -175,6 +185,7 @@ bool parse_r1cs_json(const uint8_t *data, size_t len, R1cs *out) {
         set_error("unable to read: nPubInputs/nOutputs/nVars missing"); return false; }
     const JVal *cons = root.get("constraints");
     if (!cons || cons->t != JVal::ARR) { set_error("unable to read: constraints missing"); return false; }
+    if (n_vars >= (1ull << 32) || n_pub >= (1ull << 32) || n_out >= (1ull << 32)) { set_error("unable to read: nVars / nPubInputs / nOutputs out of range"); return false; }
     out->num_inputs = n_pub + n_out + 1;
     if (n_vars < out->num_inputs) { set_error("unable to read: nVars < number of inputs"); return false; }
     out->num_aux = n_vars - out->num_inputs;
@@ -194,6 +205,7 @@ bool parse_r1cs_json(const uint8_t *data, size_t len, R1cs *out) {
                 uint64_t w = 0; HFr cf;
                 JVal kv; kv.t = JVal::STR; kv.s = t.first;
                 if (!json_u64(&kv, &w) || !fr_from_decimal(t.second, &cf)) { set_error("unable to read: bad term in linear combination"); return false; }
+                if (w >= n_vars) { set_error("unable to read: wire index out of range"); return false; }      // checked before the 32-bit cast
                 abc[k]->push_back({(uint32_t)w, cf});
             }
         }
@@ -406,16 +418,18 @@ extern "C" int32_t plk_circuit_load(const uint8_t *r1cs, uint64_t r1cs_len, int3
                                     const uint8_t *witness, uint64_t witness_len, int32_t witness_is_json, plk_circuit **out) {
     if (!r1cs || !out) { set_error("plk_circuit_load: bad argument"); return PLK_ERR_ARG; }
     *out = nullptr;
-    plk_circuit *c = new plk_circuit();
-    bool ok = r1cs_is_json ? parse_r1cs_json(r1cs, r1cs_len, &c->r1cs) : parse_r1cs_bin(r1cs, r1cs_len, &c->r1cs);
-    if (ok && witness) {
-        ok = witness_is_json ? parse_witness_json(witness, witness_len, &c->witness) : parse_wtns_bin(witness, witness_len, &c->witness);
-        c->has_witness = ok;
-        if (ok && c->witness.size() < c->r1cs.num_variables) { set_error("witness shorter than the number of variables"); ok = false; }
-    }
-    if (!ok) { delete c; return PLK_ERR_FORMAT; }
-    *out = c;
-    return PLK_OK;
+    return guarded("plk_circuit_load", PLK_ERR_FORMAT, [&]() -> int32_t {
+        std::unique_ptr<plk_circuit> c(new plk_circuit());
+        bool ok = r1cs_is_json ? parse_r1cs_json(r1cs, r1cs_len, &c->r1cs) : parse_r1cs_bin(r1cs, r1cs_len, &c->r1cs);
+        if (ok && witness) {
+            ok = witness_is_json ? parse_witness_json(witness, witness_len, &c->witness) : parse_wtns_bin(witness, witness_len, &c->witness);
+            c->has_witness = ok;
+            if (ok && c->witness.size() < c->r1cs.num_variables) { set_error("witness shorter than the number of variables"); ok = false; }
+        }
+        if (!ok) return PLK_ERR_FORMAT;
+        *out = c.release();
+        return PLK_OK;
+    });
 }
 
 void plk_circuit_unregister(plk_circuit *c);
@@ -423,12 +437,14 @@ extern "C" void plk_circuit_free(plk_circuit *c) { if (c) { plk_circuit_unregist
 
 extern "C" int32_t plk_circuit_analyse(const plk_circuit *c, char *out_json, uint64_t cap) {
     if (!c || !out_json) { set_error("plk_circuit_analyse: bad argument"); return PLK_ERR_ARG; }
-    Transpiled t;
-    if (!transpile(c->r1cs, nullptr, &t)) return PLK_ERR_UNSAT;
-    std::string s = analyse_json(c->r1cs, t);
-    if (s.size() + 1 > cap) { set_error("plk_circuit_analyse: buffer too small"); return PLK_ERR_ARG; }
-    memcpy(out_json, s.c_str(), s.size() + 1);
-    return PLK_OK;
+    return guarded("plk_circuit_analyse", PLK_ERR_FORMAT, [&]() -> int32_t {
+        Transpiled t;
+        if (!transpile(c->r1cs, nullptr, &t)) return PLK_ERR_UNSAT;
+        std::string s = analyse_json(c->r1cs, t);
+        if (s.size() + 1 > cap) { set_error("plk_circuit_analyse: buffer too small"); return PLK_ERR_ARG; }
+        memcpy(out_json, s.c_str(), s.size() + 1);
+        return PLK_OK;
+    });
 }
 
 // ------------------------------------------------------------------ synthetic R1CS (bench input)
@@ -470,9 +486,15 @@ struct Xoshiro256ss {
 }  // namespace
 }  // namespace plk
 
+static int32_t circuit_synthetic_impl(uint64_t target_gates, uint64_t seed, plk_circuit **out);
 extern "C" int32_t plk_circuit_synthetic(uint64_t target_gates, uint64_t seed, plk_circuit **out) {
-    if (!out || target_gates < 4) { set_error("plk_circuit_synthetic: bad argument"); return PLK_ERR_ARG; }
-    plk_circuit *c = new plk_circuit();
+    if (!out || target_gates < 4 || target_gates >= (1ull << 28)) { set_error("plk_circuit_synthetic: bad argument"); return PLK_ERR_ARG; }
+    *out = nullptr;
+    return guarded("plk_circuit_synthetic", PLK_ERR_ARG, [&] { return circuit_synthetic_impl(target_gates, seed, out); });
+}
+static int32_t circuit_synthetic_impl(uint64_t target_gates, uint64_t seed, plk_circuit **out) {
+    std::unique_ptr<plk_circuit> holder(new plk_circuit());
+    plk_circuit *c = holder.get();
     Xoshiro256ss rng(seed);
     std::vector<HFr> &w = c->witness;
     w.reserve(target_gates + 8);
@@ -525,14 +547,18 @@ extern "C" int32_t plk_circuit_synthetic(uint64_t target_gates, uint64_t seed, p
     c->r1cs.num_variables = w.size();
     c->r1cs.num_aux = w.size() - 2;
     c->has_witness = true;
-    *out = c;
+    *out = holder.release();
     return PLK_OK;
 }
 
 // exports the circuit in the reference's own file formats (iden3 .r1cs v1 / .wtns v2), so that the
 // same synthetic input can be fed to a real `plonkit` binary (PLONKIT_REF_BIN)
+static int32_t circuit_export_impl(const plk_circuit *c, int32_t what, uint8_t *out, uint64_t cap, uint64_t *len);
 extern "C" int32_t plk_circuit_export(const plk_circuit *c, int32_t what, uint8_t *out, uint64_t cap, uint64_t *len) {
     if (!c || !len) { set_error("plk_circuit_export: bad argument"); return PLK_ERR_ARG; }
+    return guarded("plk_circuit_export", PLK_ERR_ARG, [&] { return circuit_export_impl(c, what, out, cap, len); });
+}
+static int32_t circuit_export_impl(const plk_circuit *c, int32_t what, uint8_t *out, uint64_t cap, uint64_t *len) {
     std::vector<uint8_t> b;
     auto u32 = [&](uint32_t v) { for (int i = 0; i < 4; i++) b.push_back((uint8_t)(v >> (8 * i))); };
     auto u64 = [&](uint64_t v) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(v >> (8 * i))); };

@@ -14,7 +14,20 @@
 #include <vector>
 #include "hostmath.h"
 
+#include <new>
+#include <exception>
+
 namespace plk {
+
+void set_error(const std::string &msg);
+// nothing may unwind through the extern "C" boundary: a std::bad_alloc (a header that announces 2^32 constraints) or any
+// other exception becomes a status code.  The Rust reference panics (aborts the call) at the same places.
+template <class Fn> static inline int32_t guarded(const char *who, int32_t on_alloc, Fn fn) {
+    try { return fn(); }
+    catch (const std::bad_alloc &) { set_error(std::string(who) + ": out of host memory (malformed size field?)"); return on_alloc; }
+    catch (const std::exception &e) { set_error(std::string(who) + ": " + e.what()); return on_alloc; }
+    catch (...) { set_error(std::string(who) + ": unexpected exception"); return on_alloc; }
+}
 
 using host::HFr;
 

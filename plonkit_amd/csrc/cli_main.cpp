@@ -64,12 +64,17 @@ static Args parse(int argc, char **argv, const std::map<std::string, std::string
         std::string s = argv[i];
         if (s == "--overwrite") { a.overwrite = true; continue; }
         std::string key;
+        // an entry "canonical|alias" accepts both long names and stores the value under the canonical one
+        auto canonical = [](const std::string &v) { size_t bar = v.find('|'); return bar == std::string::npos ? v : v.substr(0, bar); };
         if (s.rfind("--", 0) == 0) {
-            key = s.substr(2);
+            const std::string name = s.substr(2);
             bool known = false;
-            for (auto &kv : shorts) if (kv.second == key) known = true;
+            for (auto &kv : shorts) {
+                size_t bar = kv.second.find('|');
+                if (kv.second == name || (bar != std::string::npos && (kv.second.substr(0, bar) == name || kv.second.substr(bar + 1) == name))) { known = true; key = canonical(kv.second); }
+            }
             if (!known) { fprintf(stderr, "error: Found argument '%s' which wasn't expected\n", s.c_str()); exit(2); }
-        } else if (s.size() == 2 && s[0] == '-' && shorts.count(s.substr(1))) key = shorts.at(s.substr(1));
+        } else if (s.size() == 2 && s[0] == '-' && shorts.count(s.substr(1))) key = canonical(shorts.at(s.substr(1)));
         else { fprintf(stderr, "error: Found argument '%s' which wasn't expected\n", s.c_str()); exit(2); }
         if (i + 1 >= argc) { fprintf(stderr, "error: The argument '%s' requires a value\n", s.c_str()); exit(2); }
         a.kv[key] = argv[++i];
@@ -241,6 +246,10 @@ static int run(int argc, char **argv) {
         fprintf(stderr, "Proving...\n");
         std::vector<uint8_t> buf(1 << 16); uint64_t len = 0;
         int32_t rc = plk_prove(ctx, s, c, buf.data(), buf.size(), &len);
+        if (rc == PLK_ERR_ARG && len > buf.size()) {                 // many public inputs: the call reports the size it needs
+            buf.resize(len);
+            rc = plk_prove(ctx, s, c, buf.data(), buf.size(), &len);
+        }
         if (rc == PLK_ERR_UNSAT) { fprintf(stderr, "must satisfy: %s\n", plk_last_error()); return 101; }
         if (rc != PLK_OK) die("prove", rc);
         phase("prove");
@@ -259,9 +268,11 @@ static int run(int argc, char **argv) {
         spit(ij, reinterpret_cast<const uint8_t *>(is.data()), is.size());
         fprintf(stderr, "Public input json saved to %s\n", ij.c_str());
     } else if (cmd == "verify") {                                    // src/bin/main.rs:425-437 (no GPU involved)
-        Args a = parse(argc, argv, {{"p", "proof"}, {"v", "vk"}, {"t", "transcript"}});
+        // VerifyOpts (src/bin/main.rs:125-137): the key is `-v` / `--verification_key` here, while export-verification-key
+        // names its output `--vk` (src/bin/main.rs:186-187); `--vk` is kept as an alias on verify
+        Args a = parse(argc, argv, {{"p", "proof"}, {"v", "verification_key|vk"}, {"t", "transcript"}});
         if (a.get("transcript", "keccak") != "keccak") { fprintf(stderr, "not implemented: transcript '%s' (only keccak; rescue needs franklin-crypto)\n", a.get("transcript").c_str()); return 101; }
-        std::vector<uint8_t> vk = slurp(a.get("vk", "vk.bin"), "read vk file err"), pr = slurp(a.get("proof", "proof.bin"), "read proof file err");
+        std::vector<uint8_t> vk = slurp(a.get("verification_key", "vk.bin"), "read vk file err"), pr = slurp(a.get("proof", "proof.bin"), "read proof file err");
         int32_t valid = 0;
         CK("fail to verify proof", plk_verify(vk.data(), vk.size(), pr.data(), pr.size(), &valid));
         if (valid) fprintf(stderr, "Proof is valid.\n");

@@ -104,9 +104,18 @@ void g1_to_bytes(const HAffine &p, uint8_t out[64]) {
     p.x.to_be_bytes(out); p.y.to_be_bytes(out + 32);
 }
 
+// pairing_ce's G1Uncompressed::into_affine_unchecked: the infinity flag must come with an all-zero remainder, and the
+// coordinates (0, 0) without the flag are an ordinary (off-curve) point, not infinity — both are refused there
 bool g1_from_bytes(const uint8_t in[64], HAffine *out) {
-    if (in[0] & 0x40) { out->x = HFq::zero(); out->y = HFq::zero(); return true; }
-    return HFq::from_be_bytes(in, &out->x) && HFq::from_be_bytes(in + 32, &out->y);
+    if (in[0] & 0x40) {
+        if (in[0] != 0x40) return false;
+        for (int i = 1; i < 64; i++) if (in[i]) return false;
+        out->x = HFq::zero(); out->y = HFq::zero();
+        return true;
+    }
+    if (in[0] & 0x80) return false;                       // compression flag on an uncompressed encoding
+    if (!HFq::from_be_bytes(in, &out->x) || !HFq::from_be_bytes(in + 32, &out->y)) return false;
+    return !(out->x.is_zero() && out->y.is_zero());       // (0, 0) unflagged: not on the curve
 }
 
 }  // namespace plk

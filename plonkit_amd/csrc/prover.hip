@@ -68,6 +68,8 @@ static int32_t enqueue_pieces(plk_ctx *ctx, const Fr *const *vecs, uint32_t cnt,
     return PLK_OK;
 }
 static int32_t finish_pieces(plk_ctx *ctx, uint32_t cnt, HJac *j) {
+    if (ctx->msm_fin != ctx->msm_enq && ctx->slot[ctx->msm_fin & 1].batch != cnt) {      // never pop somebody else's commitment
+        set_error("commitment FIFO out of step: the slot in flight holds a different batch than the prover enqueued"); return PLK_ERR_ARG; }
     PLK_TRY(msm_finish_batch(ctx, nullptr, j));
     if (!ctx->commit_pieces.empty()) {
         for (uint32_t k = 0; k < cnt; k++) j[k] = jac_add(j[k], ctx->commit_pieces[k]);
@@ -87,7 +89,7 @@ static int32_t commit_begin(plk_ctx *ctx, const Fr *const *vecs, uint32_t count,
     ctx->commit_done.clear();
     // at the largest sizes a batch of commitments would need gigabytes of per-task partial-sum slots (2^26 gates: 16 GiB for
     // four wires, which is what stands between that domain and the 288 GB): one commitment at a time there
-    if (count > 1 && hi - lo >= msm_piece_terms()) {
+    if (count > 1 && hi - lo > msm_piece_terms()) {
         for (uint32_t k = 0; k + 1 < count; k++) {
             HJac j;
             PLK_TRY(enqueue_pieces(ctx, vecs + k, 1, lo, hi, first_base));
@@ -125,6 +127,27 @@ static int32_t commit_many(plk_ctx *ctx, const Fr *const *coefs, uint32_t count,
     }
     return PLK_OK;
 }
+
+// plk_prove / plk_setup_write_vk own the two-slot commitment FIFO for the duration of the call: it must be empty on
+// entry (a commitment the caller enqueued with plk_msm_g1_enqueue_dev and never finished would otherwise be popped as
+// one of the prover's), and whatever an early error return leaves in flight is drained before the call returns.
+static int32_t fifo_must_be_empty(plk_ctx *ctx, const char *who) {
+    if (ctx->msm_enq == ctx->msm_fin) return PLK_OK;
+    set_error(std::string(who) + ": a commitment enqueued with plk_msm_g1_enqueue_dev is still in flight (call plk_msm_g1_finish first)");
+    return PLK_ERR_ARG;
+}
+struct FifoGuard {
+    plk_ctx *ctx;
+    explicit FifoGuard(plk_ctx *c) : ctx(c) {}
+    ~FifoGuard() {
+        if (ctx->msm_fin != ctx->msm_enq) {
+            const std::string keep = plk_last_error();               // the drain must not replace the error being returned
+            while (ctx->msm_fin != ctx->msm_enq) { HJac j[8]; (void)msm_finish_batch(ctx, nullptr, j); }
+            set_error(keep);
+        }
+        ctx->commit_done.clear(); ctx->commit_pieces.clear();
+    }
+};
 
 struct Arena {
     DevBuf *buf; size_t off = 0;
@@ -168,7 +191,7 @@ extern "C" {
 uint64_t plk_setup_domain_size(const plk_setup *s) { return s ? s->N : 0; }
 void plk_setup_free(plk_setup *s) { if (s) { s->store.release(); s->lde_store.release(); s->ops_dev.release(); s->terms_dev.release(); delete s; } }
 
-int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
+static int32_t setup_prepare_impl(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
     if (!ctx || !c || !out) { set_error("plk_setup_prepare: bad argument"); return PLK_ERR_ARG; }
     *out = nullptr;
     PLK_HIP(hipSetDevice(ctx->device));
@@ -284,9 +307,11 @@ static void put_u64(std::vector<uint8_t> &b, uint64_t v) { for (int i = 7; i >= 
 static void put_g1(std::vector<uint8_t> &b, const HAffine &p) { uint8_t t[64]; g1_to_bytes(p, t); b.insert(b.end(), t, t + 64); }
 static void put_fr(std::vector<uint8_t> &b, const HFr &v) { uint8_t t[32]; v.to_be_bytes(t); b.insert(b.end(), t, t + 32); }
 
-int32_t plk_setup_write_vk(plk_ctx *ctx, const plk_setup *s, const uint8_t g2_bytes[256], uint8_t *out, uint64_t cap, uint64_t *len) {
+static int32_t setup_write_vk_impl(plk_ctx *ctx, const plk_setup *s, const uint8_t g2_bytes[256], uint8_t *out, uint64_t cap, uint64_t *len) {
     if (!ctx || !s || !g2_bytes || !out || !len) { set_error("plk_setup_write_vk: bad argument"); return PLK_ERR_ARG; }
     PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(fifo_must_be_empty(ctx, "plk_setup_write_vk"));
+    FifoGuard fifo_guard(ctx);
     std::vector<uint8_t> b;
     put_u64(b, s->n); put_u64(b, s->num_inputs);
     HAffine cm[11];
@@ -318,11 +343,14 @@ int32_t plk_prove_timings(const plk_ctx *ctx, double *out_ms, uint32_t cap, uint
     return PLK_OK;
 }
 
-int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_t *proof_out, uint64_t cap, uint64_t *len) {
+static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_t *proof_out, uint64_t cap, uint64_t *len) {
     if (!ctx || !S || !c || !proof_out || !len) { set_error("plk_prove: bad argument"); return PLK_ERR_ARG; }
+    *len = 0;
     if (!c->has_witness) { set_error("plk_prove: circuit has no witness"); return PLK_ERR_ARG; }
     PLK_HIP(hipSetDevice(ctx->device));
     if (!ctx->srs || (!ctx->combine && ctx->srs_n < S->N)) { set_error("SRS too small for this circuit"); return PLK_ERR_SRS; }
+    PLK_TRY(fifo_must_be_empty(ctx, "plk_prove"));
+    FifoGuard fifo_guard(ctx);
     ctx->timings.clear();
     double t_prev = now_ms();
     auto lap = [&]() { double t = now_ms(); ctx->timings.push_back(t - t_prev); t_prev = t; };
@@ -469,7 +497,8 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
         if (!S->lde_ready) {
             // the coset-point vector is a convenience (one load instead of two loads and two products per point):
             // above 2^24 gates its 4N * 32 bytes are better spent elsewhere (2^26 would not fit in 288 GB)
-            const bool cache_x = log_n <= 24;
+            static const bool no_cache_env = getenv("PLK_NO_COSET_CACHE") != nullptr;       // tests: the large-domain branch at a small size
+            const bool cache_x = log_n <= 24 && !no_cache_env;
             PLK_TRY(S->lde_store.reserve((cache_x ? 13 : 12) * MB));
             Arena LA{&S->lde_store};
             for (int k = 0; k < (cache_x ? 13 : 12); k++) S->lde[k] = LA.take<Fr>(M);
@@ -616,6 +645,17 @@ int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_
     memcpy(proof_out, b.data(), b.size());
     lap();                                                                    // [6] serialise
     return PLK_OK;
+}
+
+// the exported entry points: no C++ exception (std::bad_alloc from a host vector of a 2^26 domain) crosses the boundary
+int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
+    return guarded("plk_setup_prepare", PLK_ERR_HIP, [&] { return setup_prepare_impl(ctx, c, out); });
+}
+int32_t plk_setup_write_vk(plk_ctx *ctx, const plk_setup *s, const uint8_t g2_bytes[256], uint8_t *out, uint64_t cap, uint64_t *len) {
+    return guarded("plk_setup_write_vk", PLK_ERR_HIP, [&] { return setup_write_vk_impl(ctx, s, g2_bytes, out, cap, len); });
+}
+int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_t *proof_out, uint64_t cap, uint64_t *len) {
+    return guarded("plk_prove", PLK_ERR_HIP, [&] { return prove_impl(ctx, S, c, proof_out, cap, len); });
 }
 
 }  // extern "C"

@@ -16,6 +16,9 @@ using namespace plk::host;
 
 namespace {
 
+template <class T> constexpr uint64_t sizeof_item() { return 64; }              // G1 (uncompressed)
+template <> constexpr uint64_t sizeof_item<HFr>() { return 32; }
+
 struct Reader {
     const uint8_t *p; uint64_t left; bool ok = true;
     uint64_t u64() {
@@ -43,7 +46,7 @@ struct Reader {
     }
     template <class T, class Fn> bool vec(std::vector<T> &out, uint64_t expect, Fn rd) {
         uint64_t n = u64();
-        if (!ok || (expect && n != expect) || n > 1024) { ok = false; return false; }
+        if (!ok || (expect && n != expect) || n > left / sizeof_item<T>()) { ok = false; return false; }   // bounded by the bytes that are left
         for (uint64_t i = 0; i < n && ok; i++) out.push_back(rd());
         return ok;
     }

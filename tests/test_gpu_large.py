@@ -1,0 +1,181 @@
+"""-m gpu: the BASELINE.json configurations above 2^20, checked on the device the driver gives the test tier.
+
+  configs[2]  "Synthetic R1CS 2^24 constraints, SRS 2^24": one 2^24-term commitment against the tau = 42 trapdoor
+              answer (uniform and witness-like scalars), a whole prove at the 2^22 and 2^24 domains accepted by the
+              host verifier (real pairing) and rejected after tampering; two ranks with a sliced SRS at the 2^20 domain
+              (tests/test_gpu_sharded_prove.py holds the small sizes).
+  configs[3]  dump-lagrange at 2^20: out_i = L_i(42) * G at 64 indices and sum_i out_i = G.
+  configs[4]  the recursive prover's kernel shapes: NTT 2^24 and 2^26 (round trip, linearity, evaluation at four
+              points), MSM 2^24 (the first item).
+  Reference sizes: SETUP_MAX_POW2 = 26 (src/plonk.rs:26-27), the 2^24 key of test/test_poseidon_plonk_recursive.sh:8,28.
+
+The oracle cannot re-run these sizes in test time, so each check is a size-independent property computed on the host
+with the oracle's serial C arithmetic (Horner evaluation, one scalar multiplication) — never a second GPU result."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle_lib as ol
+from oracle.oracle_lib import R_MOD
+
+
+def _rand_fr(n, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)          # < 2^252 < r: valid Montgomery residues
+    return a
+
+
+def _trapdoor(s):
+    """MSM(s, crs_42) = s(42) * G: one Horner pass in the oracle's C arithmetic + one scalar multiplication"""
+    return ol.g1_mul(ol.g1_generator(), ol.poly_eval(s, 42))
+
+
+@pytest.fixture(scope="module")
+def ctx24():
+    """one context holding the 2^24-point tau = 42 key (1 GiB) and its fixed-base table (15 GiB), shared by the
+    commitment and the prove tests of this module"""
+    import plonkit_amd as pa
+    c = pa.Context(0)
+    c.srs_generate(1 << 24, 0, 42)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "witness_like"])
+def test_msm_2pow24_trapdoor(ctx24, kind):
+    import torch
+    n = 1 << 24
+    s = _rand_fr(n, 2400)
+    if kind == "witness_like":                    # 50 % zero, 25 % below 2^16, 25 % uniform
+        rng = np.random.default_rng(7)
+        sel = rng.integers(0, 4, size=n)
+        s[sel < 2] = 0
+        small = ol.fr_vec(list(range(1 << 16)))   # Montgomery forms of 0 .. 65535
+        idx = np.nonzero(sel == 2)[0]
+        s[idx] = small[rng.integers(0, 1 << 16, size=idx.shape[0])]
+    want = _trapdoor(s)
+    d = torch.from_numpy(s.view(np.int64)).to("cuda:0")
+    torch.cuda.synchronize()
+    assert np.array_equal(ctx24.msm_dev(d, n), want)
+    # the same vector through the host entry point (staging copy) and as the sum of two half-length commitments
+    half = n // 2
+    lo = ctx24.msm_partial_dev(d, half)
+    hi = ctx24.msm_partial_dev(d[half:], half, base_offset=half)
+    import plonkit_amd as pa
+    assert np.array_equal(pa.g1_sum_jacobian(np.stack([lo, hi])), want)
+
+
+@pytest.mark.parametrize("log_n", [24, 26])
+def test_ntt_recursive_prover_shapes(log_n):
+    """NTT 2^24 (N) and 2^26 (4N) of the recursive circuit: round trip, linearity, evaluation at four points"""
+    import torch
+    import plonkit_amd as pa
+    ctx = pa.Context(0)
+    n = 1 << log_n
+    a, b = _rand_fr(n, 10 + log_n), _rand_fr(n, 20 + log_n)
+    dev = torch.device("cuda:0")
+    ta = torch.from_numpy(a.view(np.int64)).to(dev)
+    ctx.ntt_dev(ta, log_n)
+    ctx.synchronize()
+    fa = ta.cpu().numpy().view(np.uint64)
+    w = ol.omega(log_n)
+    for k in (0, 1, 123456789 % n, n - 1):
+        assert ol.fr_ints(fa[k:k + 1])[0] == ol.poly_eval(a, pow(w, k, R_MOD)), k
+    ctx.ntt_dev(ta, log_n, inverse=True)
+    ctx.synchronize()
+    assert np.array_equal(ta.cpu().numpy().view(np.uint64), a)
+    tb = torch.from_numpy(b.view(np.int64)).to(dev)
+    ctx.ntt_dev(tb, log_n)
+    ts = torch.from_numpy(ol.vadd(a, b).view(np.int64)).to(dev)
+    ctx.ntt_dev(ts, log_n)
+    ctx.synchronize()
+    assert np.array_equal(ts.cpu().numpy().view(np.uint64), ol.vadd(fa, tb.cpu().numpy().view(np.uint64)))
+    # coset variant (the 4N evaluation domain of round 3): f(7 * w^k) at two points, and back
+    g = ol.fr_mont(7)
+    ctx.ntt_dev(ta, log_n, coset=g)
+    ctx.synchronize()
+    fc = ta.cpu().numpy().view(np.uint64)
+    for k in (5, n - 2):
+        assert ol.fr_ints(fc[k:k + 1])[0] == ol.poly_eval(a, 7 * pow(w, k, R_MOD) % R_MOD), k
+    ctx.ntt_dev(ta, log_n, inverse=True, coset=g)
+    ctx.synchronize()
+    assert np.array_equal(ta.cpu().numpy().view(np.uint64), a)
+    del ta, tb, ts
+    ctx.close()
+
+
+@pytest.mark.parametrize("log_n", [22, 24])
+def test_prove_large_domain_verifies(ctx24, log_n):
+    """whole prove (setup_prepare + 5 rounds) at the 2^22 and 2^24 domains on the 2^24 key: the library's host verifier
+    (real pairing) and the oracle's restatement of contrib/template.sol accept the proof against the GPU-made
+    verification key, both reject it after tampering with an evaluation or a commitment, proving twice gives the same
+    bytes."""
+    import plonkit_amd as pa
+    from oracle import plonk_oracle as po
+    circ = pa.Circuit.synthetic((1 << log_n) - 2)
+    setup = pa.SetupForProver(ctx24, circ)
+    assert setup.domain_size == 1 << log_n
+    vk_bytes = setup.verification_key_bytes(pa.crs42_g2_bytes())
+    proof = setup.prove(circ)
+    assert setup.prove(circ) == proof
+    assert pa.verify(vk_bytes, proof)
+    vk, P = po.read_vk(vk_bytes), po.read_proof(proof)
+    assert P.n == (1 << log_n) - 1 and len(P.inputs) == 1
+    assert po.verify(vk, P, tau=42)
+    P.linearization_polynomial_at_z = (P.linearization_polynomial_at_z + 1) % R_MOD
+    assert not pa.verify(vk_bytes, po.write_proof(P)) and not po.verify(vk, P, tau=42)
+    bad = bytearray(proof)
+    other = pa.g1_to_bytes(ol.g1_generator())
+    off = 8 + 8 + 32 + 8                                  # n, inputs (len + 1 value), wire-commitment count
+    bad[off:off + 64] = other                             # first wire commitment replaced by G
+    assert not pa.verify(vk_bytes, bytes(bad))
+    setup.close(); circ.close()
+
+
+def test_dump_lagrange_2pow20():
+    """configs[3]: SRS 2^20 monomial -> Lagrange on one GPU (Crs::<Lagrange>::from_powers, src/plonk.rs:179-185)"""
+    import torch
+    import plonkit_amd as pa
+    log_n = 20
+    n = 1 << log_n
+    ctx = pa.Context(0)
+    ctx.srs_generate(n, 0, 42)
+    out = torch.empty((n, 8), dtype=torch.int64, device="cuda:0")
+    ctx.g1_intt_srs_dev(log_n, out)
+    ctx.synchronize()
+    res = out.cpu().numpy().view(np.uint64)
+    w, G = ol.omega(log_n), ol.g1_generator()
+    zh = (pow(42, n, R_MOD) - 1) % R_MOD
+    rnd = random.Random(log_n)
+    for i in [0, 1, n - 1] + [rnd.randrange(n) for _ in range(61)]:
+        wi = pow(w, i, R_MOD)
+        li = wi * zh % R_MOD * pow(n * (42 - wi) % R_MOD, -1, R_MOD) % R_MOD
+        assert np.array_equal(res[i], ol.g1_mul(G, li)), i
+    one = np.array([0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f], dtype=np.uint64)
+    jac = np.concatenate([res, np.tile(one, (n, 1))], axis=1)
+    jac[~res.any(axis=1), 8:] = 0
+    assert np.array_equal(pa.g1_sum_jacobian(jac), G)              # sum_i L_i(tau) = 1
+    # and the Lagrange key commits evaluations to what the monomial key commits coefficients to
+    vals = _rand_fr(n, 77)
+    coeffs = torch.from_numpy(vals.view(np.int64)).to("cuda:0")
+    ctx.ntt_dev(coeffs, log_n, inverse=True)
+    ctx.synchronize()
+    mono = ctx.msm_dev(coeffs, n)
+    lag = pa.Context(0)
+    lag.srs_set_dev(out, n)
+    dv = torch.from_numpy(vals.view(np.int64)).to("cuda:0")
+    torch.cuda.synchronize()
+    assert np.array_equal(lag.msm_dev(dv, n), mono)
+    lag.close(); ctx.close()
+
+
+def test_two_ranks_sliced_srs_2pow20():
+    """configs[2] at the size one test GPU can host twice: two ranks (sharing device 0, gloo) with half of the 2^20
+    key each reproduce the single-GPU verification key and proof bytes"""
+    from tests.test_gpu_sharded_prove import test_two_ranks_produce_the_single_gpu_proof as run
+    run(20, False)

@@ -93,6 +93,65 @@ def test_r1cs_bin_loader_matches_oracle_and_rejects_bad_input(golden_dir):
         pa.Circuit(bytes(hdr_bad), False)
 
 
+def test_malformed_circuit_files_are_refused(golden_dir):
+    """wire ids outside [0, n_wires) and size fields that exceed the file: the reference indexes its
+    variable table with the wire id and panics (src/circom_circuit.rs:107-113); here the loaders return PLK_ERR_FORMAT
+    instead of writing past the ends of the setup's tables, and nothing unwinds through the C ABI"""
+    import json
+    data = bytearray(open(os.path.join(golden_dir, "r1cs_sample.bin"), "rb").read())
+    r1 = po.load_r1cs_bin(bytes(data))
+    n_wires = r1.num_variables
+    # locate the first wire id of the constraint section: header (12) + section table walk
+    off, secs = 12, {}
+    for _ in range(struct.unpack_from("<I", data, 8)[0]):
+        t, sz = struct.unpack_from("<IQ", data, off)
+        secs[t] = (off + 12, sz)
+        off += 12 + sz
+    c0 = secs[2][0]
+    assert struct.unpack_from("<I", data, c0)[0] >= 1                 # first LC has at least one term
+    for wire in (n_wires, 0x7fffffff, 0xffffffff):
+        bad = bytearray(data)
+        struct.pack_into("<I", bad, c0 + 4, wire)
+        with pytest.raises(pa.PlkError) as e:
+            pa.Circuit(bytes(bad), False)
+        assert e.value.code == 6 and "wire index" in str(e.value)
+    ok = bytearray(data)
+    struct.pack_into("<I", ok, c0 + 4, n_wires - 1)                   # the largest valid id still loads
+    pa.Circuit(bytes(ok), False)
+    # header announcing 2^32 - 1 constraints in a 200-byte file: refused before anything is allocated
+    h0 = secs[1][0]
+    huge = bytearray(data)
+    struct.pack_into("<I", huge, h0 + 4 + 32 + 16 + 8, 0xffffffff)    # field_size, prime, 4 x u32, u64 labels, then n_constraints
+    with pytest.raises(pa.PlkError) as e:
+        pa.Circuit(bytes(huge), False)
+    assert e.value.code == 6
+    # JSON: wire id >= nVars, and one that only fits 64 bits (it used to be truncated to 32)
+    js = json.loads(open(os.path.join(golden_dir, "circuit.r1cs.json")).read())
+    for wire in (str(js["nVars"]), str((1 << 32) + 1), str(1 << 70)):
+        bad = json.loads(json.dumps(js))
+        bad["constraints"][0][0] = {wire: "1"}
+        with pytest.raises(pa.PlkError) as e:
+            pa.Circuit(json.dumps(bad).encode(), True)
+        assert e.value.code == 6
+    bad = json.loads(json.dumps(js)); bad["nVars"] = 1 << 40
+    with pytest.raises(pa.PlkError):
+        pa.Circuit(json.dumps(bad).encode(), True)
+
+
+def test_point_encoding_is_canonical():
+    """pairing_ce refuses an infinity flag with a non-zero remainder and the unflagged (0, 0): so do
+    plk_g1_from_bytes, the key parser and the verifier's readers"""
+    inf = b"\x40" + b"\x00" * 63
+    assert not pa.g1_from_bytes(inf).any()
+    for bad in (b"\x40" + b"\x00" * 62 + b"\x01", b"\x41" + b"\x00" * 63, b"\x00" * 64, b"\xc0" + b"\x00" * 63):
+        with pytest.raises(pa.PlkError):
+            pa.g1_from_bytes(bad)
+    g = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
+    assert pa.g1_to_bytes(pa.g1_from_bytes(g)) == g
+    with pytest.raises(pa.PlkError):
+        pa.g1_from_bytes(b"\x80" + g[1:])                             # compression flag on an uncompressed encoding
+
+
 def test_witness_loaders(golden_dir):
     r = open(os.path.join(golden_dir, "circuit.r1cs.json"), "rb").read()
     w = [1, 35, 3, 9]
@@ -170,6 +229,16 @@ def test_cli_analyse_and_flag_surface(golden_dir, tmp_path):
     assert subprocess.call([cli, "setup", "-p", "10"], stderr=subprocess.DEVNULL) == 2
     assert subprocess.call([cli, "prove", "--bogus", "1"], stderr=subprocess.DEVNULL) == 2
     assert subprocess.call([cli, "frobnicate"], stderr=subprocess.DEVNULL) == 2
+    # verify (pure CPU): the key option is -v / --verification_key as in the reference (src/bin/main.rs:130-134); --vk stays an alias
+    vk, proof = os.path.join(golden_dir, "vk.bin"), os.path.join(golden_dir, "proof.bin")
+    for flag in ("-v", "--verification_key", "--vk"):
+        assert subprocess.call([cli, "verify", "-p", proof, flag, vk], stderr=subprocess.DEVNULL) == 0, flag
+    assert subprocess.call([cli, "verify", "--proof", proof, "--verification_key", vk, "-t", "keccak"], stderr=subprocess.DEVNULL) == 0
+    bad = tmp_path / "bad_proof.bin"
+    raw = bytearray(open(proof, "rb").read()); raw[-70] ^= 1
+    bad.write_bytes(bytes(raw))
+    assert subprocess.call([cli, "verify", "-p", str(bad), "--verification_key", vk], stderr=subprocess.DEVNULL) != 0
+    assert subprocess.call([cli, "export-verification-key", "--verification_key", "x"], stderr=subprocess.DEVNULL) == 2   # that command spells it --vk
 
 
 def test_synthetic_circuit_generator_is_stable():
