@@ -9,14 +9,26 @@ A step = one KZG commitment (G1 MSM) of 2^20 uniform scalars per GPU against tha
 shard of a tau = 42 monomial SRS (BASELINE.json configs[1]; with N GPUs the job is one commitment
 of N*2^20 terms with the bases split across ranks, partial sums exchanged over RCCL — "weak").
 `value` = total scalar·muls per second over all ranks, inputs resident in HBM.
-The one JSON line also carries `roofline` (dominant kernel: msm_accumulate, HIP-event timed),
-`cpu_baseline` (oracle restatement of bellman's dense_multiexp on the host cores, bounded sample)
-and, at N=1, `prove` (wall-clock of a full prove at the 2^20 domain once the prover is built in).
+
+The one JSON line also carries
+  roofline      dominant kernel msm_accumulate.  `kernel_ms` is its HIP-event duration with ONE commitment in flight
+                (--pipeline-depth 1 region, timed right after the headline region); `kernel_ms_pipelined` is what the
+                same kernel takes inside the headline region, where it shares the GPU with the bucket reduction of the
+                previous commitment.  `valu` prices the kernel against the measured v_mad_u64_u32 issue rate.
+  cpu_baseline  the oracle's restatement of bellman's dense_multiexp / best_fft / prove on the host cores (kind "port"),
+                MSM and NTT at 2^20, whole prove at the 2^20 domain; with PLONKIT_REF_BIN set, also the real
+                `plonkit prove` on the same files (kind "reference").
+  prove         (N = 1) wall-clock of a full prove at the 2^20 domain: warm (tables, cached extensions, allocations
+                in place) and cold (first proof of a fresh context).
+  strong        (N > 1) ONE 2^24-term commitment with the SRS split 2^24/N per rank (BASELINE.json configs[2]) next
+                to the same commitment on rank 0 alone: the figure north_star's ">= 6x at 1 -> 8 GPUs" reads.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 # the library keeps two commitments in flight on two streams; with HIP's default of 4 hardware queues per device
@@ -37,8 +49,17 @@ ALGO_BYTES_PER_TERM = 96         # 64 B base + 32 B scalar
 # = 1.007 GB, + 63 MB of sorted entries: the counter is consistent with 64 B per gather, i.e. no
 # over-fetch) + 63,146 KB written (lane partial sums).  Only valid for --log-n 20, N=1.
 PMC_TRAFFIC_BYTES_2POW20 = (1034100 + 63146) * 1024
-MSM_WINDOWS = 15                # 17-bit signed windows over the 254-bit scalars: mixed additions per term
-VALU_PEAK_GMADD = 15.6           # tools/ubench_w: isolated mixed-addition loop, G additions/s (profiles/r01_ubench_w.txt)
+MSM_WINDOWS = 15                 # 17-bit signed windows over the 254-bit scalars: mixed additions per term
+# VALU yardsticks.  Hardware: v_mad_u64_u32 issues at 576.1 G wave-instructions/s chip-wide
+# (profiles/r01_ubench_int.txt, k_mad64: 4.27 cycles per wave-instruction per SIMD at 2.4 GHz) = 36.87 T lane-mads/s;
+# one XYZZ mixed addition on the 9 x 29-bit layer is 1467 of them (6 products of 162 + 2 squarings of 126 + one fused
+# double product of 243; counted in the hot block of the code object) -> 25.1 G mixed additions/s if nothing but the
+# multiply-adds were issued.  The loop as compiled (1467 mads + 817 other VALU instructions per addition) reaches
+# 15.6 G/s in isolation (tools/ubench_w, profiles/r01_ubench_w.txt).
+MAD_RATE_TLANE_S = 576.11e9 * 64 / 1e12
+MADS_PER_MIXED_ADD = 1467
+VALU_PEAK_GMADD = MAD_RATE_TLANE_S * 1e3 / MADS_PER_MIXED_ADD
+LOOP_ISOLATED_GMADD = 15.6
 
 
 def rand_scalars(n, seed, device):
@@ -50,7 +71,8 @@ def rand_scalars(n, seed, device):
     return t
 
 
-def cpu_baseline(ctx, log_sample, seed):
+# ------------------------------------------------------------------------------------------ CPU baselines
+def cpu_msm_baseline(ctx, log_sample, seed):
     """bellman dense_multiexp restatement (oracle/, kind "port") on the host cores, bounded sample"""
     from oracle import oracle_lib as ol          # checker / baseline only — never on the product path
     m = 1 << log_sample
@@ -58,21 +80,56 @@ def cpu_baseline(ctx, log_sample, seed):
     rng = np.random.default_rng(seed)
     s = rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64)
     s[:, 3] &= np.uint64((1 << 60) - 1)
-    # the restatement keeps bellman's per-thread bucket arrays, whose reduction grows with the thread count: on the
-    # 256-core GPU host 16 threads is the fastest setting (profiles/r01_cpu_msm_threads.txt: 1.49 M/s at 16, 0.06 at 256)
-    cores = min(os.cpu_count() or 1, 16)
-    ol.msm(bases[:1024], s[:1024], threads=cores)            # warm the library
-    t0 = time.perf_counter()
-    ref = ol.msm(bases, s, threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": m / dt / 1e6, "unit": "Mscalar·mul/s", "cores": cores, "kind": "port",
+    # the restatement keeps bellman's per-thread bucket arrays (each thread owns 2^c - 1 Jacobian buckets and sums them
+    # once per window), so its reduction cost grows with the thread count: on the 256-core GPU host 16 threads is the
+    # fastest setting (profiles/r01_cpu_msm_threads.txt: 1.49 M/s at 16, 0.06 at 256).  Both are timed and the better
+    # one is the baseline.
+    ncpu = os.cpu_count() or 1
+    ol.msm(bases[:1024], s[:1024], threads=min(ncpu, 16))     # warm the library
+    best = None
+    tried = {}
+    for cores in sorted({min(ncpu, 16), min(ncpu, 64)}):
+        t0 = time.perf_counter()
+        ref = ol.msm(bases, s, threads=cores)
+        dt = time.perf_counter() - t0
+        tried[str(cores)] = round(m / dt / 1e6, 3)
+        if best is None or dt < best[0]:
+            best = (dt, cores, ref)
+    dt, cores, ref = best
+    return {"value": m / dt / 1e6, "unit": "Mscalar·mul/s", "cores": cores, "kind": "port", "host_cores": ncpu,
+            "by_threads_Mscalar_mul_s": tried,
             "sample": "one dense_multiexp (c=ceil(ln n), per-thread buckets) of 2^%d uniform scalars, %.2f s" % (log_sample, dt)}, ref, s
 
 
+def cpu_ntt_baseline(sizes=(20, 22)):
+    """bellman best_fft restatement: serial radix-2 below log2(cpus), the classic split into
+    2^log_cpus interleaved sub-FFTs above; timed at 16 threads and at every host core, the better one is reported"""
+    from oracle import oracle_lib as ol
+    ncpu = os.cpu_count() or 1
+    out = {}
+    for log_n in sizes:
+        n = 1 << log_n
+        rng = np.random.default_rng(log_n)
+        a = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        best = None
+        for cores in sorted({min(ncpu, 16), ncpu}):
+            t0 = time.perf_counter()
+            ol.ntt(a, log_n, threads=cores)
+            dt = time.perf_counter() - t0                    # (includes one 32*n-byte copy, as bellman's Polynomial::fft moves its input)
+            if best is None or dt < best[0]:
+                best = (dt, cores)
+        out["ntt_2^%d" % log_n] = {"ms": round(best[0] * 1e3, 2), "cores": best[1], "kind": "port",
+                                   "algorithmic_GBs": round(64 * n / best[0] / 1e9, 2)}
+    return out
+
+
 def cpu_prove_baseline(ctx, log_domain):
-    """the oracle's restatement of the whole prove (numpy glue + OpenMP C kernels, kind "port") on a smaller
-    domain than the headline one, beside the HIP prover on the SAME circuit, witness and SRS; the two proofs
-    must be byte-identical.  Bounded sample: 2^16 gates is ~5-10 s of CPU work."""
+    """the oracle's restatement of the whole prove (numpy / Python glue + OpenMP C kernels, kind "port") at the
+    headline domain, beside the HIP prover on the SAME circuit, witness and SRS; the two proofs must be
+    byte-identical.  `cpu_c_kernels_s` is the part of the CPU time spent inside the C arithmetic (11 MSM, 25
+    NTT-equivalents, vector passes); the remainder is Python glue a compiled prover would not pay, so the ratio against
+    `cpu_c_kernels_s` is the conservative one."""
     import plonkit_amd as pa
     from oracle import oracle_lib as ol, plonk_oracle as po      # checker / baseline only
     circ = pa.Circuit.synthetic((1 << log_domain) - 2)
@@ -80,22 +137,64 @@ def cpu_prove_baseline(ctx, log_domain):
     srs_keep = ctx.srs_size()
     ctx.srs_generate(1 << log_domain, 0, 42)
     crs = po.Crs(ctx.srs_download(0, 1 << log_domain), b"\x01" * 256)
+    t0 = time.perf_counter()
     S = po.setup(r1cs)
+    setup_s = time.perf_counter() - t0
+    ol.C_SECONDS[0] = 0.0
     t0 = time.perf_counter()
     ref = po.write_proof(po.prove(r1cs, wit, crs, S))
     cpu_s = time.perf_counter() - t0
+    c_s = ol.C_SECONDS[0]
     setup = pa.SetupForProver(ctx, circ)
     setup.prove(circ)
     t0 = time.perf_counter()
     got = setup.prove(circ)
     gpu_s = time.perf_counter() - t0
     setup.close(); circ.close()
-    ctx.srs_generate(srs_keep, 0, 42)
-    return {"domain": 1 << log_domain, "cpu_s": round(cpu_s, 3), "gpu_s": round(gpu_s, 5), "threads": ol.ncpu(),
-            "kind": "port", "proof_bytes_identical": bool(got == ref),
+    if srs_keep:
+        ctx.srs_generate(srs_keep, 0, 42)
+    return {"domain": 1 << log_domain, "cpu_s": round(cpu_s, 3), "cpu_c_kernels_s": round(c_s, 3), "cpu_setup_s": round(setup_s, 2),
+            "gpu_s": round(gpu_s, 5), "threads": ol.ncpu(), "kind": "port", "proof_bytes_identical": bool(got == ref),
+            "speedup_vs_cpu_total": round(cpu_s / gpu_s, 1), "speedup_vs_cpu_c_kernels": round(c_s / gpu_s, 1),
             "sample": "one prove (rounds 1-5, 11 MSM + 25 NTT-equivalents) of a synthetic 2^%d-gate circuit" % log_domain}
 
 
+def reference_binary_baseline(log_domain):
+    """if PLONKIT_REF_BIN names a real `plonkit` binary, time its `prove` on the same .r1cs / .wtns /
+    key files this library is given, byte-compare the two proof.bin and let the reference verify ours.  The files are
+    produced through the C ABI (plk_circuit_export, `plonkit setup` of this package for the tau = 42 key)."""
+    ref = os.environ.get("PLONKIT_REF_BIN")
+    if not ref:
+        return None
+    import plonkit_amd as pa
+    ours = os.path.join(os.path.dirname(pa.lib_path()), "plonkit")
+    d = tempfile.mkdtemp(prefix="plonkit_ref_")
+    f = lambda name: os.path.join(d, name)
+    circ = pa.Circuit.synthetic((1 << log_domain) - 2)
+    open(f("circuit.r1cs"), "wb").write(circ.export("r1cs"))
+    open(f("witness.wtns"), "wb").write(circ.export("wtns"))
+    circ.close()
+    out = {"binary": ref, "domain": 1 << log_domain, "kind": "reference", "cores": os.cpu_count()}
+    try:
+        subprocess.check_call([ours, "setup", "-p", str(log_domain), "-m", f("key.bin"), "--overwrite"], stderr=subprocess.DEVNULL)
+        subprocess.check_call([ours, "export-verification-key", "-m", f("key.bin"), "-c", f("circuit.r1cs"), "-v", f("vk.bin"), "--overwrite"], stderr=subprocess.DEVNULL)
+        common = ["-m", f("key.bin"), "-c", f("circuit.r1cs"), "-w", f("witness.wtns")]
+        t0 = time.perf_counter()
+        subprocess.check_call([ours, "prove"] + common + ["-p", f("proof_ours.bin"), "-j", f("pj_ours.json"), "-i", f("ij_ours.json"), "--overwrite"], stderr=subprocess.DEVNULL)
+        out["ours_cli_prove_s"] = round(time.perf_counter() - t0, 3)
+        t0 = time.perf_counter()
+        subprocess.check_call([ref, "prove"] + common + ["-p", f("proof_ref.bin"), "-j", f("pj_ref.json"), "-i", f("ij_ref.json"), "--overwrite"],
+                              stderr=subprocess.DEVNULL, timeout=3600)
+        out["reference_cli_prove_s"] = round(time.perf_counter() - t0, 3)
+        out["proof_bytes_identical"] = open(f("proof_ours.bin"), "rb").read() == open(f("proof_ref.bin"), "rb").read()
+        out["reference_verifies_ours"] = subprocess.call([ref, "verify", "-p", f("proof_ours.bin"), "-v", f("vk.bin")], stderr=subprocess.DEVNULL) == 0
+        out["speedup_whole_cli"] = round(out["reference_cli_prove_s"] / out["ours_cli_prove_s"], 1)
+    except Exception as exc:                                       # noqa: BLE001 — a broken reference binary must not cost the bench line
+        out["error"] = repr(exc)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ multi-GPU legs
 def sharded_prove(ctx, dist, device, log_n, rank, world):
     """whole prove with every commitment sharded over the ranks (plonkit_amd.sharded.ShardedProver)"""
     import plonkit_amd as pa
@@ -118,9 +217,80 @@ def sharded_prove(ctx, dist, device, log_n, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         best = float(t.item()) if best is None else min(best, float(t.item()))
     sp.close()
+    setup.close(); circ.close()
     return {"wall_s": round(best, 4), "domain": n, "n_gpus": world, "srs_points_per_gpu": local, "proof_bytes": len(proof),
             "what": "SetupForProver::prove with every commitment computed as the sum over ranks of MSM(slice of the scalars, "
                     "slice of the SRS): all_gather of the Jacobian partial sums + host EC sum; NTTs and point-wise work replicated"}
+
+
+def strong_scaling_msm(ctx, dist, device, rank, world, log_total=24, reps=5):
+    """BASELINE.json configs[2] / north_star ">= 6x MSM scaling 1 -> 8 GPUs": ONE commitment of 2^24 terms, the SRS
+    split 2^24 / world per rank (total work fixed: strong scaling).  Rank 0 also times the whole 2^24-term commitment
+    on its own GPU in the same run, so `scaling_vs_1gpu` is a same-run ratio, not a number carried over from a file."""
+    from plonkit_amd.sharded import ShardedMsm
+    total = 1 << log_total
+    local = total // world
+    scal = rand_scalars(local, 0x24 + rank, device)
+    torch.cuda.synchronize()
+    ctx.srs_generate(local, rank * local, 42)
+    msm = ShardedMsm(ctx, dist, device)
+    stream = torch.cuda.Stream(device=device)
+    for _ in msm.commit_stream((scal for _ in range(2)), local, stream=stream):
+        pass
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for out in msm.commit_stream((scal for _ in range(reps)), local, stream=stream):
+        pass
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    sharded_ms = float(t.item()) / reps * 1e3
+    # latency of a single sharded commitment (nothing else in flight)
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    msm.commit(scal, local, stream=stream)
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    single_ms = float(t.item()) * 1e3
+    one_gpu_ms = None
+    if rank == 0:                                                   # the same 2^24 terms on one GPU (16 GiB fixed-base table)
+        full = rand_scalars(total, 0x24, device)
+        ctx.srs_generate(total, 0, 42)
+        solo = ShardedMsm(ctx, None, device)
+        for _ in solo.commit_stream((full for _ in range(2)), total, stream=stream):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in solo.commit_stream((full for _ in range(3)), total, stream=stream):
+            pass
+        torch.cuda.synchronize()
+        one_gpu_ms = (time.perf_counter() - t0) / 3 * 1e3
+        del full
+    dist.barrier()
+    res = {"terms_total": total, "terms_per_gpu": local, "n_gpus": world, "scaling": "strong",
+           "ms_per_commitment": round(sharded_ms, 3), "ms_single_commitment_latency": round(single_ms, 3),
+           "Mscalar_mul_s": round(total / sharded_ms / 1e3, 1)}
+    if one_gpu_ms:
+        res["one_gpu_ms_per_commitment"] = round(one_gpu_ms, 3)
+        res["scaling_vs_1gpu"] = round(one_gpu_ms / sharded_ms, 2)
+    return res
+
+
+def time_commitments(ctx, msm, scalars, n, steps, stream, depth):
+    """K commitments back to back.  depth 2: two in flight (ShardedMsm.commit_stream); depth 1: one at a time."""
+    kernel_ms = []
+    out = None
+    t0 = time.perf_counter()
+    if depth == 2:
+        for out in msm.commit_stream((scalars for _ in range(steps)), n, stream=stream):
+            kernel_ms.append(ctx.msm_last_kernel_ms())
+    else:
+        for _ in range(steps):
+            out = msm.commit(scalars, n, stream=stream)
+            kernel_ms.append(ctx.msm_last_kernel_ms())
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, kernel_ms, out
 
 
 def main():
@@ -129,8 +299,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the per-GPU commitment size")
-    ap.add_argument("--cpu-log-n", type=int, default=20, help="log2 of the CPU-baseline sample")
+    ap.add_argument("--cpu-log-n", type=int, default=20, help="log2 of the CPU-baseline samples (MSM terms, prove domain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline-depth", type=int, default=2, choices=(1, 2),
+                    help="commitments in flight in the timed region (2 = the library's two-slot FIFO; 1 = one at a time: "
+                         "the region roofline.kernel_ms is taken from)")
     ap.add_argument("--msm-only", action="store_true", help="only the timed commitments (no cpu_baseline / prove / kernels legs): "
                                                             "the command the rocprofv3 summary under profiles/ is taken from")
     args = ap.parse_args()
@@ -164,32 +337,37 @@ def main():
     msm = ShardedMsm(ctx, dist if (world > 1 or force_dist) else None, device)
     ctx.set_kernel_timing(True)
 
-    # K commitments back to back; the exchange of commitment k overlaps the kernels of k+1 (ShardedMsm.commit_stream)
-    for out in msm.commit_stream((scalars for _ in range(args.warmup)), n, stream=stream):
-        pass
+    # W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; the exchange of commitment k
+    # overlaps the kernels of k+1 (ShardedMsm.commit_stream)
+    time_commitments(ctx, msm, scalars, n, args.warmup, stream, args.pipeline_depth)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    kernel_ms = []
-    t0 = time.perf_counter()
-    for out in msm.commit_stream((scalars for _ in range(args.steps)), n, stream=stream):
-        kernel_ms.append(ctx.msm_last_kernel_ms())
-    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    _, kernel_ms, out = time_commitments(ctx, msm, scalars, n, args.steps, stream, args.pipeline_depth)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t_start
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the dominant kernel alone: one commitment in flight, so nothing shares the GPU with msm_accumulate
+    solo_elapsed, solo_kernel_ms, _ = time_commitments(ctx, msm, scalars, n, max(5, args.steps // 2), stream, 1)
+    if dist:
+        dist.barrier()
 
+    line = None
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * n / (elapsed / args.steps) / 1e6
-        k_ms = float(np.mean(kernel_ms))
+        k_pipe = float(np.mean(kernel_ms))
+        k_solo = float(np.mean(solo_kernel_ms))
+        k_ms = k_solo if args.pipeline_depth == 2 else k_pipe
         achieved = ALGO_BYTES_PER_TERM * n / (k_ms * 1e-3) / 1e9
+        gmadd = n * MSM_WINDOWS / (k_ms * 1e-3) / 1e9
         line = {
             "metric": "G1 MSM throughput at 2^%d terms per GPU (KZG commitment of the PLONK prover)" % args.log_n,
             "value": round(value, 3), "unit": "Mscalar·mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,40 +376,58 @@ def main():
             "config": {"workload": "Pippenger G1 MSM, 2^%d uniform scalars per GPU, tau=42 monomial SRS sharded by rank "
                                    "(BASELINE.json configs[1]: SRS 2^20, single MI355X at N=1)" % args.log_n,
                        "terms_per_gpu": n, "parallelism": "srs-shard x%d + all_gather of partial sums" % world,
+                       "pipeline_depth": args.pipeline_depth,
                        "result_x_be": pa.g1_to_bytes(out).hex()[:64]},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": PMC_TRAFFIC_BYTES_2POW20 if (args.log_n == 20) else None,
-                         "kernel_ms": round(k_ms, 4), "algorithmic_bytes": ALGO_BYTES_PER_TERM * n,
-                         "valu": {"achieved_gmadd_s": round(n * MSM_WINDOWS / (k_ms * 1e-3) / 1e9, 2),
-                                  "peak_gmadd_s": VALU_PEAK_GMADD,
-                                  "frac": round(n * MSM_WINDOWS / (k_ms * 1e-3) / 1e9 / VALU_PEAK_GMADD, 3)},
-                         "note": "commitments are pipelined two deep, so this kernel runs beside the bucket reduction of the previous "
-                                 "commitment and its HIP-event duration (kernel_ms) equals the step time; alone it takes about 1.3 ms "
-                                 "(profiles/r01_bench_final_kernel_stats.csv).  "
-                                 "The kernel is bound by v_mad_u64_u32 issue, not HBM (SURVEY.md §8d): `valu` compares its "
-                                 "mixed-addition rate with the same loop measured in isolation (tools/ubench_w); `traffic` "
-                                 "is 11x the algorithmic bytes because Pippenger gathers one 64-byte point per (term, window): "
-                                 "15 windows, each from its own shifted copy of the SRS (0.94 GiB fixed-base table in HBM)"},
+                         "kernel_ms": round(k_ms, 4), "kernel_ms_pipelined": round(k_pipe, 4),
+                         "ms_per_step_one_in_flight": round(solo_elapsed * 1e3 / len(solo_kernel_ms), 4),
+                         "algorithmic_bytes": ALGO_BYTES_PER_TERM * n,
+                         "valu": {"achieved_gmadd_s": round(gmadd, 2), "peak_gmadd_s": round(VALU_PEAK_GMADD, 2),
+                                  "frac": round(gmadd / VALU_PEAK_GMADD, 3),
+                                  "loop_isolated_gmadd_s": LOOP_ISOLATED_GMADD,
+                                  "frac_of_isolated_loop": round(gmadd / LOOP_ISOLATED_GMADD, 3),
+                                  "derivation": "peak = measured v_mad_u64_u32 issue rate (576.1 G wave-instr/s x 64 lanes, "
+                                                "profiles/r01_ubench_int.txt) / 1467 mads per XYZZ mixed addition; "
+                                                "loop_isolated = the same loop with its 817 non-mad instructions, alone on the chip"},
+                         "note": "kernel_ms = HIP-event duration of msm_accumulate with one commitment in flight (the region timed right "
+                                 "after the headline one; rocprofv3 of `bench.py --msm-only --pipeline-depth 1` agrees, profiles/); "
+                                 "kernel_ms_pipelined = the same kernel inside the headline region, where two commitments are in flight "
+                                 "and it shares the GPU with the bucket reduction of the previous one (its duration there can exceed the "
+                                 "step time: kernels of consecutive commitments overlap).  The kernel is bound by v_mad_u64_u32 issue, "
+                                 "not HBM (SURVEY.md §8d); `traffic` is 11x the algorithmic bytes because Pippenger gathers one "
+                                 "64-byte point per (term, window): 15 windows, each from its own shifted copy of the SRS "
+                                 "(0.94 GiB fixed-base table in HBM)"},
         }
         if world == 1 and not args.no_cpu_baseline and not args.msm_only:
-            cb, ref, s_host = cpu_baseline(ctx, min(args.cpu_log_n, args.log_n), 1234)
+            cb, ref, s_host = cpu_msm_baseline(ctx, min(args.cpu_log_n, args.log_n), 1234)
             got = ctx.msm(s_host)                         # same sample through the HIP path
             cb["matches_gpu"] = bool(np.array_equal(got, ref))
-            cb["prove"] = cpu_prove_baseline(ctx, min(16, args.log_n))
+            cb["ntt"] = cpu_ntt_baseline()
+            cb["prove"] = cpu_prove_baseline(ctx, min(args.cpu_log_n, args.log_n))
+            rb = reference_binary_baseline(min(args.cpu_log_n, args.log_n))
+            if rb:
+                cb["reference_binary"] = rb
             line["cpu_baseline"] = cb
         if world == 1 and not force_dist and not args.msm_only:
             from plonkit_amd import prover_bench
             line["prove"] = prover_bench.run(ctx, args.log_n)
             line["kernels"] = prover_bench.kernel_table(ctx, device)
     if world > 1 or force_dist:
-        # multi-GPU prove at the same 2^log_n domain: the SRS sliced across the ranks, commitments combined over RCCL,
-        # NTTs replicated.  Every rank takes part; a failure here must not cost the headline line.
+        # (a) strong scaling of ONE 2^24-term commitment (configs[2]); (b) multi-GPU prove at the 2^log_n domain: the SRS
+        # sliced across the ranks, commitments combined over RCCL, NTTs replicated.  Every rank takes part;
+        # a failure here must not cost the headline line.
+        try:
+            strong = strong_scaling_msm(ctx, dist, device, rank, world)
+        except Exception as exc:                                   # noqa: BLE001
+            strong = {"error": repr(exc)}
         try:
             sharded = sharded_prove(ctx, dist, device, args.log_n, rank, world)
         except Exception as exc:                                   # noqa: BLE001
             sharded = {"error": repr(exc)}
         if rank == 0:
+            line["strong"] = strong
             line["prove"] = sharded
     if rank == 0:
         print(json.dumps(line, ensure_ascii=False), flush=True)

@@ -112,6 +112,31 @@ int32_t plk_g1_intt_srs_dev(plk_ctx *ctx, uint32_t log_n, void *out_dev, void *s
 typedef int32_t (*plk_combine_fn)(void *user, plk_g1_jacobian *sums, uint32_t count);
 int32_t plk_set_commit_shard(plk_ctx *ctx, uint64_t first_index, plk_combine_fn combine, void *user);
 
+/* ---- the same, with the exchange built in (comm.cpp): the counterpart of `Worker::new()` (src/plonk.rs:41,47,183) for a node
+ *      of GPUs is ONE PROCESS PER GPU, each with its own plk_ctx, joined by an RCCL communicator.  A caller in any language
+ *      (the Rust host of INTEGRATION.md, the `plonkit` binary of this package) needs no collective library of its own:
+ *        rank 0:  plk_comm_unique_id(&id), hand the 128 bytes to the other ranks (file, pipe, env — the caller's choice)
+ *        all:     plk_create(device_of_rank) ; plk_comm_init(ctx, rank, world, &id, first_index)
+ *                 plk_srs_upload(ctx, key + first_index, n_local)      (or plk_srs_generate(ctx, n_local, first_index, tau))
+ *                 plk_setup_prepare / plk_setup_write_vk / plk_prove as on one GPU: identical bytes on every rank
+ *      plk_comm_init creates the communicator on the context's device (ncclCommInitRank — collective: every rank must
+ *      call it) and installs the built-in combiner: one ncclAllGather of count x 96 bytes on the context's stream per
+ *      batch of commitments, then world-1 host EC additions each (EC addition is not an RCCL reduction op).
+ *      RCCL is bound at run time (librccl.so.1); without it these calls return PLK_ERR_HIP and everything else works.
+ *      plk_comm_init_tcp is the same combiner over a TCP hub on 127.0.0.1:port (rank 0 listens) for the one case RCCL
+ *      refuses — several ranks sharing ONE device, as on a single-GPU test box.                                        */
+typedef struct { char bytes[128]; } plk_comm_id;                       /* an ncclUniqueId */
+int32_t plk_comm_unique_id(plk_comm_id *out);
+int32_t plk_comm_init(plk_ctx *ctx, int32_t rank, int32_t world, const plk_comm_id *id, uint64_t first_index);
+int32_t plk_comm_init_tcp(plk_ctx *ctx, int32_t rank, int32_t world, uint16_t port, uint64_t first_index);
+int32_t plk_comm_destroy(plk_ctx *ctx);                                 /* back to single-GPU commitments */
+/* the combiner on its own (no context, no GPU): the TCP transport opened directly, and the plk_combine_fn it serves —
+ * plk_set_commit_shard(ctx, first, plk_comm_combine, comm) is what plk_comm_init_tcp does.  Used by the CPU tests. */
+int32_t plk_comm_open_tcp(int32_t rank, int32_t world, uint16_t port, void **comm_out);
+int32_t plk_comm_combine(void *comm, plk_g1_jacobian *sums, uint32_t count);
+void plk_comm_close(void *comm);
+int32_t plk_comm_info(const plk_ctx *ctx, int32_t *rank, int32_t *world, uint64_t *exchanges);
+
 /* ---- Lagrange-form key: Crs<E, CrsForLagrangeForm> (L_i(tau)*G, i < N), the optional `-l` key of `plonkit prove`
  *      (src/bin/main.rs:384-391; src/plonk.rs:138-146: with it, prove() commits the witness and grand-product
  *      polynomials from their evaluations — commit_using_values — instead of their coefficients).  A second resident

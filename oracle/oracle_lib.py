@@ -34,13 +34,39 @@ def build(force=False):
 
 
 _lib = None
+C_SECONDS = [0.0]          # wall-clock spent inside liboracle.so calls (bench.py: the C share of a CPU prove)
+
+
+class _Timed:
+    """the CDLL with every call timed: bench.py's cpu_baseline reports how much of the oracle's prove is the C
+    arithmetic (MSM, NTT, vector ops) and how much is the numpy / Python glue around it"""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        self._cache = {}
+
+    def __getattr__(self, name):
+        f = self._cache.get(name)
+        if f is None:
+            raw = getattr(self._cdll, name)
+            import time as _t
+
+            def f(*a, _raw=raw):
+                t0 = _t.perf_counter()
+                try:
+                    return _raw(*a)
+                finally:
+                    C_SECONDS[0] += _t.perf_counter() - t0
+            f.raw = raw
+            self._cache[name] = f
+        return f
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = ctypes.CDLL(_SO)
+        _lib = _Timed(ctypes.CDLL(_SO))
     return _lib
 
 
@@ -252,7 +278,7 @@ def g1_mul(a, k):
 
 
 def g1_on_curve(a):
-    lib().orc_g1_on_curve.restype = ctypes.c_int
+    lib().orc_g1_on_curve.raw.restype = ctypes.c_int
     return bool(lib().orc_g1_on_curve(_p(np.ascontiguousarray(a))))
 
 

@@ -13,8 +13,9 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from ._lib import (PlkError, lib, lib_path, Context, last_error, have_gpu,   # noqa: F401
                    g1_sum_jacobian, g1_to_bytes, g1_from_bytes, fr_to_bytes, fr_from_bytes,
-                   Transcript, keccak256, Circuit, SetupForProver, verify, pairing_check, crs42_g2_bytes)
+                   Transcript, keccak256, Circuit, SetupForProver, verify, pairing_check, crs42_g2_bytes,
+                   comm_unique_id)
 
 __all__ = ["PlkError", "lib", "lib_path", "Context", "last_error", "have_gpu", "g1_sum_jacobian",
            "g1_to_bytes", "g1_from_bytes", "fr_to_bytes", "fr_from_bytes", "Transcript", "keccak256", "Circuit", "SetupForProver",
-           "verify", "pairing_check", "crs42_g2_bytes"]
+           "verify", "pairing_check", "crs42_g2_bytes", "comm_unique_id"]

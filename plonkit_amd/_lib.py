@@ -136,6 +136,22 @@ class Context:
         self._combine_cb = proto(trampoline)                          # keep the callback object alive
         _check(lib().plk_set_commit_shard(self._h, ctypes.c_uint64(first_index), self._combine_cb, None))
 
+    # the same exchange built into the library (comm.cpp): RCCL all-gather + host EC sum, no Python in the loop
+    def comm_init(self, rank, world, unique_id, first_index):
+        assert len(unique_id) == 128
+        _check(lib().plk_comm_init(self._h, ctypes.c_int32(rank), ctypes.c_int32(world), bytes(unique_id), ctypes.c_uint64(first_index)))
+
+    def comm_init_tcp(self, rank, world, port, first_index):
+        _check(lib().plk_comm_init_tcp(self._h, ctypes.c_int32(rank), ctypes.c_int32(world), ctypes.c_uint16(port), ctypes.c_uint64(first_index)))
+
+    def comm_destroy(self):
+        _check(lib().plk_comm_destroy(self._h))
+
+    def comm_info(self):
+        r, w, x = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_uint64(0)
+        _check(lib().plk_comm_info(self._h, ctypes.byref(r), ctypes.byref(w), ctypes.byref(x)))
+        return r.value, w.value, x.value
+
     # Lagrange-form key (`prove -l`): second resident SRS used by prove() for commit_using_values
     def srs_lagrange_upload(self, bases):
         bases = np.ascontiguousarray(bases, dtype=np.uint64)
@@ -352,6 +368,13 @@ def g1_sum_jacobian(parts):
     out = np.zeros(8, dtype=np.uint64)
     _check(lib().plk_g1_sum_jacobian(_np(parts), ctypes.c_uint64(parts.shape[0]), _np(out)))
     return out
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (rank 0 calls it and hands the 128 bytes to the other ranks)"""
+    out = ctypes.create_string_buffer(128)
+    _check(lib().plk_comm_unique_id(out))
+    return out.raw
 
 
 def g1_to_bytes(p):

@@ -3,6 +3,12 @@
 // Same option names, short flags and defaults (src/bin/main.rs:55-136,176-190), same refusal to overwrite
 // (src/bin/main.rs:336-339,374-377,403-406) and the circuit-file default rule (src/bin/main.rs:346-357).
 // Everything arithmetic goes through include/plonkit_amd.h.
+//
+// Multi-GPU (an extension; the reference is one process): start one `plonkit prove` / `export-verification-key` per GPU
+// with PLONKIT_WORLD=<ranks> PLONKIT_RANK=<r> and PLONKIT_COMM=rccl:<id file> (rank 0 writes the RCCL unique id there, the
+// others wait for it) or PLONKIT_COMM=tcp:<port> (ranks sharing one device).  Rank r uses device PLONKIT_DEVICE or
+// r mod #devices, keeps only its 1/world slice of the key resident and computes its share of every commitment
+// (plk_comm_init, include/plonkit_amd.h); every rank derives the same bytes and rank 0 writes the files.
 #include "../../include/plonkit_amd.h"
 #include <cstdio>
 #include <cstdlib>
@@ -147,16 +153,58 @@ static bool proof_words(const uint8_t *p, size_t len, std::vector<std::string> *
     return g1() && g1() && off == len;
 }
 
-static plk_ctx *open_ctx() { plk_ctx *ctx = nullptr; CK("plk_create", plk_create(0, &ctx)); return ctx; }
-static void load_key(plk_ctx *ctx, const std::string &path, uint8_t g2[256], bool lagrange = false) {
+struct Ranks { int rank = 0, world = 1; std::string comm; };
+static Ranks ranks_from_env() {
+    Ranks r;
+    if (const char *w = getenv("PLONKIT_WORLD")) r.world = atoi(w);
+    if (const char *k = getenv("PLONKIT_RANK")) r.rank = atoi(k);
+    if (const char *c = getenv("PLONKIT_COMM")) r.comm = c;
+    if (r.world < 1 || r.rank < 0 || r.rank >= r.world) { fprintf(stderr, "PLONKIT_RANK / PLONKIT_WORLD out of range\n"); exit(2); }
+    if (r.world > 1 && r.comm.rfind("rccl:", 0) != 0 && r.comm.rfind("tcp:", 0) != 0) { fprintf(stderr, "PLONKIT_WORLD > 1 needs PLONKIT_COMM=rccl:<id file> or tcp:<port>\n"); exit(2); }
+    return r;
+}
+static plk_ctx *open_ctx(const Ranks &rk = Ranks()) {
+    int dev = 0;
+    if (const char *d = getenv("PLONKIT_DEVICE")) dev = atoi(d);
+    else if (rk.world > 1) { int n = plk_device_count(); dev = n > 0 ? rk.rank % n : 0; }
+    plk_ctx *ctx = nullptr; CK("plk_create", plk_create(dev, &ctx)); return ctx;
+}
+// joins the ranks: commitments over the N-point domain are split into world contiguous slices of N / world SRS points
+static void join_ranks(plk_ctx *ctx, const Ranks &rk, uint64_t N) {
+    if (rk.world == 1) return;
+    if (N % (uint64_t)rk.world) { fprintf(stderr, "PLONKIT_WORLD must divide the domain size\n"); exit(101); }
+    const uint64_t first = (uint64_t)rk.rank * (N / rk.world);
+    if (rk.comm.rfind("tcp:", 0) == 0) { CK("plk_comm_init_tcp", plk_comm_init_tcp(ctx, rk.rank, rk.world, (uint16_t)atoi(rk.comm.c_str() + 4), first)); return; }
+    const std::string path = rk.comm.substr(5);
+    plk_comm_id id;
+    if (rk.rank == 0) {
+        CK("plk_comm_unique_id", plk_comm_unique_id(&id));
+        spit(path + ".tmp", reinterpret_cast<const uint8_t *>(id.bytes), sizeof id.bytes);
+        if (rename((path + ".tmp").c_str(), path.c_str()) != 0) { fprintf(stderr, "cannot write %s\n", path.c_str()); exit(101); }
+    } else {
+        for (int i = 0; i < 1200 && !exists(path); i++) usleep(100000);           // up to two minutes for rank 0
+        std::vector<uint8_t> raw = slurp(path, "RCCL unique id");
+        if (raw.size() != sizeof id.bytes) { fprintf(stderr, "bad RCCL id file %s\n", path.c_str()); exit(101); }
+        memcpy(id.bytes, raw.data(), sizeof id.bytes);
+    }
+    CK("plk_comm_init", plk_comm_init(ctx, rk.rank, rk.world, &id, first));
+}
+// uploads the key; with several ranks only this rank's slice [rank * N/world, (rank + 1) * N/world) of its first N points
+static void load_key(plk_ctx *ctx, const std::string &path, uint8_t g2[256], bool lagrange = false, const Ranks &rk = Ranks(), uint64_t N = 0) {
     const char *what = lagrange ? "read key_lagrange_form err" : "read key_monomial_form err";
     std::vector<uint8_t> raw = slurp(path, what);
     uint64_t n = 0;
     CK(what, plk_key_parse(raw.data(), raw.size(), nullptr, 0, &n, g2));
     std::vector<plk_g1_affine> pts(n);
     CK(what, plk_key_parse(raw.data(), raw.size(), pts.data(), n, &n, g2));
-    if (lagrange) CK("srs upload", plk_srs_lagrange_upload(ctx, pts.data(), n));
-    else CK("srs upload", plk_srs_upload(ctx, pts.data(), n));
+    const plk_g1_affine *first = pts.data();
+    if (rk.world > 1) {
+        if (n < N) { fprintf(stderr, "%s: key has %llu points, the domain needs %llu\n", what, (unsigned long long)n, (unsigned long long)N); exit(101); }
+        first += (uint64_t)rk.rank * (N / rk.world);
+        n = N / rk.world;
+    }
+    if (lagrange) CK("srs upload", plk_srs_lagrange_upload(ctx, first, n));
+    else CK("srs upload", plk_srs_upload(ctx, first, n));
 }
 
 static int run(int argc, char **argv) {
@@ -212,37 +260,50 @@ static int run(int argc, char **argv) {
         fprintf(stderr, "srs_lagrange_form saved to %s\n", out.c_str());
     } else if (cmd == "export-verification-key") {                   // src/bin/main.rs:484-504
         Args a = parse(argc, argv, {{"m", "srs_monomial_form"}, {"c", "circuit"}, {"v", "vk"}});
+        const Ranks rk = ranks_from_env();
         plk_circuit *c = load_circuit(resolve_circuit(a), nullptr);
-        plk_ctx *ctx = open_ctx();
+        plk_ctx *ctx = open_ctx(rk);
         uint8_t g2[256];
-        load_key(ctx, a.get("srs_monomial_form"), g2);
         plk_setup *s = nullptr;
         CK("prepare err", plk_setup_prepare(ctx, c, &s));
+        join_ranks(ctx, rk, plk_setup_domain_size(s));
+        load_key(ctx, a.get("srs_monomial_form"), g2, false, rk, plk_setup_domain_size(s));
         std::vector<uint8_t> buf(4096); uint64_t len = 0;
         CK("make_verification_key", plk_setup_write_vk(ctx, s, g2, buf.data(), buf.size(), &len));
         std::string out = a.get("vk", "vk.bin");
-        refuse_duplicate(a, out, "vk");
-        spit(out, buf.data(), len);
-        fprintf(stderr, "Verification key saved to %s\n", out.c_str());
+        if (rk.rank == 0) {
+            refuse_duplicate(a, out, "vk");
+            spit(out, buf.data(), len);
+            fprintf(stderr, "Verification key saved to %s\n", out.c_str());
+        }
     } else if (cmd == "prove") {                                     // src/bin/main.rs:384-424
         Args a = parse(argc, argv, {{"m", "srs_monomial_form"}, {"l", "srs_lagrange_form"}, {"c", "circuit"}, {"w", "witness"},
                                     {"p", "proof"}, {"j", "proofjson"}, {"i", "publicjson"}, {"t", "transcript"}});
         if (a.get("transcript", "keccak") != "keccak") { fprintf(stderr, "not implemented: transcript '%s' (only keccak; rescue needs franklin-crypto)\n", a.get("transcript").c_str()); return 101; }
         phase("start");
+        const Ranks rk = ranks_from_env();
         std::string wf = a.get("witness", "witness.wtns");
         plk_circuit *c = load_circuit(resolve_circuit(a), &wf);
         phase("load circuit + witness");
-        plk_ctx *ctx = open_ctx();
+        plk_ctx *ctx = open_ctx(rk);
         phase("plk_create (HIP init)");
         uint8_t g2[256];
-        load_key(ctx, a.get("srs_monomial_form"), g2);
+        plk_setup *s = nullptr;
+        if (rk.world > 1) {                                          // the slice of the key depends on the domain size
+            CK("prepare err", plk_setup_prepare(ctx, c, &s));
+            phase("setup_prepare");
+            join_ranks(ctx, rk, plk_setup_domain_size(s));
+        }
+        const uint64_t N = s ? plk_setup_domain_size(s) : 0;
+        load_key(ctx, a.get("srs_monomial_form"), g2, false, rk, N);
         phase("load key (parse + upload)");
         // a Lagrange-form key (-l) changes how the witness commitments are computed (commit_using_values), never the
         // proof bytes (src/plonk.rs:138-146); an empty or missing option means "monomial only" as in the reference
-        if (!a.get("srs_lagrange_form", "").empty()) { uint8_t g2l[256]; load_key(ctx, a.get("srs_lagrange_form"), g2l, true); }
-        plk_setup *s = nullptr;
-        CK("prepare err", plk_setup_prepare(ctx, c, &s));
-        phase("setup_prepare");
+        if (!a.get("srs_lagrange_form", "").empty()) { uint8_t g2l[256]; load_key(ctx, a.get("srs_lagrange_form"), g2l, true, rk, N); }
+        if (!s) {
+            CK("prepare err", plk_setup_prepare(ctx, c, &s));
+            phase("setup_prepare");
+        }
         fprintf(stderr, "Proving...\n");
         std::vector<uint8_t> buf(1 << 16); uint64_t len = 0;
         int32_t rc = plk_prove(ctx, s, c, buf.data(), buf.size(), &len);
@@ -253,6 +314,7 @@ static int run(int argc, char **argv) {
         if (rc == PLK_ERR_UNSAT) { fprintf(stderr, "must satisfy: %s\n", plk_last_error()); return 101; }
         if (rc != PLK_OK) die("prove", rc);
         phase("prove");
+        if (rk.rank != 0) return 0;                                  // every rank holds the same bytes; rank 0 writes them
         std::string out = a.get("proof", "proof.bin");
         refuse_duplicate(a, out, "proof");
         spit(out, buf.data(), len);

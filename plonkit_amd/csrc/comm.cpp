@@ -1,0 +1,260 @@
+// Multi-GPU commitments below the C ABI: one process per GPU, the SRS split into contiguous slices, every KZG
+// commitment of plk_prove / plk_setup_write_vk = sum over ranks of MSM(slice of the scalars, slice of the SRS).
+//
+// The reference has one process and bellman's `Worker` thread pool (src/plonk.rs:41,47,183); the exchange step here is
+// the one SURVEY.md §8(e) describes: ONE all-gather of the 96-byte Jacobian partial sums per batch of commitments over
+// RCCL/xGMI (EC addition is not an RCCL reduction op, so a literal ncclAllReduce is impossible), then world-1 host EC
+// additions per commitment.  The payload is <= 8 x 96 B per rank: latency-bound, nothing to tune in bandwidth terms.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1) so that the library — and the `plonkit` binary for single-GPU use —
+// load on machines without it, and so that a host program that already carries RCCL (PyTorch) shares its copy.
+// A second transport, a TCP hub on 127.0.0.1, exists for the one case RCCL refuses: several ranks on the SAME device
+// (the single-GPU test tier).  It moves the same bytes through the same combiner.
+#include "ctx.h"
+#include "comm.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+#include <cstring>
+#include <chrono>
+#include <thread>
+#include <vector>
+
+namespace plk {
+using namespace host;
+
+namespace {
+
+struct Rccl {
+    void *so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl *rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.so ? &r : nullptr;
+    tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.so) break;
+    }
+    if (!r.so) return nullptr;
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.so, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.so, "ncclCommInitRank"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.so, "ncclAllGather"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.so, "ncclCommDestroy"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.so, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { dlclose(r.so); r.so = nullptr; return nullptr; }
+    return &r;
+}
+
+int32_t rccl_fail(ncclResult_t e, const char *what) {
+    Rccl *R = rccl();
+    set_error(std::string("RCCL: ") + what + ": " + (R && R->GetErrorString ? R->GetErrorString(e) : "error") );
+    return PLK_ERR_HIP;
+}
+
+bool send_all(int fd, const void *p, size_t n) {
+    const char *c = static_cast<const char *>(p);
+    while (n) { ssize_t k = ::send(fd, c, n, MSG_NOSIGNAL); if (k <= 0) return false; c += k; n -= (size_t)k; }
+    return true;
+}
+bool recv_all(int fd, void *p, size_t n) {
+    char *c = static_cast<char *>(p);
+    while (n) { ssize_t k = ::recv(fd, c, n, 0); if (k <= 0) return false; c += k; n -= (size_t)k; }
+    return true;
+}
+
+}  // namespace
+
+struct Comm {
+    int rank = 0, world = 1;
+    // RCCL transport
+    ncclComm_t nccl = nullptr;
+    DevBuf d_send, d_recv;
+    // TCP hub transport (rank 0 listens; fds[r] = connection of rank r on the hub, fds[0] = the hub's socket on a spoke)
+    bool tcp = false;
+    int listen_fd = -1;
+    std::vector<int> fds;
+    std::vector<plk_g1_jacobian> host_all;
+    plk_ctx *ctx = nullptr;
+    uint64_t gathers = 0;                    // number of exchanges performed (tracing / tests)
+};
+
+// all ranks' `count` partial sums -> all[r * count + k]
+static int32_t gather(Comm *C, const plk_g1_jacobian *mine, uint32_t count, plk_g1_jacobian *all) {
+    const size_t bytes = (size_t)count * sizeof(plk_g1_jacobian);
+    C->gathers++;
+    if (C->tcp) {
+        if (C->rank == 0) {
+            memcpy(all, mine, bytes);
+            for (int r = 1; r < C->world; r++)
+                if (!recv_all(C->fds[r], reinterpret_cast<char *>(all) + (size_t)r * bytes, bytes)) { set_error("tcp combiner: a rank went away"); return PLK_ERR_IO; }
+            for (int r = 1; r < C->world; r++)
+                if (!send_all(C->fds[r], all, bytes * C->world)) { set_error("tcp combiner: a rank went away"); return PLK_ERR_IO; }
+        } else {
+            if (!send_all(C->fds[0], mine, bytes) || !recv_all(C->fds[0], all, bytes * C->world)) { set_error("tcp combiner: the hub went away"); return PLK_ERR_IO; }
+        }
+        return PLK_OK;
+    }
+    Rccl *R = rccl();
+    hipStream_t st = C->ctx->stream;
+    PLK_TRY(C->d_send.reserve(8 * sizeof(plk_g1_jacobian)));
+    PLK_TRY(C->d_recv.reserve((size_t)C->world * 8 * sizeof(plk_g1_jacobian)));
+    PLK_HIP(hipMemcpyAsync(C->d_send.p, mine, bytes, hipMemcpyHostToDevice, st));
+    ncclResult_t e = R->AllGather(C->d_send.p, C->d_recv.p, bytes, ncclUint8, C->nccl, st);
+    if (e != ncclSuccess) return rccl_fail(e, "ncclAllGather");
+    PLK_HIP(hipMemcpyAsync(all, C->d_recv.p, bytes * C->world, hipMemcpyDeviceToHost, st));
+    PLK_HIP(hipStreamSynchronize(st));
+    return PLK_OK;
+}
+
+// the built-in plk_combine_fn: sums[k] <- sum over ranks of sums[k]; every rank ends with the same group elements
+static int32_t builtin_combine(void *user, plk_g1_jacobian *sums, uint32_t count) {
+    Comm *C = static_cast<Comm *>(user);
+    if (count == 0 || count > 8) { set_error("combiner: batch must be 1..8"); return PLK_ERR_ARG; }
+    C->host_all.resize((size_t)C->world * count);
+    PLK_TRY(gather(C, sums, count, C->host_all.data()));
+    for (uint32_t k = 0; k < count; k++) {
+        HJac acc = HJac::inf();
+        for (int r = 0; r < C->world; r++) {
+            const plk_g1_jacobian &p = C->host_all[(size_t)r * count + k];
+            HJac j; memcpy(j.x.l, p.x, 32); memcpy(j.y.l, p.y, 32); memcpy(j.z.l, p.z, 32);
+            acc = jac_add(acc, j);                     // rank order 0..world-1 on every rank: identical bytes everywhere
+        }
+        memcpy(sums[k].x, acc.x.l, 32); memcpy(sums[k].y, acc.y.l, 32); memcpy(sums[k].z, acc.z.l, 32);
+    }
+    return PLK_OK;
+}
+
+static void comm_free(Comm *C) {
+    if (!C) return;
+    if (C->nccl) { Rccl *R = rccl(); if (R) (void)R->CommDestroy(C->nccl); }
+    C->d_send.release(); C->d_recv.release();
+    for (int fd : C->fds) if (fd >= 0) ::close(fd);
+    if (C->listen_fd >= 0) ::close(C->listen_fd);
+    delete C;
+}
+
+void comm_release(plk_ctx *ctx) {
+    if (!ctx || !ctx->comm) return;
+    if (ctx->combine == builtin_combine) { ctx->combine = nullptr; ctx->combine_user = nullptr; ctx->shard_first = 0; }
+    comm_free(static_cast<Comm *>(ctx->comm));
+    ctx->comm = nullptr;
+}
+
+}  // namespace plk
+
+using namespace plk;
+
+extern "C" {
+
+int32_t plk_comm_unique_id(plk_comm_id *out) {
+    if (!out) { set_error("plk_comm_unique_id: null"); return PLK_ERR_ARG; }
+    static_assert(sizeof(plk_comm_id) == sizeof(ncclUniqueId), "plk_comm_id is an ncclUniqueId");
+    Rccl *R = rccl();
+    if (!R) { set_error("RCCL (librccl.so.1) cannot be loaded"); return PLK_ERR_HIP; }
+    ncclUniqueId id;
+    ncclResult_t e = R->GetUniqueId(&id);
+    if (e != ncclSuccess) return rccl_fail(e, "ncclGetUniqueId");
+    memcpy(out->bytes, id.internal, sizeof id.internal);
+    return PLK_OK;
+}
+
+int32_t plk_comm_init(plk_ctx *ctx, int32_t rank, int32_t world, const plk_comm_id *id, uint64_t first_index) {
+    if (!ctx || !id || world < 1 || rank < 0 || rank >= world) { set_error("plk_comm_init: bad argument"); return PLK_ERR_ARG; }
+    Rccl *R = rccl();
+    if (!R) { set_error("RCCL (librccl.so.1) cannot be loaded"); return PLK_ERR_HIP; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    comm_release(ctx);
+    Comm *C = new Comm();
+    C->rank = rank; C->world = world; C->ctx = ctx;
+    ncclUniqueId nid;
+    memcpy(nid.internal, id->bytes, sizeof nid.internal);
+    ncclResult_t e = R->CommInitRank(&C->nccl, world, nid, rank);
+    if (e != ncclSuccess) { C->nccl = nullptr; comm_free(C); return rccl_fail(e, "ncclCommInitRank (one rank per GPU: RCCL refuses two ranks on one device)"); }
+    ctx->comm = C;
+    return plk_set_commit_shard(ctx, first_index, builtin_combine, C);
+}
+
+int32_t plk_comm_open_tcp(int32_t rank, int32_t world, uint16_t port, void **out) {
+    if (!out || world < 1 || rank < 0 || rank >= world || port == 0) { set_error("plk_comm_open_tcp: bad argument"); return PLK_ERR_ARG; }
+    *out = nullptr;
+    Comm *C = new Comm();
+    C->rank = rank; C->world = world; C->ctx = nullptr; C->tcp = true;
+    C->fds.assign(world, -1);
+    sockaddr_in addr{};
+    addr.sin_family = AF_INET; addr.sin_port = htons(port); addr.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+    const int one = 1;
+    if (rank == 0) {
+        C->listen_fd = ::socket(AF_INET, SOCK_STREAM, 0);
+        ::setsockopt(C->listen_fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+        if (C->listen_fd < 0 || ::bind(C->listen_fd, reinterpret_cast<sockaddr *>(&addr), sizeof addr) != 0 || ::listen(C->listen_fd, world) != 0) {
+            comm_free(C); set_error("plk_comm_open_tcp: cannot listen on 127.0.0.1"); return PLK_ERR_IO; }
+        for (int k = 1; k < world; k++) {
+            int fd = ::accept(C->listen_fd, nullptr, nullptr);
+            int32_t peer = -1;
+            if (fd < 0 || !recv_all(fd, &peer, 4) || peer < 1 || peer >= world || C->fds[peer] >= 0) { if (fd >= 0) ::close(fd); comm_free(C); set_error("plk_comm_init_tcp: bad peer"); return PLK_ERR_IO; }
+            ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+            C->fds[peer] = fd;
+        }
+    } else {
+        int fd = -1;
+        for (int attempt = 0; attempt < 600; attempt++) {            // the hub may start later: retry for a minute
+            fd = ::socket(AF_INET, SOCK_STREAM, 0);
+            if (fd >= 0 && ::connect(fd, reinterpret_cast<sockaddr *>(&addr), sizeof addr) == 0) break;
+            if (fd >= 0) ::close(fd);
+            fd = -1;
+            std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        }
+        int32_t me = rank;
+        if (fd < 0 || !send_all(fd, &me, 4)) { if (fd >= 0) ::close(fd); comm_free(C); set_error("plk_comm_init_tcp: cannot reach rank 0"); return PLK_ERR_IO; }
+        ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+        C->fds[0] = fd;
+    }
+    *out = C;
+    return PLK_OK;
+}
+
+void plk_comm_close(void *comm) { comm_free(static_cast<Comm *>(comm)); }
+
+int32_t plk_comm_combine(void *comm, plk_g1_jacobian *sums, uint32_t count) {
+    if (!comm || !sums) { set_error("plk_comm_combine: bad argument"); return PLK_ERR_ARG; }
+    return builtin_combine(comm, sums, count);
+}
+
+int32_t plk_comm_init_tcp(plk_ctx *ctx, int32_t rank, int32_t world, uint16_t port, uint64_t first_index) {
+    if (!ctx) { set_error("plk_comm_init_tcp: bad argument"); return PLK_ERR_ARG; }
+    comm_release(ctx);
+    void *C = nullptr;
+    PLK_TRY(plk_comm_open_tcp(rank, world, port, &C));
+    static_cast<Comm *>(C)->ctx = ctx;
+    ctx->comm = C;
+    return plk_set_commit_shard(ctx, first_index, builtin_combine, C);
+}
+
+int32_t plk_comm_destroy(plk_ctx *ctx) {
+    if (!ctx) { set_error("plk_comm_destroy: null ctx"); return PLK_ERR_ARG; }
+    comm_release(ctx);
+    return PLK_OK;
+}
+
+int32_t plk_comm_info(const plk_ctx *ctx, int32_t *rank, int32_t *world, uint64_t *exchanges) {
+    if (!ctx) { set_error("plk_comm_info: null ctx"); return PLK_ERR_ARG; }
+    const Comm *C = static_cast<const Comm *>(ctx->comm);
+    if (rank) *rank = C ? C->rank : 0;
+    if (world) *world = C ? C->world : 1;
+    if (exchanges) *exchanges = C ? C->gathers : 0;
+    return PLK_OK;
+}
+
+}  // extern "C"

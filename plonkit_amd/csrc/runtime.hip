@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include "ntt.h"
 #include "msm.h"
+#include "comm.h"
 #include <cstring>
 #include <cstdio>
 
@@ -109,6 +110,7 @@ void plk_destroy(plk_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
     for (auto &S : ctx->slot) if (S.stream) (void)hipStreamSynchronize(S.stream);     // commitments still in flight
+    comm_release(ctx);
     for (void *p : ctx->coset_allocs) (void)hipFree(p);
     ctx->tables.release(); ctx->ntt_scratch.release(); ctx->srs_own.release(); ctx->srs_w.release(); ctx->lag.own.release(); ctx->lag.w.release();
     for (auto &S : ctx->slot) {

@@ -6,10 +6,32 @@ import time
 from . import _lib
 
 
+def cold(device, log_n, circ):
+    """first proof of a process as a `plonkit prove` user meets it (the reference is always in this state: it passes
+    `None` precomputations, src/plonk.rs:152-159): a fresh context with only the key resident — the fixed-base table of
+    the MSM, the 12 constant coset extensions, every workspace allocation and the HIP module load are inside."""
+    ctx = _lib.Context(device)
+    ctx.srs_generate(1 << log_n, 0, 42)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    setup = _lib.SetupForProver(ctx, circ)
+    ctx.synchronize()
+    t_setup = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    proof = setup.prove(circ)
+    t_first = time.perf_counter() - t0
+    phases = setup.timings_ms()
+    setup.close()
+    ctx.close()
+    return proof, {"first_prove_s": round(t_first, 4), "setup_prepare_s": round(t_setup, 3),
+                   "rounds_ms": {k: round(v, 2) for k, v in phases.items()}}
+
+
 def run(ctx, log_n, reps=2):
     t0 = time.perf_counter()
     circ = _lib.Circuit.synthetic((1 << log_n) - 2)
     t_synth = time.perf_counter() - t0
+    cold_proof, cold_info = cold(ctx.device, log_n, circ)
     t0 = time.perf_counter()
     setup = _lib.SetupForProver(ctx, circ)
     ctx.synchronize()
@@ -25,12 +47,14 @@ def run(ctx, log_n, reps=2):
         if best is None or dt < best:
             best, phases = dt, setup.timings_ms()
     gpu_ms = sum(v for k, v in phases.items() if k.startswith("round"))
-    return {"wall_s": round(best, 4), "domain": 1 << log_n, "proof_bytes": len(proof),
+    assert cold_proof == proof
+    return {"wall_s": round(best, 4), "cold": cold_info, "domain": 1 << log_n, "proof_bytes": len(proof),
             "rounds_ms": {k: round(v, 2) for k, v in phases.items()},
             "gpu_rounds_s": round(gpu_ms / 1e3, 4),
             "setup_prepare_s": round(t_setup, 3), "circuit_generation_s": round(t_synth, 3),
             "what": "SetupForProver::prove (witness synthesis + satisfiability check on the host, rounds 1-5 on the GPU, "
-                    "Proof::write); setup_prepare = transpile + 11 iNTT, timed separately as in the reference's CLI"}
+                    "Proof::write); setup_prepare = transpile + 11 iNTT, timed separately as in the reference's CLI; "
+                    "wall_s = warm (tables, cached constant extensions and allocations in place), cold = first proof of a fresh context"}
 
 
 def kernel_table(ctx, device):

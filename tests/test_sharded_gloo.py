@@ -115,3 +115,48 @@ def test_sharded_commit_stream_world2():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True, 3), (1, True, 3)]
+
+
+# ------------------------------------------------------------------ the combiner below the C ABI (comm.cpp)
+def _native_worker(rank, world, port, n_per_rank, q):
+    """the library's own combiner (plk_comm_combine over the TCP transport; on a GPU node the same function runs over an
+    RCCL all-gather): no torch.distributed, no Python in the exchange"""
+    import ctypes
+    import plonkit_amd as pa
+    L = pa.lib()
+    comm = ctypes.c_void_p()
+    assert L.plk_comm_open_tcp(ctypes.c_int32(rank), ctypes.c_int32(world), ctypes.c_uint16(port), ctypes.byref(comm)) == 0, pa.last_error()
+    try:
+        srs = ol.crs42(world * n_per_rank, threads=2)
+        rng = np.random.default_rng(7)
+        count = 3                                                 # a batch of three commitments, the third one empty on rank 1
+        sums = np.zeros((count, 12), dtype=np.uint64)
+        want = []
+        for k in range(count):
+            s = rng.integers(0, 1 << 62, size=(world * n_per_rank, 4), dtype=np.uint64)
+            s[:, 3] &= np.uint64((1 << 60) - 1)
+            if k == 2:
+                s[n_per_rank:] = 0                                # rank 1's share of this commitment is the point at infinity
+            lo, hi = rank * n_per_rank, (rank + 1) * n_per_rank
+            sums[k] = ol.msm_jacobian(srs[lo:hi], s[lo:hi], threads=2)
+            want.append(ol.msm(srs, s, threads=2))
+        assert L.plk_comm_combine(comm, sums.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(count)) == 0, pa.last_error()
+        ok = all(np.array_equal(ol.jac_to_affine(sums[k])[0], want[k]) for k in range(count))
+        q.put((rank, ok, sums.tobytes()))
+    finally:
+        L.plk_comm_close(comm)
+
+
+def test_native_combiner_world2_and_world3():
+    for world in (2, 3):
+        port = _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_native_worker, args=(r, world, port, 200, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+        assert [r[:2] for r in res] == [(r, True) for r in range(world)]
+        assert len({r[2] for r in res}) == 1                      # every rank ends with the same bytes
