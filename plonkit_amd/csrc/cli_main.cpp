@@ -171,7 +171,7 @@ static plk_ctx *open_ctx(const Ranks &rk = Ranks()) {
 }
 // joins the ranks: commitments over the N-point domain are split into world contiguous slices of N / world SRS points
 static void join_ranks(plk_ctx *ctx, const Ranks &rk, uint64_t N) {
-    if (rk.world == 1) return;
+    if (rk.world == 1 && rk.comm.empty()) return;                  // (a communicator of one rank is allowed: it exercises the transport)
     if (N % (uint64_t)rk.world) { fprintf(stderr, "PLONKIT_WORLD must divide the domain size\n"); exit(101); }
     const uint64_t first = (uint64_t)rk.rank * (N / rk.world);
     if (rk.comm.rfind("tcp:", 0) == 0) { CK("plk_comm_init_tcp", plk_comm_init_tcp(ctx, rk.rank, rk.world, (uint16_t)atoi(rk.comm.c_str() + 4), first)); return; }

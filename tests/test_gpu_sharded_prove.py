@@ -75,3 +75,97 @@ def test_two_ranks_produce_the_single_gpu_proof(log_n, lagrange):
     for rank, vk, proof in res:
         assert vk == want_vk, rank
         assert proof == want_proof, rank
+
+
+# ---------------------------------------------------------------- the exchange below the C ABI (comm.cpp, plk_comm_init)
+def test_rccl_communicator_of_one_rank():
+    """plk_comm_unique_id + plk_comm_init over the real RCCL (librccl.so.1 bound at run time): a communicator of one
+    rank on device 0, every commitment of the verification key and the proof goes through ncclAllGather; same bytes as
+    without it.  (RCCL refuses two ranks on one device, so world > 1 over RCCL needs a multi-GPU node: bench.py --gpus N.)"""
+    import plonkit_amd as pa
+    n = 1 << 12
+    ctx = pa.Context(0)
+    ctx.srs_generate(n, 0, 42)
+    circ = pa.Circuit.synthetic(n - 2)
+    setup = pa.SetupForProver(ctx, circ)
+    want_vk, want_proof = setup.verification_key_bytes(pa.crs42_g2_bytes()), setup.prove(circ)
+    ctx.comm_init(0, 1, pa.comm_unique_id(), 0)
+    assert ctx.comm_info()[:2] == (0, 1)
+    assert setup.verification_key_bytes(pa.crs42_g2_bytes()) == want_vk
+    assert setup.prove(circ) == want_proof
+    assert ctx.comm_info()[2] == 2 + 4                           # 11 commitments of the key in two batches; a proof has 4 batches (4 wires, z, 4 quotient parts, 2 openings)
+    ctx.comm_destroy()
+    assert setup.prove(circ) == want_proof and ctx.comm_info() == (0, 1, 0)
+    ctx.close()
+
+
+def test_two_plonkit_processes_share_the_key(tmp_path):
+    """one `plonkit` process per rank (PLONKIT_WORLD / PLONKIT_RANK / PLONKIT_COMM, cli_main.cpp), no Python and no torch
+    in the exchange: each rank keeps half of the key resident, the built-in combiner joins the partial sums (TCP hub,
+    because both ranks sit on this box's single GPU); rank 0 writes vk.bin / proof.bin, identical to the one-process files"""
+    import subprocess
+    import plonkit_amd as pa
+    cli = os.path.join(os.path.dirname(pa.lib_path()), "plonkit")
+    log_n = 14
+    circ = pa.Circuit.synthetic((1 << log_n) - 2)
+    f = lambda name: str(tmp_path / name)
+    open(f("c.r1cs"), "wb").write(circ.export("r1cs"))
+    open(f("w.wtns"), "wb").write(circ.export("wtns"))
+    subprocess.check_call([cli, "setup", "-p", str(log_n), "-m", f("key.bin")], stderr=subprocess.DEVNULL)
+    subprocess.check_call([cli, "export-verification-key", "-m", f("key.bin"), "-c", f("c.r1cs"), "-v", f("vk1.bin")], stderr=subprocess.DEVNULL)
+    subprocess.check_call([cli, "prove", "-m", f("key.bin"), "-c", f("c.r1cs"), "-w", f("w.wtns"), "-p", f("p1.bin"), "-j", f("j1.json"), "-i", f("i1.json")],
+                          stderr=subprocess.DEVNULL)
+    for cmd, outs in ((["export-verification-key", "-m", f("key.bin"), "-c", f("c.r1cs"), "-v", f("vk2.bin")], ("vk1.bin", "vk2.bin")),
+                      (["prove", "-m", f("key.bin"), "-c", f("c.r1cs"), "-w", f("w.wtns"), "-p", f("p2.bin"), "-j", f("j2.json"), "-i", f("i2.json")], ("p1.bin", "p2.bin"))):
+        port = _free_port()
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, PLONKIT_WORLD="2", PLONKIT_RANK=str(rank), PLONKIT_COMM="tcp:%d" % port, PLONKIT_DEVICE="0")
+            procs.append(subprocess.Popen([cli] + cmd, env=env, stderr=subprocess.PIPE))
+        for p in procs:
+            _, err = p.communicate(timeout=300)
+            assert p.returncode == 0, err.decode()[-2000:]
+        assert open(f(outs[0]), "rb").read() == open(f(outs[1]), "rb").read()
+    assert pa.verify(open(f("vk2.bin"), "rb").read(), open(f("p2.bin"), "rb").read())
+    # the RCCL transport through the same binary: a communicator of one rank (id file written and read back)
+    env = dict(os.environ, PLONKIT_WORLD="1", PLONKIT_RANK="0", PLONKIT_COMM="rccl:" + f("rccl.id"))
+    subprocess.check_call([cli, "prove", "-m", f("key.bin"), "-c", f("c.r1cs"), "-w", f("w.wtns"), "-p", f("p3.bin"), "-j", f("j3.json"), "-i", f("i3.json")],
+                          env=env, stderr=subprocess.DEVNULL)
+    assert open(f("p3.bin"), "rb").read() == open(f("p1.bin"), "rb").read() and os.path.getsize(f("rccl.id")) == 128
+
+
+def _native_rank(rank, world, port, log_n, q):
+    import plonkit_amd as pa
+    n = 1 << log_n
+    local = n // world
+    ctx = pa.Context(0)
+    ctx.srs_generate(local, rank * local, 42)
+    ctx.comm_init_tcp(rank, world, port, rank * local)
+    circ = pa.Circuit.synthetic(n - 2)
+    setup = pa.SetupForProver(ctx, circ)
+    q.put((rank, setup.verification_key_bytes(pa.crs42_g2_bytes()), setup.prove(circ), ctx.comm_info()))
+    ctx.close()
+
+
+def test_two_ranks_with_the_builtin_combiner():
+    """the Python mirror of the same path: Context.comm_init_tcp instead of ShardedProver's torch.distributed combiner"""
+    import plonkit_amd as pa
+    log_n, world = 13, 2
+    n = 1 << log_n
+    ctx = pa.Context(0)
+    ctx.srs_generate(n, 0, 42)
+    circ = pa.Circuit.synthetic(n - 2)
+    setup = pa.SetupForProver(ctx, circ)
+    want = (setup.verification_key_bytes(pa.crs42_g2_bytes()), setup.prove(circ))
+    port = _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_native_rank, args=(r, world, port, log_n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for rank, vk, proof, info in res:
+        assert (vk, proof) == want, rank
+        assert info == (rank, world, 6)
