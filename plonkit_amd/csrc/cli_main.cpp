@@ -289,7 +289,7 @@ static int run(int argc, char **argv) {
         phase("plk_create (HIP init)");
         uint8_t g2[256];
         plk_setup *s = nullptr;
-        if (rk.world > 1) {                                          // the slice of the key depends on the domain size
+        if (rk.world > 1 || !rk.comm.empty()) {                      // the slice of the key depends on the domain size
             CK("prepare err", plk_setup_prepare(ctx, c, &s));
             phase("setup_prepare");
             join_ranks(ctx, rk, plk_setup_domain_size(s));
