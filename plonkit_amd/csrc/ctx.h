@@ -82,7 +82,7 @@ struct plk_ctx {
     struct MsmSlot {
         plk::DevBuf a, b, c, d, e, f;
         void *pinned = nullptr; size_t pinned_cap = 0;
-        uint32_t windows = 0, c_bits = 0, pending_parts = 0, batch = 1, roles = 2;
+        uint32_t windows = 0, c_bits = 0, pending_parts = 0, batch = 1, roles = 2, fine_bits = 7;
         hipStream_t stream = nullptr;        // the kernels of this commitment; ordered after the caller's stream by `ready`
         hipEvent_t ready = nullptr;
         hipEvent_t ev[2] = {nullptr, nullptr};   // optional bracket around msm_accumulate (bench roofline)

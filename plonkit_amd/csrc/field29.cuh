@@ -22,6 +22,7 @@
 namespace plk {
 
 constexpr uint32_t M29 = (1u << 29) - 1;
+constexpr uint32_t MULW_A_LIMB_MAX = 3280000000u;          // largest limb of mulw's LEFT operand (derivation at mulw)
 
 struct FrW {
     static constexpr uint32_t P29[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
@@ -142,8 +143,11 @@ template <class WP> PLK_HD W9<WP> neg2(const W9<WP> &a) {
 }
 template <class WP> PLK_HD W9<WP> addn(const W9<WP> &a, const W9<WP> &b) { return normw(addw(a, b)); }
 
-// Montgomery product, radix 2^29, R' = 2^261.  Limbs: a < 2^30, b < 2^29 (normalised).
-// Every column accumulates at most 9 * (2^59 + 2^58) < 2^63: no carries until the end.
+// Montgomery product, radix 2^29, R' = 2^261.  Limbs: b < 2^29 (normalised); a may be an un-normalised sum or padded
+// difference: a global column receives at most 9 products a_j*b_i, 9 products m_i*p_j (both factors < 2^29) and one
+// carry (< 2^35), so  9*A*(2^29-1) + 9*(2^29-1)^2 + 2^35 < 2^64  allows a-limbs up to A = 3.28e9 (MULW_A_LIMB_MAX).
+// The sums the kernels feed in: x + y (< 2^30), x + PAD2 - y (< 2^29 + 2.66e9 = 3.19e9).  Checked on the host at the
+// bound (tests/host/field29_check.hip).
 template <class WP>
 PLK_HD W9<WP> mulw(const W9<WP> &a, const W9<WP> &b) {
     uint64_t t[10];

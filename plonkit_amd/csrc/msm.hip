@@ -34,12 +34,19 @@
 #include "hostmath.h"
 #include <cstring>
 #include <cstdlib>
+#include <type_traits>
 
 namespace plk {
 
 constexpr int MSM_THREADS = 256;
-constexpr uint32_t FINE_BITS = 7;                 // 128 buckets per accumulate workgroup
-constexpr uint32_t FINE = 1u << FINE_BITS;
+// Buckets per accumulate workgroup = 2^FB ("fine" part of the bucket index; the coarse part selects the bin).  Two shapes
+// are compiled (template parameter FB of the kernels below) and chosen per commitment by pick_fine_bits():
+//   FB = 6: 64 buckets per task.  At c = 17 that is 1024 coarse bins of ~15 K entries at 2^20 terms = ONE task per bin,
+//           so every bucket is reduced once (65 K task-buckets) — the bucket reduction (msm_task_reduce) is not a latency
+//           detail: in VALU work it was 38 % of the accumulation (992 waves x 37 dependent full additions of 14 products
+//           against 15.7 M mixed additions of 9.3), and it shares the GPU with the next commitment's accumulation.
+//   FB = 7: 128 buckets per task, 512 bins of ~31 K entries = two tasks per bin (131 K task-buckets): the round-1 shape.
+constexpr uint32_t FINE_BITS_MAX = 7;
 constexpr uint32_t CHUNK = 16384;                 // entries per accumulate workgroup (sorted in 64 KB of LDS; two workgroups per CU)
 constexpr uint32_t DIGIT_CHUNK = 16384;            // scalars per partition workgroup (per window): 64 KB of LDS staging
 constexpr uint32_t TASK_MAX = CHUNK;
@@ -51,7 +58,8 @@ struct MsmParams {
     uint32_t n;
     uint32_t c;               // window bits
     uint32_t windows;         // W per commitment
-    uint32_t coarse_bits;     // c - 1 - FINE_BITS
+    uint32_t fine_bits;       // FB: buckets per accumulate task = 2^FB
+    uint32_t coarse_bits;     // c - 1 - fine_bits
     uint32_t nbins;           // 1 << coarse_bits
     uint32_t batch;           // number of scalar vectors (same n, same bases); "global window" = m * W + w
     uint32_t debug;           // experiments only: 1 = skip the additions (sort cost), 0 = normal
@@ -116,7 +124,7 @@ __global__ void __launch_bounds__(PART_THREADS) msm_partition(const int32_t *dig
     __syncthreads();
     for (uint32_t i = first + tid; i < last; i += PART_THREADS) {
         int32_t d = dg[i];
-        if (d) { uint32_t mg = (uint32_t)(d < 0 ? -d : d) - 1; atomicAdd(&lcnt[mg >> FINE_BITS], 1u); }
+        if (d) { uint32_t mg = (uint32_t)(d < 0 ? -d : d) - 1; atomicAdd(&lcnt[mg >> p.fine_bits], 1u); }
     }
     __syncthreads();
     if (!SCATTER) {
@@ -143,8 +151,8 @@ __global__ void __launch_bounds__(PART_THREADS) msm_partition(const int32_t *dig
     for (uint32_t i = first + tid; i < last; i += PART_THREADS) {
         int32_t d = dg[i];
         if (d) {
-            uint32_t mg = (uint32_t)(d < 0 ? -d : d) - 1, bin = mg >> FINE_BITS;
-            staged[lstart[bin] + atomicAdd(&lcnt[bin], 1u)] = ((copy_tag | i) << 8) | (d < 0 ? 0x80u : 0u) | (mg & (FINE - 1));
+            uint32_t mg = (uint32_t)(d < 0 ? -d : d) - 1, bin = mg >> p.fine_bits;
+            staged[lstart[bin] + atomicAdd(&lcnt[bin], 1u)] = ((copy_tag | i) << 8) | (d < 0 ? 0x80u : 0u) | (mg & ((1u << p.fine_bits) - 1));
         }
     }
     __syncthreads();
@@ -321,8 +329,13 @@ static int32_t ensure_base_table(plk_ctx *ctx, uint32_t copies, hipStream_t stre
 // Per-task output of kernel A: 128 PRIMARY slots (a bucket whose run lies inside one lane's slice), and per
 // lane one HEAD slot (its first run continues a bucket begun by an earlier lane) and one TAIL slot (its last
 // run is continued by a later lane).  Which slots are live follows from the bucket offsets alone.
-constexpr uint32_t SLOT_PRIMARY = 0, SLOT_HEAD = FINE, SLOT_TAIL = FINE + MSM_THREADS, SLOTS_PER_TASK = FINE + 2 * MSM_THREADS;
-constexpr uint32_t META_PER_TASK = FINE + 2;              // start[0..128] and the entry count
+template <uint32_t FB> struct Shape {
+    static constexpr uint32_t FINE = 1u << FB;
+    static constexpr uint32_t SLOT_PRIMARY = 0, SLOT_HEAD = FINE, SLOT_TAIL = FINE + MSM_THREADS, SLOTS_PER_TASK = FINE + 2 * MSM_THREADS;
+    static constexpr uint32_t META_PER_TASK = FINE + 2;   // start[0..FINE] and the entry count
+};
+static uint32_t slots_per_task(uint32_t fb) { return (1u << fb) + 2 * MSM_THREADS; }
+static uint32_t meta_per_task(uint32_t fb) { return (1u << fb) + 2; }
 
 // Kernel A — one workgroup per task = one slice (<= CHUNK entries) of a (window, coarse bin): 128 buckets.
 //  1. counting sort of the slice by fine bucket inside LDS
@@ -332,9 +345,12 @@ constexpr uint32_t META_PER_TASK = FINE + 2;              // start[0..128] and t
 // Only mixed additions happen here (10 products each, ~25 KB of code).  One wave per SIMD already saturates the
 // VALU (tools/ubench_w: 15 G mixed-adds/s at any occupancy, 25 % less when squeezed into 128 VGPRs with
 // spills), so the register budget is the full 256 and nothing is spilled.  Kernel B folds the partial sums.
+template <uint32_t FB>
 __global__ void __launch_bounds__(MSM_THREADS, 2) msm_accumulate(const G1Affine *bases, const uint32_t *entries,
                                                                   const uint32_t *bin_start, const uint32_t *task_start,
                                                                   XyzzW *partials, uint32_t *task_meta, MsmParams p) {
+    constexpr uint32_t FINE = Shape<FB>::FINE, SLOT_PRIMARY = Shape<FB>::SLOT_PRIMARY, SLOT_HEAD = Shape<FB>::SLOT_HEAD,
+                       SLOT_TAIL = Shape<FB>::SLOT_TAIL, SLOTS_PER_TASK = Shape<FB>::SLOTS_PER_TASK, META_PER_TASK = Shape<FB>::META_PER_TASK;
     extern __shared__ uint32_t sorted[];                      // [CHUNK]
     __shared__ uint32_t cnt[FINE], start[FINE + 1], cursor[FINE];
     const uint32_t tid = threadIdx.x, task = blockIdx.x;
@@ -354,11 +370,16 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_accumulate(const G1Affine 
     __syncthreads();
     for (uint32_t idx = tid; idx < nc; idx += MSM_THREADS) atomicAdd(&cnt[entries[s + idx] & (FINE - 1)], 1u);
     __syncthreads();
-    if (tid < 64) {                                           // exclusive scan of 128 counts by one wave
-        uint32_t a = cnt[2 * tid], b = cnt[2 * tid + 1], v = a + b;
+    if (tid < 64) {                                           // exclusive scan of the FINE counts by one wave
+        constexpr uint32_t PER = FINE / 64;                   // 1 or 2 buckets per lane
+        uint32_t own[PER], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) { own[k] = cnt[PER * tid + k]; sum += own[k]; }
+        uint32_t v = sum;
         for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off); if ((int)tid >= off) v += t; }
-        uint32_t ex = v - (a + b);
-        start[2 * tid] = ex; start[2 * tid + 1] = ex + a;
+        uint32_t run = v - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) { start[PER * tid + k] = run; run += own[k]; }
         if (tid == 63) start[FINE] = v;
     }
     __syncthreads();
@@ -404,13 +425,15 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_accumulate(const G1Affine 
 // Kernel B0 — folds a bucket that kernel A spread over more than HOT_SPAN lanes (repeated scalars: a witness
 // full of 0/1 values) into that bucket's otherwise unused PRIMARY slot, RL lanes per task working together.
 // Uniform scalars never take this path; the kernel then only reads the bucket offsets.
-constexpr uint32_t RL = 32, RL_LOG = 5, RB = FINE / RL, RB_LOG = 2, HOT_SPAN = 8;
-static_assert((1u << RB_LOG) == RB && (1u << RL_LOG) == RL, "task-reduce shape");
+constexpr uint32_t RL = 32, RL_LOG = 5, HOT_SPAN = 8;       // RL lanes per task, RB = FINE / RL buckets per lane
 __device__ __forceinline__ uint32_t bucket_span(const uint32_t *meta, uint32_t b, uint32_t mu) {
     const uint32_t s0 = meta[b], e0 = meta[b + 1];
     return e0 > s0 ? (e0 - 1) / mu - s0 / mu : 0;
 }
+template <uint32_t FB>
 __global__ void __launch_bounds__(MSM_THREADS) msm_fold_hot(XyzzW *partials, const uint32_t *task_meta, const uint32_t *task_start, uint32_t total_bins) {
+    constexpr uint32_t FINE = Shape<FB>::FINE, SLOT_PRIMARY = Shape<FB>::SLOT_PRIMARY, SLOT_HEAD = Shape<FB>::SLOT_HEAD,
+                       SLOTS_PER_TASK = Shape<FB>::SLOTS_PER_TASK, META_PER_TASK = Shape<FB>::META_PER_TASK, RB = FINE / RL;
     const uint32_t gt = blockIdx.x * MSM_THREADS + threadIdx.x;
     const uint32_t task = gt / RL, sub = gt % RL;
     const bool live = task < task_start[total_bins];
@@ -443,8 +466,12 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_fold_hot(XyzzW *partials, con
 // step loop — every step is "X += O" or "Y += X" with the operand selected beforehand — so the operands live
 // in registers: passing two 144-byte points to an out-of-line addition through scratch memory cost more
 // L2 write-through traffic than the arithmetic (measured 0.60 ms for this kernel against 0.3 ms of VALU work).
+template <uint32_t FB>
 __global__ void __launch_bounds__(MSM_THREADS, 2) msm_task_reduce(const XyzzW *partials, const uint32_t *task_meta,
                                                                    const uint32_t *task_start, XyzzW *task_out, uint32_t total_bins) {
+    constexpr uint32_t FINE = Shape<FB>::FINE, SLOT_PRIMARY = Shape<FB>::SLOT_PRIMARY, SLOT_HEAD = Shape<FB>::SLOT_HEAD, SLOT_TAIL = Shape<FB>::SLOT_TAIL,
+                       SLOTS_PER_TASK = Shape<FB>::SLOTS_PER_TASK, META_PER_TASK = Shape<FB>::META_PER_TASK, RB = FINE / RL, RB_LOG = FB - RL_LOG;
+    static_assert(FB >= RL_LOG + 1, "at least two buckets per lane");
     const uint32_t gt = blockIdx.x * MSM_THREADS + threadIdx.x;
     const uint32_t task = gt / RL, sub = gt % RL;
     const bool live = task < task_start[total_bins];
@@ -508,24 +535,43 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_task_reduce(const XyzzW *p
     if (live && sub == 0) store_xyzzw(task_out + 2 * (size_t)task, X);
 }
 
+// ------------------------------------------------------------------------ bin folding
+// A coarse bin cut into many tasks (repeated scalars: all ones, all r-1, a witness of booleans put 2^20 entries into one
+// bucket of every window) would be walked task by task by ONE thread of msm_window_sums — a serial chain of full
+// additions (all r-1 at 2^20: 3.4 ms against 2.0 ms for uniform scalars).  The per-task sums of a bin simply add up
+// (same bucket range), so one wave per such bin folds them first: lane l takes tasks l, l + 64, .. then a shuffle tree;
+// the bin's first task receives (sum S, sum T), the others the identity.  Bins with <= BIN_FOLD_MIN tasks are left alone:
+// for uniform scalars the kernel only reads the task offsets.
+constexpr uint32_t BIN_FOLD_MIN = 4;
+__global__ void __launch_bounds__(MSM_THREADS) msm_bin_fold(XyzzW *task_out, const uint32_t *task_start, uint32_t total_bins) {
+    const uint32_t bin = blockIdx.x * (MSM_THREADS / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
+    if (bin >= total_bins) return;
+    const uint32_t t0 = task_start[bin], t1 = task_start[bin + 1];
+    if (t1 - t0 <= BIN_FOLD_MIN) return;                       // wave-uniform
+    for (uint32_t which = 0; which < 2; which++) {            // 0: S, 1: T
+        XyzzW acc = xyzzw_identity();
+        for (uint32_t t = t0 + lane; t < t1; t += 64) { XyzzW o = load_xyzzw(task_out + 2 * (size_t)t + which); xyzzw_add_nl(acc, o); }
+        for (uint32_t x = 1; x < 64; x <<= 1) { XyzzW o = shfl_xor_w(acc, x); xyzzw_add_nl(acc, o); }
+        for (uint32_t t = t0 + lane; t < t1; t += 64) store_xyzzw(task_out + 2 * (size_t)t + which, t == t0 ? acc : xyzzw_identity());
+    }
+}
+
 // ------------------------------------------------------------------------ window reduction
-// W_w = sum_t S_t + 2^FINE_BITS * sum_c c * D_c,  D_c = sum of T_t over the tasks of coarse bin c.
-// Two workgroups per window, running side by side: role 0 tree-sums the S_t, role 1 forms sum_c c * D_c as
-// the sum of the suffix sums of D (Hillis-Steele scan through LDS, then a tree).  Both are pure chains of
-// full additions issued from one inlined call site (operands in registers, see msm_task_reduce); the
-// shift by 2^FINE_BITS and the final addition are left to the host Horner, which doubles anyway.
-// Results are exported in the library's external form (canonical, R = 2^256).
-// 256 threads; with 512 coarse bins (c = 17) thread t serves bins t and t + 256:  sum_c c*D_c =
-// sum_t t*(D_t + D_{t+256}) + 256 * sum_t D_{t+256}, the last sum being a third workgroup (role 2) whose weight
-// 2^8 is again left to the host.
+// W_w = sum_t S_t + 2^FB * sum_c c * D_c,  D_c = sum of T_t over the tasks of coarse bin c.
+// 256 threads; thread t serves bins t, t + 256, .. (nbins <= 1024: up to four of them).  With c = 256 u + t:
+//     sum_c c * D_c = sum_t t * E_t + 256 * sum_{u >= 1} u * F_u,   E_t = sum_u D_{t + 256 u},   F_u = sum_t D_{t + 256 u}.
+// One workgroup per role, side by side: role 0 tree-sums the S_t; role 1 forms sum_t t * E_t as the sum of the suffix
+// sums of E (Hillis-Steele scan through LDS, then a tree); role 1 + u (u >= 1) tree-sums F_u.  All are pure chains of
+// full additions issued from one inlined call site (operands in registers, see msm_task_reduce); the weights 2^FB, 2^8
+// and u are left to the host, which doubles anyway.  Results leave in the library's external form (canonical, R = 2^256).
 constexpr uint32_t THREADS_LOG = 8;
 static_assert((1u << THREADS_LOG) == MSM_THREADS, "THREADS_LOG");
 __global__ void __launch_bounds__(MSM_THREADS, 2) msm_window_sums(const XyzzW *task_out, const uint32_t *task_start, G1Xyzz *window_out, uint32_t nbins, uint32_t roles) {
     __shared__ __attribute__((aligned(16))) XyzzW sh[MSM_THREADS];
     const uint32_t tid = threadIdx.x, w = blockIdx.x, role = blockIdx.y;
-    const uint32_t halves = (nbins + MSM_THREADS - 1) / MSM_THREADS;            // 1 or 2
-    uint32_t u = role == 2 ? 1 : 0;
-    const uint32_t u_end = role == 2 ? 2 : halves;
+    const uint32_t halves = (nbins + MSM_THREADS - 1) / MSM_THREADS;            // 1 .. 4
+    uint32_t u = role >= 2 ? role - 1 : 0;
+    const uint32_t u_end = role >= 2 ? role : halves;
     uint32_t t = 0, t_end = 0;
     auto open_bin = [&]() {                                   // next non-empty bin of this thread
         for (; u < u_end; u++) {
@@ -604,6 +650,16 @@ static uint32_t pick_window_bits(uint64_t n, bool have_table) {
     return 17;                                                // 15 windows; 2^16 buckets = 512 coarse bins x 128
 }
 
+// Buckets per task.  64 (one task per coarse bin at the 2^20-term / one-bucket-set shape, half the bucket-reduction work)
+// whenever the coarse part then still fits the 1024 bins msm_window_sums serves; PLK_MSM_FINE_BITS overrides (A/B runs).
+static uint32_t pick_fine_bits(uint64_t n, uint32_t c) {
+    static const int probe = [] { const char *e = getenv("PLK_MSM_FINE_BITS"); return e ? atoi(e) : 0; }();
+    uint32_t fb = (probe == 6 || probe == 7) ? (uint32_t)probe : 6;
+    (void)n;
+    if (c - 1 - fb > 10) fb = FINE_BITS_MAX;                  // at most 1024 coarse bins
+    return fb;
+}
+
 int32_t ensure_pinned(plk_ctx *ctx, size_t bytes);
 
 static int32_t slot_pinned(plk_ctx::MsmSlot &S, size_t bytes) {
@@ -669,7 +725,8 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     p.groups = p.windows / copies;                            // copies > 1 only for c = 17: 15 windows, copies | 15
     p.nbits = nbits;
     p.copy_stride = copies > 1 ? (uint32_t)(p.groups * ctx->srs_n) : 0;
-    p.coarse_bits = p.c - 1 - FINE_BITS;
+    p.fine_bits = pick_fine_bits(n, p.c);
+    p.coarse_bits = p.c - 1 - p.fine_bits;
     p.nbins = 1u << p.coarse_bits;
     p.batch = batch;
     static const uint32_t probe_debug = [] { const char *e = getenv("PLK_MSM_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();   // experiments only, read once
@@ -680,9 +737,10 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     const uint32_t max_tasks = total_bins + (uint32_t)(((uint64_t)total_windows * n) / TASK_MAX) + 1;
     PLK_TRY(S.a.reserve((size_t)(3 * total_bins + 4) * sizeof(uint32_t)));               // hist/cursor, bin_start, task_start
     PLK_TRY(S.b.reserve((size_t)total_windows * n * sizeof(uint32_t)));                   // entries
+    const uint32_t META_PER_TASK = meta_per_task(p.fine_bits), SLOTS_PER_TASK = slots_per_task(p.fine_bits);
     PLK_TRY(S.c.reserve((size_t)max_tasks * 2 * sizeof(XyzzW) + (size_t)max_tasks * META_PER_TASK * 4));  // per-task (S, T) + bucket offsets
     PLK_TRY(S.e.reserve((size_t)max_tasks * SLOTS_PER_TASK * sizeof(XyzzW)));             // lane partial sums
-    PLK_TRY(S.d.reserve((size_t)3 * total_sets * sizeof(G1Xyzz)));                     // per window: sum S, sum c*D
+    PLK_TRY(S.d.reserve((size_t)5 * total_sets * sizeof(G1Xyzz)));                     // per bucket set: sum S, sum t*E_t, F_1..F_3
     uint32_t *hist = S.a.as<uint32_t>(), *bin_start = hist + total_bins, *task_start = bin_start + total_bins + 1;
     uint32_t *entries = S.b.as<uint32_t>();
     XyzzW *task_out = S.c.as<XyzzW>();
@@ -700,21 +758,27 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     static bool attr_set = false;
     if (!attr_set) {
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_partition<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<6>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<7>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
         attr_set = true;
     }
     hipLaunchKernelGGL(msm_partition<false>, dim3(pblocks, total_windows), dim3(PART_THREADS), plds_count, stream, (const int32_t *)digits, p, hist, (const uint32_t *)nullptr, (uint32_t *)nullptr);
     hipLaunchKernelGGL(msm_scan_bins, dim3(1), dim3(1024), 0, stream, hist, bin_start, task_start, total_bins);
     hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks, total_windows), dim3(PART_THREADS), plds_scatter, stream, (const int32_t *)digits, p, hist, (const uint32_t *)bin_start, entries);
     if (ctx->ev_on) PLK_HIP(hipEventRecord(S.ev[0], stream));
-    hipLaunchKernelGGL(msm_accumulate, dim3(max_tasks), dim3(MSM_THREADS), CHUNK * sizeof(uint32_t), stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
-                       (const uint32_t *)task_start, partials, task_meta, p);
-    if (ctx->ev_on) PLK_HIP(hipEventRecord(S.ev[1], stream));
-    hipLaunchKernelGGL(msm_fold_hot, dim3((max_tasks * RL + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
-                       partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
-    hipLaunchKernelGGL(msm_task_reduce, dim3((max_tasks * RL + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
-                       (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
-    const uint32_t roles = p.nbins > MSM_THREADS ? 3 : 2;       // points per bucket set left for the host
+    const uint32_t rblocks = (max_tasks * RL + MSM_THREADS - 1) / MSM_THREADS;
+    auto launch_shape = [&](auto fb_tag) {
+        constexpr uint32_t FB = decltype(fb_tag)::value;
+        hipLaunchKernelGGL(msm_accumulate<FB>, dim3(max_tasks), dim3(MSM_THREADS), CHUNK * sizeof(uint32_t), stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
+                           (const uint32_t *)task_start, partials, task_meta, p);
+        if (ctx->ev_on) (void)hipEventRecord(S.ev[1], stream);
+        hipLaunchKernelGGL(msm_fold_hot<FB>, dim3(rblocks), dim3(MSM_THREADS), 0, stream, partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
+        hipLaunchKernelGGL(msm_task_reduce<FB>, dim3(rblocks), dim3(MSM_THREADS), 0, stream,
+                           (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
+    };
+    if (p.fine_bits == 6) launch_shape(std::integral_constant<uint32_t, 6>{}); else launch_shape(std::integral_constant<uint32_t, 7>{});
+    hipLaunchKernelGGL(msm_bin_fold, dim3((total_bins + MSM_THREADS / 64 - 1) / (MSM_THREADS / 64)), dim3(MSM_THREADS), 0, stream, task_out, (const uint32_t *)task_start, total_bins);
+    const uint32_t roles = 1 + (p.nbins + MSM_THREADS - 1) / MSM_THREADS;   // points per bucket set left for the host: S, sum t*E_t, F_1 ..
     hipLaunchKernelGGL(msm_window_sums, dim3(total_sets, roles), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins, roles);
     PLK_HIP(hipGetLastError());
     PLK_TRY(slot_pinned(S, (size_t)roles * total_sets * sizeof(G1Xyzz)));
@@ -722,6 +786,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     S.roles = roles;
     S.windows = p.groups;
     S.c_bits = p.c;
+    S.fine_bits = p.fine_bits;
     ctx->msm_enq++;
     return PLK_OK;
 }
@@ -753,19 +818,20 @@ int32_t msm_finish_batch(plk_ctx *ctx, hipStream_t, host::HJac *out) {
     for (uint32_t m = 0; m < S.batch; m++) {
         HJac acc = HJac::inf();
         if (S.windows) {
-            // per bucket set the device leaves (sum S, sum_t t*E_t [, sum of the D of bins >= 256]);
-            // W = sum S + 2^FINE_BITS * (sum_t t*E_t + 2^8 * upper)
+            // per bucket set the device leaves (sum S, sum_t t*E_t, F_1, .., F_{halves-1});
+            // W = sum S + 2^FB * (sum_t t*E_t + 2^8 * sum_u u*F_u)
             const size_t per = (size_t)16 * S.roles;
             const uint64_t *raw = reinterpret_cast<const uint64_t *>(S.pinned) + per * m * S.windows;
             for (int w = (int)S.windows - 1; w >= 0; w--) {
                 for (uint32_t i = 0; i < S.c_bits; i++) acc = jac_double(acc);
                 HJac d = xyzz_host_to_jac(raw + per * w + 16);
-                if (S.roles == 3) {
-                    HJac up = xyzz_host_to_jac(raw + per * w + 32);
+                if (S.roles > 2) {
+                    HJac run = HJac::inf(), up = HJac::inf();             // sum_u u*F_u = sum of the suffix sums of F
+                    for (uint32_t r = S.roles - 1; r >= 2; r--) { run = jac_add(run, xyzz_host_to_jac(raw + per * w + 16 * r)); up = jac_add(up, run); }
                     for (uint32_t i = 0; i < THREADS_LOG; i++) up = jac_double(up);
                     d = jac_add(d, up);
                 }
-                for (uint32_t i = 0; i < FINE_BITS; i++) d = jac_double(d);
+                for (uint32_t i = 0; i < S.fine_bits; i++) d = jac_double(d);
                 acc = jac_add(acc, jac_add(xyzz_host_to_jac(raw + per * w), d));
             }
         } else {

@@ -114,12 +114,29 @@ __device__ __forceinline__ void r4_load(Radix4Group &q, const LdsTile &L, const 
     q.t3 = small_tw(tw, (jl + h) << (log_r - s - 2), log_r);
 }
 
+// Lazy normalisation: mulw takes a left operand with limbs up to 3.28e9 (field29.cuh, MULW_A_LIMB_MAX), so the sums and
+// differences that only feed a product, or another sum, are left as raw limb-wise results; one carry propagation per
+// OUTPUT (4 per group instead of 10).  Limb bounds (normalised = < 2^29 = 0.54e9; PAD2/PAD4 limbs < 2.68e9):
+//     x2 + PAD2 - y3 < 3.22e9 (product operand)      x0 + PAD4 - y1 - b3 < 3.22e9      everything else smaller.
+// Values grow by at most 4p per pair of stages, as before.
 __device__ __forceinline__ void r4_finish(const Radix4Group &q, const LdsTile &L, uint32_t s) {
-    const FrW9 y1 = s ? mulw(q.x1, q.t1) : normw(q.x1), y3 = s ? mulw(q.x3, q.t1) : normw(q.x3);   // stage 0: twiddle 1
-    const FrW9 b0 = addn(q.x0, y1), b1 = sub2(q.x0, y1);
-    const FrW9 b2 = mulw(addn(q.x2, y3), q.t2), b3 = mulw(sub2(q.x2, y3), q.t3);
-    L.put(q.a0, addn(b0, b2)); L.put(q.a2, sub2(b0, b2));
-    L.put(q.a1, addn(b1, b3)); L.put(q.a3, sub2(b1, b3));
+    const FrW9 y1 = s ? mulw(q.x1, q.t1) : q.x1, y3 = s ? mulw(q.x3, q.t1) : q.x3;                  // stage 0: twiddle 1
+    FrW9 u, v;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { u.l[i] = q.x2.l[i] + y3.l[i]; v.l[i] = q.x2.l[i] + FrW::PAD2[i] - y3.l[i]; }
+    const FrW9 b2 = s ? mulw(u, q.t2) : u;                                                          // stage 1 of the first pair: omega_4^0 = 1
+    const FrW9 b3 = mulw(v, q.t3);
+    FrW9 o0, o1, o2, o3;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const uint32_t b0 = q.x0.l[i] + y1.l[i];                                                    // x0 + y1
+        o0.l[i] = b0 + b2.l[i];
+        o2.l[i] = b0 + FrW::PAD4[i] - b2.l[i];                                                      // (b2 may be the raw x2 + y3 < 2.2p: 4p covers it)
+        o1.l[i] = q.x0.l[i] + FrW::PAD2[i] - y1.l[i] + b3.l[i];
+        o3.l[i] = q.x0.l[i] + FrW::PAD4[i] - y1.l[i] - b3.l[i];
+    }
+    L.put(q.a0, normw(o0)); L.put(q.a2, normw(o2));
+    L.put(q.a1, normw(o1)); L.put(q.a3, normw(o3));
 }
 
 __device__ __forceinline__ void dit_stages(const LdsTile &L, const PowTable &tw, uint32_t log_r, uint32_t log_c, uint32_t pitch, uint32_t tid) {

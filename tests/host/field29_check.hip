@@ -48,6 +48,42 @@ int main() {
         FqW9 r1 = reduce_small(big), r2 = reduce_full(big);                           // same residue (x * one / R)
         for (int k = 0; k < 9; k++) if (r1.l[k] != r2.l[k]) { bad++; if (bad < 5) printf("reduce_small mismatch %d\n", it); break; }
     }
+    // mulw with an un-normalised left operand (ntt.hip r4_finish): limbs at MULW_A_LIMB_MAX against a right operand with
+    // every limb at 2^29 - 1, raw padded differences against their normalised forms, and one lazy radix-4 butterfly
+    // against the strictly normalised formulas
+    {
+        FrW9 amax, bmax;
+        for (int i = 0; i < 9; i++) { amax.l[i] = MULW_A_LIMB_MAX; bmax.l[i] = M29; }
+        amax.l[8] = 0x00ffffffu; bmax.l[8] = 0x00ffffffu;                              // keep the values inside the 2^261 capacity
+        FrW9 r1 = s_from_w(mulw(amax, bmax)), r2 = s_from_w(mulw(normw(amax), bmax));
+        for (int k = 0; k < 9; k++) if (r1.l[k] != r2.l[k]) { bad++; printf("mulw at the limb bound\n"); break; }
+    }
+    for (int it = 0; it < 20000; it++) {
+        Fr a = rnd_fp<FrParams>(), b = rnd_fp<FrParams>(), c = rnd_fp<FrParams>(), d = rnd_fp<FrParams>(), t = rnd_fp<FrParams>(), t2 = rnd_fp<FrParams>(), t3 = rnd_fp<FrParams>();
+        FrW9 x0 = unpack<FrW>(a), x1 = unpack<FrW>(b), x2 = unpack<FrW>(c), x3 = unpack<FrW>(d);
+        FrW9 w1 = w_from_s(unpack<FrW>(t)), w2 = w_from_s(unpack<FrW>(t2)), w3 = w_from_s(unpack<FrW>(t3));
+        if (it & 1) for (int k = 0; k < 9; k++) { x0.l[k] = M29; x2.l[k] = M29; }       // largest normalised limbs
+        x0.l[8] &= 0x00ffffffu; x2.l[8] &= 0x00ffffffu;
+        // strict
+        FrW9 y1 = mulw(x1, w1), y3 = mulw(x3, w1);
+        FrW9 b0 = addn(x0, y1), b1 = sub2(x0, y1), b2 = mulw(addn(x2, y3), w2), b3 = mulw(sub2(x2, y3), w3);
+        FrW9 s0 = addn(b0, b2), s2 = sub2(b0, b2), s1 = addn(b1, b3), s3 = sub2(b1, b3);
+        // lazy
+        FrW9 u, v, o0, o1, o2, o3;
+        for (int i = 0; i < 9; i++) { u.l[i] = x2.l[i] + y3.l[i]; v.l[i] = x2.l[i] + FrW::PAD2[i] - y3.l[i]; }
+        for (int i = 0; i < 9; i++) if (v.l[i] > MULW_A_LIMB_MAX || u.l[i] > MULW_A_LIMB_MAX) { bad++; printf("limb bound exceeded\n"); break; }
+        FrW9 c2 = mulw(u, w2), c3 = mulw(v, w3);
+        for (int i = 0; i < 9; i++) {
+            const uint32_t bb = x0.l[i] + y1.l[i];
+            o0.l[i] = bb + c2.l[i]; o2.l[i] = bb + FrW::PAD4[i] - c2.l[i];
+            o1.l[i] = x0.l[i] + FrW::PAD2[i] - y1.l[i] + c3.l[i]; o3.l[i] = x0.l[i] + FrW::PAD4[i] - y1.l[i] - c3.l[i];
+        }
+        FrW9 lazy[4] = {normw(o0), normw(o1), normw(o2), normw(o3)}, strict[4] = {s0, s1, s2, s3};
+        for (int q = 0; q < 4; q++) {
+            FrW9 r1 = s_from_w(lazy[q]), r2 = s_from_w(strict[q]);
+            for (int k = 0; k < 9; k++) if (r1.l[k] != r2.l[k]) { bad++; if (bad < 5) printf("lazy butterfly output %d mismatch at %d\n", q, it); break; }
+        }
+    }
     printf("field29: %d mismatches\n", bad);
     // EC: random chain of mixed adds, doubles and full adds against ec.cuh
     G1Affine g; g.x = from_u64<FqParams>(1); g.y = from_u64<FqParams>(2);
