@@ -215,6 +215,21 @@ int32_t plk_setup_write_vk(plk_ctx *ctx, const plk_setup *s, const uint8_t g2_by
 int32_t plk_prove(plk_ctx *ctx, const plk_setup *s, const plk_circuit *c, uint8_t *proof_out, uint64_t cap, uint64_t *len);
 /* per-phase wall-clock of the last plk_prove on this ctx, milliseconds (tracing hook) */
 int32_t plk_prove_timings(const plk_ctx *ctx, double *out_ms, uint32_t cap, uint32_t *count);
+/* the vectors between the rounds of the last plk_prove on this ctx (tracing hook: a proof that differs from the reference's
+ * is localised to a round).  which: 0..3 wire polynomials a, b, c, d (N coefficients), 4 grand product z (N), 5 quotient t
+ * (4N coefficients), 6 linearisation r (N), 7 / 8 the opening quotients behind W_z / W_z_omega (N).  out_host == NULL only
+ * reports the length.                                                                                                    */
+int32_t plk_prove_trace(plk_ctx *ctx, uint32_t which, plk_fr *out_host, uint64_t cap, uint64_t *n);
+
+/* ---- the polynomial helpers of rounds 2, 4 and 5 on their own (bellman_ce::plonk::polynomials / better_cs::prover, reached
+ *      from prove_by_steps src/plonk.rs:152-159): Polynomial::evaluate_at, the division by (x - z) behind the two opening
+ *      proofs ((p(x) - p(z)) / (x - z), n coefficients, the top one zero), and the permutation grand product
+ *      z_0 = 1, z_{i+1} = z_i * prod_j (w_j + beta k_j omega^i + gamma) / (w_j + beta sigma_j + gamma)  (SURVEY.md A.4 round 2;
+ *      k = 1, 5, 7, 10; no per-element inversion: prefix x suffix products and one host inversion).  Device vectors, N = 2^log_n. */
+int32_t plk_poly_evaluate_at_dev(plk_ctx *ctx, const void *coeffs_dev, uint64_t n, const plk_fr *z, plk_fr *out, void *stream);
+int32_t plk_poly_divide_by_linear_dev(plk_ctx *ctx, const void *coeffs_dev, uint64_t n, const plk_fr *z, void *quotient_dev, void *stream);
+int32_t plk_permutation_grand_product_dev(plk_ctx *ctx, const void *const wires_dev[4], const void *const sigmas_dev[4], const plk_fr *beta, const plk_fr *gamma,
+                                          uint32_t log_n, void *z_values_dev, void *stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -96,6 +96,8 @@ struct plk_ctx {
     void *pinned2 = nullptr;                 // pinned staging of the prover's temporaries
     size_t pinned2_cap = 0;
     std::vector<double> timings;
+    // intermediate vectors of the last plk_prove, still resident in prove_ws (plk_prove_trace: test / debugging hook)
+    struct Trace { const plk::Fr *ptr[12] = {nullptr}; uint64_t len[12] = {0}; bool valid = false; } trace;
     bool ev_on = false;                      // record the per-slot event bracket around msm_accumulate
     // multi-GPU commitments of the prover (plk_set_commit_shard): global index of the first resident SRS point and
     // the caller's all-ranks combiner for the Jacobian partial sums

@@ -352,6 +352,7 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     PLK_TRY(fifo_must_be_empty(ctx, "plk_prove"));
     FifoGuard fifo_guard(ctx);
     ctx->timings.clear();
+    ctx->trace.valid = false;
     double t_prev = now_ms();
     auto lap = [&]() { double t = now_ms(); ctx->timings.push_back(t - t_prev); t_prev = t; };
     hipStream_t st = ctx->stream;
@@ -641,10 +642,101 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     put_u64(b, 3); for (int j = 0; j < 3; j++) put_fr(b, sz[j]);
     put_g1(b, Wz); put_g1(b, Wzw);
     *len = b.size();
+    {   // what plk_prove_trace hands out (all of it lives in ctx->prove_ws until the next proof)
+        plk_ctx::Trace &tr_ = ctx->trace;
+        for (int j = 0; j < 4; j++) { tr_.ptr[j] = w_coef[j]; tr_.len[j] = N; }
+        tr_.ptr[4] = z_coef; tr_.len[4] = N;
+        tr_.ptr[5] = t_ext; tr_.len[5] = M;
+        tr_.ptr[6] = r_poly; tr_.len[6] = N;
+        tr_.ptr[7] = t2; tr_.len[7] = N;
+        tr_.ptr[8] = t3; tr_.len[8] = N;
+        tr_.valid = true;
+    }
     if (b.size() > cap) { set_error("plk_prove: proof buffer too small"); return PLK_ERR_ARG; }
     memcpy(proof_out, b.data(), b.size());
     lap();                                                                    // [6] serialise
     return PLK_OK;
+}
+
+// ---- tracing / test hooks: the vectors between the rounds, and the polynomial helpers of rounds 2, 4 and 5 on their own
+int32_t plk_prove_trace(plk_ctx *ctx, uint32_t which, plk_fr *out_host, uint64_t cap, uint64_t *n) {
+    if (!ctx || !n || which >= 9) { set_error("plk_prove_trace: bad argument"); return PLK_ERR_ARG; }
+    if (!ctx->trace.valid) { set_error("plk_prove_trace: no finished plk_prove on this context"); return PLK_ERR_ARG; }
+    *n = ctx->trace.len[which];
+    if (!out_host) return PLK_OK;
+    if (cap < *n) { set_error("plk_prove_trace: buffer too small"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_HIP(hipMemcpyAsync(out_host, ctx->trace.ptr[which], *n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLK_OK;
+}
+
+int32_t plk_poly_evaluate_at_dev(plk_ctx *ctx, const void *coeffs_dev, uint64_t n, const plk_fr *z, plk_fr *out, void *stream) {
+    if (!ctx || !coeffs_dev || !z || !out || n == 0 || n > (1ull << MAX_LOG_N)) { set_error("plk_poly_evaluate_at_dev: bad argument"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    DevBuf tab;
+    int32_t rc = tab.reserve((size_t)2 * POW_TAB * sizeof(Fr) + 64);
+    if (rc != PLK_OK) return rc;
+    Fr zz; memcpy(zz.l, z->l, 32);
+    PowTable pt;
+    rc = fill_pow_table_into(ctx, zz, tab.as<Fr>(), &pt, st);
+    EvalArgs ea{};
+    ea.poly[0] = (const Fr *)coeffs_dev; ea.len[0] = (uint32_t)n; ea.pt[0] = pt; ea.count = 1;
+    Fr *res = tab.as<Fr>() + 2 * POW_TAB;
+    if (rc == PLK_OK) rc = eval_batch(ctx, ea, res, st);
+    if (rc == PLK_OK && hipMemcpyAsync(out, res, sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess) rc = hip_fail(hipGetLastError(), "D2H", __FILE__, __LINE__);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == PLK_OK) rc = hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__);
+    tab.release();
+    return rc;
+}
+
+int32_t plk_poly_divide_by_linear_dev(plk_ctx *ctx, const void *coeffs_dev, uint64_t n, const plk_fr *z, void *quotient_dev, void *stream) {
+    if (!ctx || !coeffs_dev || !z || !quotient_dev || n == 0 || n > (1ull << MAX_LOG_N)) { set_error("plk_poly_divide_by_linear_dev: bad argument"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    HFr hz; memcpy(hz.l, z->l, 32);
+    if (hz.is_zero()) { set_error("plk_poly_divide_by_linear_dev: z = 0"); return PLK_ERR_ARG; }
+    DevBuf tab;
+    int32_t rc = tab.reserve((size_t)4 * POW_TAB * sizeof(Fr) + (size_t)n * sizeof(Fr));
+    if (rc != PLK_OK) return rc;
+    PowTable pz, pzi;
+    Fr *tmp = tab.as<Fr>() + 4 * POW_TAB;
+    rc = fill_pow_table_into(ctx, to_dev(hz), tab.as<Fr>(), &pz, st);
+    if (rc == PLK_OK) rc = fill_pow_table_into(ctx, to_dev(hz.inv()), tab.as<Fr>() + 2 * POW_TAB, &pzi, st);
+    // (p(x) - p(z)) / (x - z): q_k = z^-(k+1) * sum_{j > k} p_j z^j  — the schedule of round 5
+    if (rc == PLK_OK) rc = mul_powers(tmp, (const Fr *)coeffs_dev, pz, 0, (uint32_t)n, st);
+    if (rc == PLK_OK) rc = scan(ctx, tmp, tmp, (uint32_t)n, false, true, false, st);
+    if (rc == PLK_OK) rc = div_finish((Fr *)quotient_dev, tmp, pzi, (uint32_t)n, st);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == PLK_OK) rc = hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__);
+    tab.release();
+    return rc;
+}
+
+int32_t plk_permutation_grand_product_dev(plk_ctx *ctx, const void *const wires_dev[4], const void *const sigmas_dev[4], const plk_fr *beta, const plk_fr *gamma,
+                                          uint32_t log_n, void *z_values_dev, void *stream) {
+    if (!ctx || !wires_dev || !sigmas_dev || !beta || !gamma || !z_values_dev || log_n > MAX_LOG_N) { set_error("plk_permutation_grand_product_dev: bad argument"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const uint64_t N = 1ull << log_n;
+    DevBuf tmp;
+    PLK_TRY(tmp.reserve(2 * N * sizeof(Fr)));
+    HFr hb, hg; memcpy(hb.l, beta->l, 32); memcpy(hg.l, gamma->l, 32);
+    PermArgs pa;
+    pa.num = tmp.as<Fr>(); pa.den = tmp.as<Fr>() + N;
+    for (int j = 0; j < 4; j++) { pa.w[j] = (const Fr *)wires_dev[j]; pa.sigma[j] = (const Fr *)sigmas_dev[j]; pa.beta_k[j] = to_dev(hb * HFr::from_u64(NON_RESIDUES[j])); }
+    pa.beta = to_dev(hb); pa.gamma = to_dev(hg); pa.n = (uint32_t)N; pa.log_n = log_n; pa.tw = ctx->tw_fwd;
+    int32_t rc = perm_terms(pa, st);
+    if (rc == PLK_OK) rc = scan(ctx, pa.num, pa.num, (uint32_t)N, true, false, true, st);
+    if (rc == PLK_OK) rc = scan(ctx, pa.den, pa.den, (uint32_t)N, true, true, false, st);
+    HFr total;
+    if (rc == PLK_OK && hipMemcpyAsync(total.l, pa.den, sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess) rc = hip_fail(hipGetLastError(), "D2H", __FILE__, __LINE__);
+    if (rc == PLK_OK && hipStreamSynchronize(st) != hipSuccess) rc = hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__);
+    if (rc == PLK_OK && total.is_zero()) { set_error("grand product denominator vanished"); rc = PLK_ERR_UNSAT; }
+    if (rc == PLK_OK) rc = mul3((Fr *)z_values_dev, pa.num, pa.den, to_dev(total.inv()), (uint32_t)N, st);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == PLK_OK) rc = hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__);
+    tmp.release();
+    return rc;
 }
 
 // the exported entry points: no C++ exception (std::bad_alloc from a host vector of a 2^26 domain) crosses the boundary
