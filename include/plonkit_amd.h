@@ -62,6 +62,10 @@ uint64_t plk_srs_size(const plk_ctx *ctx);
  * with tau^(start+i)*G, i < n, computed on the GPU; tau = 42 reproduces the reference's local keys. */
 int32_t plk_srs_generate(plk_ctx *ctx, uint64_t n, uint64_t start, uint32_t tau);
 int32_t plk_srs_download(plk_ctx *ctx, uint64_t offset, uint64_t n, plk_g1_affine *out_host);
+/* optional: builds now what the first commitment against the resident key(s) would build — the fixed-base table of the
+ * MSM (15 shifted copies of the points, ~40 ms at 2^20 points).  A host program calls it on a second thread while it is
+ * still parsing the circuit (the `plonkit` binary does); without it the first commitment pays for the table.           */
+int32_t plk_srs_precompute(plk_ctx *ctx);
 
 /* ---- Polynomial::{fft,ifft,coset_fft,icoset_fft} over Fr (bellman_ce::plonk::polynomials; driven
  *      from setup() src/plonk.rs:104 and prove_by_steps src/plonk.rs:152-159).

@@ -631,8 +631,8 @@ def prove(r1cs: R1CS, witness, crs: Crs, S: Setup = None, return_debug=False) ->
     P.opening_at_z_proof = commit(crs, W_z)                                        # 2 x MSM(N)
     P.opening_at_z_omega_proof = commit(crs, W_zw)
     if return_debug:
-        return P, dict(beta=beta, gamma=gamma, alpha=alpha, z=z, v=v, w_coef=w_coef, z_coef=z_coef,
-                       t_coef=t_coef, r=r, setup=S)
+        return P, dict(beta=beta, gamma=gamma, alpha=alpha, z=z, v=v, w_coef=w_coef, z_coef=z_coef, z_vals=z_vals,
+                       t_coef=t_coef, r=r, W_z=W_z, W_zw=W_zw, w_vals=w_vals, setup=S)
     return P
 
 

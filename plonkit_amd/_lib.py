@@ -249,6 +249,31 @@ class Context:
         return out
 
 
+    # ---- tracing hook and the polynomial helpers of rounds 2, 4, 5 (tests localise a wrong proof with them)
+    def prove_trace(self, which):
+        """vector `which` of the last prove on this context: 0..3 wire polynomials, 4 z, 5 t (4N), 6 r, 7 / 8 opening quotients"""
+        n = ctypes.c_uint64(0)
+        _check(lib().plk_prove_trace(self._h, ctypes.c_uint32(which), None, ctypes.c_uint64(0), ctypes.byref(n)))
+        out = np.zeros((n.value, 4), dtype=np.uint64)
+        _check(lib().plk_prove_trace(self._h, ctypes.c_uint32(which), _np(out), ctypes.c_uint64(n.value), ctypes.byref(n)))
+        return out
+
+    def poly_evaluate_at_dev(self, ptr, n, z, stream=None):
+        z = np.ascontiguousarray(z, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        _check(lib().plk_poly_evaluate_at_dev(self._h, _devptr(ptr), ctypes.c_uint64(n), _np(z), _np(out), _stream(stream)))
+        return out
+
+    def poly_divide_by_linear_dev(self, ptr, n, z, out_ptr, stream=None):
+        z = np.ascontiguousarray(z, dtype=np.uint64)
+        _check(lib().plk_poly_divide_by_linear_dev(self._h, _devptr(ptr), ctypes.c_uint64(n), _np(z), _devptr(out_ptr), _stream(stream)))
+
+    def permutation_grand_product_dev(self, wires, sigmas, beta, gamma, log_n, out_ptr, stream=None):
+        w = (ctypes.c_void_p * 4)(*[_devptr(p) for p in wires])
+        s = (ctypes.c_void_p * 4)(*[_devptr(p) for p in sigmas])
+        b, g = np.ascontiguousarray(beta, dtype=np.uint64), np.ascontiguousarray(gamma, dtype=np.uint64)
+        _check(lib().plk_permutation_grand_product_dev(self._h, w, s, _np(b), _np(g), ctypes.c_uint32(log_n), _devptr(out_ptr), _stream(stream)))
+
     def g1_intt_srs_dev(self, log_n, out_ptr, stream=None):
         _check(lib().plk_g1_intt_srs_dev(self._h, ctypes.c_uint32(log_n), _devptr(out_ptr), _stream(stream)))
 

@@ -64,7 +64,7 @@ def build(verbose=False, force=False):
         subprocess.check_call(cmd)
     cli_src = os.path.join(CSRC, "cli_main.cpp")
     if os.path.exists(cli_src) and (force or not os.path.exists(CLI) or os.path.getmtime(CLI) < max(os.path.getmtime(cli_src), os.path.getmtime(SO))):
-        cmd = ["hipcc", "-O2", "-std=c++17", cli_src, "-o", CLI, "-L" + LIBDIR, "-lplonkit_amd", "-Wl,-rpath,$ORIGIN"]
+        cmd = ["hipcc", "-O2", "-std=c++17", "-pthread", cli_src, "-o", CLI, "-L" + LIBDIR, "-lplonkit_amd", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

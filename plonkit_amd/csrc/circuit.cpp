@@ -3,8 +3,10 @@
 #include "../../include/plonkit_amd.h"
 #include <algorithm>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <memory>
+#include <thread>
 #include <unordered_map>
 
 namespace plk {
@@ -40,7 +42,26 @@ struct Rd {
     uint64_t u64() { if (!need(8)) return 0; uint64_t v; memcpy(&v, p + off, 8); off += 8; return v; }
 };
 
+void parallel_for(size_t n, size_t min_per_thread, const std::function<void(size_t, size_t)> &fn, unsigned max_threads) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > max_threads) nt = max_threads;
+    if (min_per_thread && n / min_per_thread < nt) nt = (unsigned)(n / min_per_thread);
+    if (nt <= 1) { if (n) fn(0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const size_t lo = t * per, hi = lo + per < n ? lo + per : n;
+        if (lo >= hi) break;
+        th.emplace_back(fn, lo, hi);
+    }
+    for (auto &x : th) x.join();
+}
+
 // ------------------------------------------------------------------------- .r1cs (binary)
+// src/r1cs_file.rs:100-154.  Two passes over the constraint section: a serial walk that only reads the length words and
+// lays out the offset table, then the terms are converted (range checks + canonical -> Montgomery, the expensive part)
+// by all host threads — 0.16 s single-threaded for the 115 MB of a 2^20-constraint circuit.
 bool parse_r1cs_bin(const uint8_t *data, size_t len, R1cs *out) {
     Rd r(data, len);
     if (len < 12 || memcmp(data, "r1cs", 4) != 0) { set_error("Invalid magic number"); return false; }
@@ -67,28 +88,38 @@ bool parse_r1cs_bin(const uint8_t *data, size_t len, R1cs *out) {
     if (!r.ok) { set_error("InvalidData: truncated header"); return false; }
     if (field_size != 32) { set_error("This parser only supports 32-byte fields"); return false; }
     if (memcmp(prime, BN254_R_LE, 32) != 0) { set_error("This parser only supports bn256"); return false; }
-    r.off = secs[2].first;
     // a constraint takes at least its three length words: the header cannot announce more than the section holds
     if ((uint64_t)n_constraints * 12 > secs[2].second) { set_error("InvalidData: constraint count exceeds the constraint section"); return false; }
     const size_t sec2_end = secs[2].first + secs[2].second;
-    out->constraints.clear();
-    out->constraints.resize(n_constraints);
-    for (uint32_t i = 0; i < n_constraints; i++) {
-        Lc *abc[3] = {&out->constraints[i].a, &out->constraints[i].b, &out->constraints[i].c};
-        for (int k = 0; k < 3; k++) {
-            uint32_t nv = r.u32();
-            if (!r.ok || !r.need((size_t)nv * 36) || r.off + (size_t)nv * 36 > sec2_end) { set_error("InvalidData: truncated constraint"); return false; }
-            abc[k]->resize(nv);
-            for (uint32_t j = 0; j < nv; j++) {
-                (*abc[k])[j].wire = r.u32();
+    out->clear();
+    out->off.resize((size_t)3 * n_constraints + 1);
+    std::vector<size_t> src((size_t)3 * n_constraints);          // file offset of the first term of every linear combination
+    r.off = secs[2].first;
+    uint64_t total = 0;
+    for (size_t k = 0; k < (size_t)3 * n_constraints; k++) {
+        uint32_t nv = r.u32();
+        if (!r.ok || !r.need((size_t)nv * 36) || r.off + (size_t)nv * 36 > sec2_end) { set_error("InvalidData: truncated constraint"); return false; }
+        out->off[k] = total; src[k] = r.off;
+        total += nv; r.off += (size_t)nv * 36;
+    }
+    out->off[(size_t)3 * n_constraints] = total;
+    out->terms.resize(total);
+    std::atomic<int> bad(0);                                       // 1: coefficient not in the field, 2: wire id out of range
+    parallel_for((size_t)3 * n_constraints, 4096, [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi && !bad.load(std::memory_order_relaxed); k++) {
+            const uint8_t *p = data + src[k];
+            LcTerm *dst = out->terms.data() + out->off[k];
+            for (uint64_t j = 0, nv = out->off[k + 1] - out->off[k]; j < nv; j++, p += 36) {
+                memcpy(&dst[j].wire, p, 4);
                 // the reference indexes its variable table with the wire id and panics when it is out of range
                 // (src/circom_circuit.rs:107-113); here ids >= n_wires would alias the transpiler's temporaries
-                if ((*abc[k])[j].wire >= n_wires) { set_error("InvalidData: wire index out of range"); return false; }
-                if (!fr_from_le32(data + r.off, &(*abc[k])[j].coeff)) { set_error("InvalidData: coefficient not in field"); return false; }
-                r.off += 32;
+                if (dst[j].wire >= n_wires) { bad = 2; return; }
+                if (!fr_from_le32(p + 4, &dst[j].coeff)) { bad = 1; return; }
             }
         }
-    }
+    });
+    if (bad == 1) { set_error("InvalidData: coefficient not in field"); return false; }
+    if (bad == 2) { set_error("InvalidData: wire index out of range"); return false; }
     if (secs[3].second != (uint64_t)n_wires * 8) { set_error("Invalid map section size"); return false; }
     r.off = secs[3].first;
     if (n_wires) { uint64_t first = r.u64(); if (!r.ok || first != 0) { set_error("Wire 0 should always be mapped to 0"); return false; } }
@@ -190,13 +221,13 @@ bool parse_r1cs_json(const uint8_t *data, size_t len, R1cs *out) {
     if (n_vars < out->num_inputs) { set_error("unable to read: nVars < number of inputs"); return false; }
     out->num_aux = n_vars - out->num_inputs;
     out->num_variables = n_vars;
-    out->constraints.clear();
-    out->constraints.resize(cons->a.size());
+    out->clear();
+    Lc one_lc;
     for (size_t i = 0; i < cons->a.size(); i++) {
         const JVal &c = cons->a[i];
         if (c.t != JVal::ARR || c.a.size() < 3) { set_error("unable to read: constraint is not [A,B,C]"); return false; }
-        Lc *abc[3] = {&out->constraints[i].a, &out->constraints[i].b, &out->constraints[i].c};
         for (int k = 0; k < 3; k++) {
+            one_lc.clear();
             if (c.a[k].t != JVal::OBJ) { set_error("unable to read: linear combination is not an object"); return false; }
             std::vector<std::pair<std::string, std::string>> terms;
             for (auto &kv : c.a[k].o) terms.emplace_back(kv.first, kv.second.s);
@@ -206,8 +237,9 @@ bool parse_r1cs_json(const uint8_t *data, size_t len, R1cs *out) {
                 JVal kv; kv.t = JVal::STR; kv.s = t.first;
                 if (!json_u64(&kv, &w) || !fr_from_decimal(t.second, &cf)) { set_error("unable to read: bad term in linear combination"); return false; }
                 if (w >= n_vars) { set_error("unable to read: wire index out of range"); return false; }      // checked before the 32-bit cast
-                abc[k]->push_back({(uint32_t)w, cf});
+                one_lc.push_back({(uint32_t)w, cf});
             }
+            out->push_lc(one_lc.data(), one_lc.size());
         }
     }
     return true;
@@ -232,10 +264,12 @@ bool parse_wtns_bin(const uint8_t *data, size_t len, std::vector<HFr> *out) {
     if (!r.ok || sz != (uint64_t)wl * 32) { set_error("invalid witness section size"); return false; }
     if (!r.need(sz)) { set_error("read witness failed: truncated"); return false; }
     out->resize(wl);
-    for (uint32_t i = 0; i < wl; i++) {
-        if (!fr_from_le32(data + r.off, &(*out)[i])) { set_error("read witness failed: not in field"); return false; }
-        r.off += 32;
-    }
+    std::atomic<int> bad(0);
+    const uint8_t *src = data + r.off;
+    parallel_for(wl, 16384, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) if (!fr_from_le32(src + 32 * i, &(*out)[i])) { bad = 1; return; }
+    });
+    if (bad) { set_error("read witness failed: not in field"); return false; }
     return true;
 }
 
@@ -253,31 +287,51 @@ namespace {
 
 struct Term { uint32_t var; HFr coeff; };
 
+// One Builder transpiles a contiguous range of constraints into its own piece: gates, temporaries (numbered from
+// r.num_variables upwards inside the piece) and their defining linear forms.  transpile() runs one Builder per chunk on
+// the host threads and stitches the pieces in constraint order, shifting every temporary id by the number of temporaries
+// of the pieces before it — the result is what a single serial pass produces (gate order, ids, statistics).
+struct Piece {
+    std::vector<Gate> gates;
+    std::vector<HFr> tmp_values;            // per temporary; only when a witness is given
+    std::vector<WitnessOp> ops;
+    std::vector<WitnessTerm> op_terms;
+    std::vector<ConstraintStat> stats;
+    uint64_t num_hints = 0;
+    bool failed = false;
+};
+
 struct Builder {
-    Transpiled *t;
-    bool have_values;
+    Piece *t;
+    const std::vector<HFr> *witness;        // circom wires (index 0 = ONE in the file, the dummy variable here), or null
+    uint64_t first_tmp;                     // r.num_variables
     const HFr zero = HFr::zero(), one = HFr::one(), minus_one = -HFr::one();
+    bool have_values() const { return witness != nullptr; }
 
     // a temporary is always a linear form over earlier variables: record it, so that a later proof
     // can recompute the temporaries from a fresh witness without re-running the transpiler
     uint32_t alloc(const HFr &v, const Term *terms, size_t n_terms, const HFr &constant) {
-        uint32_t id = (uint32_t)t->num_vars++;
-        if (have_values) t->values.push_back(v);
+        uint32_t id = (uint32_t)(first_tmp + t->ops.size());
+        if (have_values()) t->tmp_values.push_back(v);
         WitnessOp op; op.first = (uint32_t)t->op_terms.size(); op.count = (uint32_t)n_terms; op.constant = constant;
         for (size_t i = 0; i < n_terms; i++) t->op_terms.push_back({terms[i].var, terms[i].coeff});
         t->ops.push_back(op);
         return id;
     }
-    HFr val(uint32_t v) const { return have_values ? t->values[v] : HFr::zero(); }
+    HFr val(uint32_t v) const {
+        if (!have_values() || v == 0) return HFr::zero();              // id 0 is the dummy variable, not circom's ONE
+        return v < first_tmp ? (*witness)[v] : t->tmp_values[v - first_tmp];
+    }
     void gate(const uint32_t v[4], const HFr q[7]) {
         Gate g; memcpy(g.v, v, sizeof g.v); for (int i = 0; i < 7; i++) g.q[i] = q[i];
         t->gates.push_back(g);
     }
 
     // stable de-duplication; wire 0 (the constant ONE) is folded into the constant term
-    static void split(const Lc &lc, HFr *constant, std::vector<Term> *terms) {
+    static void split(const LcTerm *lc, size_t n, HFr *constant, std::vector<Term> *terms) {
         *constant = HFr::zero(); terms->clear();
-        for (const LcTerm &x : lc) {
+        for (size_t i = 0; i < n; i++) {
+            const LcTerm &x = lc[i];
             if (x.wire == 0) { *constant = *constant + x.coeff; continue; }
             bool found = false;
             for (Term &y : *terms) if (y.var == x.wire) { y.coeff = y.coeff + x.coeff; found = true; break; }
@@ -288,7 +342,7 @@ struct Builder {
 
     HFr eval(const std::vector<Term> &lc, const HFr &free) const {
         HFr s = free;
-        if (have_values) for (const Term &x : lc) s = s + x.coeff * val(x.var);
+        if (have_values()) for (const Term &x : lc) s = s + x.coeff * val(x.var);
         return s;
     }
 
@@ -308,14 +362,14 @@ struct Builder {
             uint32_t v[4]; HFr q[7];
             for (int i = 0; i < 7; i++) q[i] = zero;
             HFr s = free;
-            for (int i = 0; i < 4; i++, pos++) { v[i] = lc[pos].var; q[i] = lc[pos].coeff; if (have_values) s = s + q[i] * val(v[i]); }
+            for (int i = 0; i < 4; i++, pos++) { v[i] = lc[pos].var; q[i] = lc[pos].coeff; if (have_values()) s = s + q[i] * val(v[i]); }
             q[5] = free; q[6] = minus_one;
             uint32_t nxt = alloc(s, lc.data(), 4, free);
             gate(v, q);
             while (lc.size() - pos > 3) {
                 for (int i = 0; i < 7; i++) q[i] = zero;
                 s = val(nxt);
-                for (int i = 0; i < 3; i++, pos++) { v[i] = lc[pos].var; q[i] = lc[pos].coeff; if (have_values) s = s + q[i] * val(v[i]); }
+                for (int i = 0; i < 3; i++, pos++) { v[i] = lc[pos].var; q[i] = lc[pos].coeff; if (have_values()) s = s + q[i] * val(v[i]); }
                 v[3] = nxt; q[3] = one; q[6] = minus_one;
                 Term chain[4] = {lc[pos - 3], lc[pos - 2], lc[pos - 1], {nxt, one}};
                 uint32_t nn = alloc(s, chain, 4, zero);
@@ -330,6 +384,56 @@ struct Builder {
         }
         *var_out = fin; *coeff_out = one;
     }
+
+    // CircomCircuit::synthesize (src/circom_circuit.rs:114-131) for the constraints [lo, hi) fed to the gate adaptor
+    void run(const R1cs &r, size_t lo, size_t hi, bool collect_stats) {
+        std::vector<Term> al, bl, cl;
+        HFr ac, bc, cc;
+        t->gates.reserve((hi - lo) * 2);
+        for (size_t idx = lo; idx < hi; idx++) {
+            const LcView ka = r.lc(idx, 0), kb = r.lc(idx, 1), kc = r.lc(idx, 2);
+            if ((ka.empty() || kb.empty()) && kc.empty()) continue;              // src/circom_circuit.rs:121-122
+            size_t g0 = t->gates.size();
+            split(ka.p, ka.n, &ac, &al); split(kb.p, kb.n, &bc, &bl); split(kc.p, kc.n, &cc, &cl);
+            bool a_k = al.empty(), b_k = bl.empty(), c_k = cl.empty();
+            uint32_t dv; HFr dc;
+            if (a_k && b_k) {
+                HFr free = cc - ac * bc;
+                if (c_k) { if (!free.is_zero()) { t->failed = true; return; } }
+                else lc_as_gates(cl, free, false, &dv, &dc);
+            } else if (a_k || b_k) {                                              // UNPINNED: constant * LC = LC
+                const HFr &kk = a_k ? ac : bc; const std::vector<Term> &lin = a_k ? bl : al; const HFr &lin_c = a_k ? bc : ac;
+                Lc merged;
+                for (const Term &x : lin) merged.push_back({x.var, x.coeff * kk});
+                for (const Term &x : cl) merged.push_back({x.var, -x.coeff});
+                HFr free = kk * lin_c - cc, dummy;
+                std::vector<Term> m2;
+                split(merged.data(), merged.size(), &dummy, &m2);
+                if (!m2.empty()) lc_as_gates(m2, free, false, &dv, &dc);
+                else if (!free.is_zero()) { t->failed = true; return; }
+            } else {
+                bool same = al.size() == 1 && bl.size() == 1 && al[0].var == bl[0].var && (c_k || (cl.size() == 1 && cl[0].var == al[0].var));
+                if (same) {                                                       // UNPINNED: quadratic gate
+                    HFr a1 = al[0].coeff, b1 = bl[0].coeff, c1 = c_k ? HFr::zero() : cl[0].coeff;
+                    uint32_t v[4] = {al[0].var, al[0].var, 0, 0}; HFr q[7];
+                    for (int i = 0; i < 7; i++) q[i] = HFr::zero();
+                    q[0] = ac * b1 + a1 * bc - c1; q[4] = a1 * b1; q[5] = ac * bc - cc;
+                    gate(v, q);
+                } else {
+                    uint32_t av, bv, cv; HFr acoef, bcoef, ccoef;
+                    lc_as_gates(al, ac, true, &av, &acoef);
+                    lc_as_gates(bl, bc, true, &bv, &bcoef);
+                    HFr q[7];
+                    for (int i = 0; i < 7; i++) q[i] = HFr::zero();
+                    q[4] = acoef * bcoef;
+                    if (c_k) { uint32_t v[4] = {av, bv, 0, 0}; q[5] = -cc; gate(v, q); }
+                    else { lc_as_gates(cl, cc, true, &cv, &ccoef); uint32_t v[4] = {av, bv, cv, 0}; q[2] = -ccoef; gate(v, q); }
+                }
+            }
+            if (collect_stats) t->stats.push_back({std::to_string(idx), (uint64_t)(t->gates.size() - g0)});
+            t->num_hints++;
+        }
+    }
 };
 
 }  // namespace
@@ -338,64 +442,63 @@ bool transpile(const R1cs &r, const std::vector<HFr> *witness, Transpiled *out) 
     out->gates.clear(); out->values.clear(); out->stats.clear(); out->num_hints = 0;
     out->ops.clear(); out->op_terms.clear();
     out->num_vars = r.num_variables;
-    Builder B{out, witness != nullptr};
+    if (witness && witness->size() < r.num_variables) { set_error("witness shorter than the number of variables"); return false; }
+    const size_t nc = r.num_constraints();
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 32) nt = 32;
+    size_t chunks = nc / 8192;                                   // pieces of >= 8192 constraints, a few per thread
+    if (chunks > 4 * (size_t)nt) chunks = 4 * (size_t)nt;
+    if (chunks < 1) chunks = 1;
+    std::vector<Piece> pieces(chunks);
+    const size_t per = (nc + chunks - 1) / chunks;
+    const bool stats = out->collect_stats;
+    parallel_for(chunks, 1, [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; k++) {
+            Builder B{&pieces[k], witness, r.num_variables};
+            B.run(r, k * per, std::min(nc, (k + 1) * per), stats);
+        }
+    }, nt);
+    for (const Piece &p : pieces) if (p.failed) { set_error("unsatisfiable constant constraint"); return false; }
+    // stitch: prefix sums of gates / temporaries / terms, then every piece copies itself into place with its ids shifted
+    std::vector<size_t> g0(chunks + 1, 0), t0(chunks + 1, 0), o0(chunks + 1, 0), s0(chunks + 1, 0);
+    for (size_t k = 0; k < chunks; k++) {
+        g0[k + 1] = g0[k] + pieces[k].gates.size(); t0[k + 1] = t0[k] + pieces[k].ops.size();
+        o0[k + 1] = o0[k] + pieces[k].op_terms.size(); s0[k + 1] = s0[k] + pieces[k].stats.size();
+        out->num_hints += pieces[k].num_hints;
+    }
+    if (r.num_variables + t0[chunks] >= (1ull << 32) || o0[chunks] >= (1ull << 32)) { set_error("circuit too large: variable ids do not fit 32 bits"); return false; }
+    out->gates.resize(g0[chunks]); out->ops.resize(t0[chunks]); out->op_terms.resize(o0[chunks]);
+    if (stats) out->stats.resize(s0[chunks]);
+    out->num_vars = r.num_variables + t0[chunks];
     if (witness) {
-        if (witness->size() < r.num_variables) { set_error("witness shorter than the number of variables"); return false; }
-        out->values.assign(witness->begin(), witness->begin() + r.num_variables);
+        out->values.resize(out->num_vars);
+        std::copy(witness->begin(), witness->begin() + r.num_variables, out->values.begin());
         out->values[0] = HFr::zero();                        // id 0 is the dummy variable, not circom's ONE
     }
-    std::vector<Term> al, bl, cl;
-    HFr ac, bc, cc;
-    out->gates.reserve(r.constraints.size() * 2);
-    for (size_t idx = 0; idx < r.constraints.size(); idx++) {
-        const Constraint &k = r.constraints[idx];
-        if ((k.a.empty() || k.b.empty()) && k.c.empty()) continue;          // src/circom_circuit.rs:121-122
-        size_t g0 = out->gates.size();
-        Builder::split(k.a, &ac, &al); Builder::split(k.b, &bc, &bl); Builder::split(k.c, &cc, &cl);
-        bool a_k = al.empty(), b_k = bl.empty(), c_k = cl.empty();
-        uint32_t dv; HFr dc;
-        if (a_k && b_k) {
-            HFr free = cc - ac * bc;
-            if (c_k) { if (!free.is_zero()) { set_error("unsatisfiable constant constraint"); return false; } }
-            else B.lc_as_gates(cl, free, false, &dv, &dc);
-        } else if (a_k || b_k) {                                              // UNPINNED: constant * LC = LC
-            const HFr &kk = a_k ? ac : bc; const std::vector<Term> &lin = a_k ? bl : al; const HFr &lin_c = a_k ? bc : ac;
-            Lc merged;
-            for (const Term &x : lin) merged.push_back({x.var, x.coeff * kk});
-            for (const Term &x : cl) merged.push_back({x.var, -x.coeff});
-            HFr free = kk * lin_c - cc, dummy;
-            std::vector<Term> m2;
-            Builder::split(merged, &dummy, &m2);
-            if (!m2.empty()) B.lc_as_gates(m2, free, false, &dv, &dc);
-            else if (!free.is_zero()) { set_error("unsatisfiable constant constraint"); return false; }
-        } else {
-            bool same = al.size() == 1 && bl.size() == 1 && al[0].var == bl[0].var && (c_k || (cl.size() == 1 && cl[0].var == al[0].var));
-            if (same) {                                                       // UNPINNED: quadratic gate
-                HFr a1 = al[0].coeff, b1 = bl[0].coeff, c1 = c_k ? HFr::zero() : cl[0].coeff;
-                uint32_t v[4] = {al[0].var, al[0].var, 0, 0}; HFr q[7];
-                for (int i = 0; i < 7; i++) q[i] = HFr::zero();
-                q[0] = ac * b1 + a1 * bc - c1; q[4] = a1 * b1; q[5] = ac * bc - cc;
-                B.gate(v, q);
-            } else {
-                uint32_t av, bv, cv; HFr acoef, bcoef, ccoef;
-                B.lc_as_gates(al, ac, true, &av, &acoef);
-                B.lc_as_gates(bl, bc, true, &bv, &bcoef);
-                HFr q[7];
-                for (int i = 0; i < 7; i++) q[i] = HFr::zero();
-                q[4] = acoef * bcoef;
-                if (c_k) { uint32_t v[4] = {av, bv, 0, 0}; q[5] = -cc; B.gate(v, q); }
-                else { B.lc_as_gates(cl, cc, true, &cv, &ccoef); uint32_t v[4] = {av, bv, cv, 0}; q[2] = -ccoef; B.gate(v, q); }
+    const uint32_t nv = (uint32_t)r.num_variables;
+    parallel_for(chunks, 1, [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; k++) {
+            Piece &p = pieces[k];
+            const uint32_t shift = (uint32_t)t0[k];
+            Gate *gd = out->gates.data() + g0[k];
+            for (size_t i = 0; i < p.gates.size(); i++) {
+                gd[i] = p.gates[i];
+                for (int j = 0; j < 4; j++) if (gd[i].v[j] >= nv) gd[i].v[j] += shift;
             }
+            for (size_t i = 0; i < p.ops.size(); i++) { WitnessOp op = p.ops[i]; op.first += (uint32_t)o0[k]; out->ops[t0[k] + i] = op; }
+            for (size_t i = 0; i < p.op_terms.size(); i++) { WitnessTerm wt = p.op_terms[i]; if (wt.var >= nv) wt.var += shift; out->op_terms[o0[k] + i] = wt; }
+            if (stats) for (size_t i = 0; i < p.stats.size(); i++) out->stats[s0[k] + i] = std::move(p.stats[i]);
+            if (witness) std::copy(p.tmp_values.begin(), p.tmp_values.end(), out->values.begin() + r.num_variables + t0[k]);
+            std::vector<Gate>().swap(p.gates);                 // give the memory back as soon as the piece is placed
         }
-        if (out->collect_stats) out->stats.push_back({std::to_string(idx), (uint64_t)(out->gates.size() - g0)});
-        out->num_hints++;
-    }
+    }, nt);
     return true;
 }
 
 std::string analyse_json(const R1cs &r, const Transpiled &t) {
     std::string s = "{\"num_inputs\":" + std::to_string(r.num_inputs) + ",\"num_aux\":" + std::to_string(r.num_aux) +
-                    ",\"num_variables\":" + std::to_string(r.num_variables) + ",\"num_constraints\":" + std::to_string(r.constraints.size()) +
+                    ",\"num_variables\":" + std::to_string(r.num_variables) + ",\"num_constraints\":" + std::to_string(r.num_constraints()) +
                     ",\"num_nontrivial_constraints\":" + std::to_string(t.stats.size()) + ",\"num_gates\":" + std::to_string(t.gates.size()) +
                     ",\"num_hints\":" + std::to_string(t.num_hints);
     if (!t.stats.empty()) {
@@ -499,8 +602,9 @@ static int32_t circuit_synthetic_impl(uint64_t target_gates, uint64_t seed, plk_
     std::vector<HFr> &w = c->witness;
     w.reserve(target_gates + 8);
     w.push_back(HFr::one()); w.push_back(HFr::zero()); w.push_back(rng.fr()); w.push_back(rng.fr());
-    std::vector<Constraint> &cons = c->r1cs.constraints;
-    cons.reserve(target_gates);
+    R1cs &R = c->r1cs;
+    R.clear();
+    R.terms.reserve(target_gates * 4); R.off.reserve(target_gates * 3 + 4);
     // Pass 1 draws every coefficient in the generator's order (the draws do not depend on the witness), pass 2 walks
     // the chain.  The divisions w = (...) / c are by those coefficients, so all of them are inverted together with
     // Montgomery's trick — one field inversion instead of one per constraint (4 s at 2^20 gates).
@@ -528,21 +632,23 @@ static int32_t circuit_synthetic_impl(uint64_t target_gates, uint64_t seed, plk_
         const Draw &d = draws[i];
         uint32_t u = (uint32_t)w.size() - 1, v = (uint32_t)w.size() - 2;
         HFr prod = d.ca * w[u] * d.cb * w[v];
-        Constraint k;
-        k.a.push_back({u, d.ca}); k.b.push_back({v, d.cb});
+        const LcTerm ka{u, d.ca}, kb{v, d.cb};
+        R.push_lc(&ka, 1); R.push_lc(&kb, 1);
         if (!d.two) {
             w.push_back(prod * inv_c[i]);
-            k.c.push_back({(uint32_t)w.size() - 1, d.cdiv});
+            const LcTerm kc{(uint32_t)w.size() - 1, d.cdiv};
+            R.push_lc(&kc, 1);
         } else {
             w.push_back((prod - d.kk - d.c1 * w[v]) * inv_c[i]);
-            k.c.push_back({0, d.kk}); k.c.push_back({v, d.c1}); k.c.push_back({(uint32_t)w.size() - 1, d.cdiv});
+            const LcTerm kc[3] = {{0, d.kk}, {v, d.c1}, {(uint32_t)w.size() - 1, d.cdiv}};
+            R.push_lc(kc, 3);
         }
-        cons.push_back(std::move(k));
     }
     w[1] = w.back();
-    Constraint tie;
-    tie.a.push_back({1, HFr::one()}); tie.b.push_back({0, HFr::one()}); tie.c.push_back({(uint32_t)w.size() - 1, HFr::one()});
-    cons.push_back(std::move(tie));
+    {
+        const LcTerm ta{1, HFr::one()}, tb{0, HFr::one()}, tc{(uint32_t)w.size() - 1, HFr::one()};
+        R.push_lc(&ta, 1); R.push_lc(&tb, 1); R.push_lc(&tc, 1);
+    }
     c->r1cs.num_inputs = 2;
     c->r1cs.num_variables = w.size();
     c->r1cs.num_aux = w.size() - 2;
@@ -567,12 +673,12 @@ static int32_t circuit_export_impl(const plk_circuit *c, int32_t what, uint8_t *
         b.insert(b.end(), {'r', '1', 'c', 's'}); u32(1); u32(3);
         u32(1); u64(64); u32(32); b.insert(b.end(), BN254_R_LE, BN254_R_LE + 32);
         u32((uint32_t)c->r1cs.num_variables); u32(0); u32((uint32_t)c->r1cs.num_inputs - 1); u32((uint32_t)c->r1cs.num_aux);
-        u64(c->r1cs.num_variables); u32((uint32_t)c->r1cs.constraints.size());
-        uint64_t sz = 0;
-        for (const Constraint &k : c->r1cs.constraints) sz += 12 + 36 * (k.a.size() + k.b.size() + k.c.size());
-        u32(2); u64(sz);
-        for (const Constraint &k : c->r1cs.constraints)
-            for (const Lc *lc : {&k.a, &k.b, &k.c}) { u32((uint32_t)lc->size()); for (const LcTerm &t : *lc) { u32(t.wire); fr(t.coeff); } }
+        const R1cs &R = c->r1cs;
+        u64(R.num_variables); u32((uint32_t)R.num_constraints());
+        u32(2); u64(12 * (uint64_t)R.num_constraints() + 36 * (uint64_t)R.terms.size());
+        b.reserve(b.size() + 12 * R.num_constraints() + 36 * R.terms.size() + 8 * R.num_variables + 64);
+        for (size_t i = 0; i < R.num_constraints(); i++)
+            for (int which = 0; which < 3; which++) { const LcView lc = R.lc(i, which); u32((uint32_t)lc.size()); for (const LcTerm &t : lc) { u32(t.wire); fr(t.coeff); } }
         u32(3); u64(8 * c->r1cs.num_variables);
         for (uint64_t i = 0; i < c->r1cs.num_variables; i++) u64(i);
     } else {                                                            // .wtns

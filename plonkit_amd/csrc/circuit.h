@@ -16,6 +16,7 @@
 
 #include <new>
 #include <exception>
+#include <functional>
 
 namespace plk {
 
@@ -33,12 +34,29 @@ using host::HFr;
 
 struct LcTerm { uint32_t wire; HFr coeff; };
 typedef std::vector<LcTerm> Lc;
-struct Constraint { Lc a, b, c; };
+struct LcView {                             // one linear combination inside R1cs::terms
+    const LcTerm *p; size_t n;
+    const LcTerm *begin() const { return p; }
+    const LcTerm *end() const { return p + n; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    const LcTerm &operator[](size_t i) const { return p[i]; }
+};
 
+// R1CS of src/circom_circuit.rs:33-39, stored flat: all linear combinations back to back (A_0, B_0, C_0, A_1, ..) with one
+// offset table — a 2^20-constraint circuit is three allocations, not three million, and the loaders fill it from many threads
 struct R1cs {
     uint64_t num_inputs = 0, num_aux = 0, num_variables = 0;
-    std::vector<Constraint> constraints;
+    std::vector<LcTerm> terms;
+    std::vector<uint64_t> off{0};           // 3 * num_constraints + 1 offsets into terms
+    size_t num_constraints() const { return (off.size() - 1) / 3; }
+    LcView lc(size_t constraint, int which) const { const uint64_t b = off[3 * constraint + which]; return {terms.data() + b, (size_t)(off[3 * constraint + which + 1] - b)}; }
+    void clear() { terms.clear(); off.assign(1, 0); }
+    void push_lc(const LcTerm *t, size_t n) { terms.insert(terms.end(), t, t + n); off.push_back(terms.size()); }
 };
+
+// runs fn(lo, hi) over [0, n) on up to `max_threads` host threads (serially when the range is small)
+void parallel_for(size_t n, size_t min_per_thread, const std::function<void(size_t, size_t)> &fn, unsigned max_threads = 32);
 
 // variable ids: 0 = dummy (value 0); w in [1, num_variables) = circom wire w (Input(w) for
 // w < num_inputs, Aux(w - num_inputs + AUX_OFFSET) otherwise, src/circom_circuit.rs:107-113);

@@ -17,6 +17,7 @@
 #include <chrono>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -283,23 +284,40 @@ static int run(int argc, char **argv) {
         phase("start");
         const Ranks rk = ranks_from_env();
         std::string wf = a.get("witness", "witness.wtns");
-        plk_circuit *c = load_circuit(resolve_circuit(a), &wf);
-        phase("load circuit + witness");
-        plk_ctx *ctx = open_ctx(rk);
-        phase("plk_create (HIP init)");
+        const bool single = rk.world == 1 && rk.comm.empty();
         uint8_t g2[256];
+        plk_ctx *ctx = nullptr;
         plk_setup *s = nullptr;
-        if (rk.world > 1 || !rk.comm.empty()) {                      // the slice of the key depends on the domain size
-            CK("prepare err", plk_setup_prepare(ctx, c, &s));
-            phase("setup_prepare");
-            join_ranks(ctx, rk, plk_setup_domain_size(s));
-        }
-        const uint64_t N = s ? plk_setup_domain_size(s) : 0;
-        load_key(ctx, a.get("srs_monomial_form"), g2, false, rk, N);
-        phase("load key (parse + upload)");
+        plk_circuit *c = nullptr;
         // a Lagrange-form key (-l) changes how the witness commitments are computed (commit_using_values), never the
         // proof bytes (src/plonk.rs:138-146); an empty or missing option means "monomial only" as in the reference
-        if (!a.get("srs_lagrange_form", "").empty()) { uint8_t g2l[256]; load_key(ctx, a.get("srs_lagrange_form"), g2l, true, rk, N); }
+        const std::string lag = a.get("srs_lagrange_form", "");
+        if (single) {
+            // the GPU side of the start-up (HIP initialisation, key parse + upload, fixed-base table of the MSM) runs on a
+            // second thread while this one parses the circuit and the witness: neither needs the other until the setup
+            std::thread gpu([&] {
+                ctx = open_ctx(rk);
+                load_key(ctx, a.get("srs_monomial_form"), g2);
+                if (!lag.empty()) { uint8_t g2l[256]; load_key(ctx, lag, g2l, true); }
+                CK("srs precompute", plk_srs_precompute(ctx));
+            });
+            c = load_circuit(resolve_circuit(a), &wf);
+            phase("load circuit + witness");
+            gpu.join();
+            phase("HIP init + key + table (other thread)");
+        } else {
+            c = load_circuit(resolve_circuit(a), &wf);
+            phase("load circuit + witness");
+            ctx = open_ctx(rk);
+            phase("plk_create (HIP init)");
+            CK("prepare err", plk_setup_prepare(ctx, c, &s));             // the slice of the key depends on the domain size
+            phase("setup_prepare");
+            join_ranks(ctx, rk, plk_setup_domain_size(s));
+            const uint64_t N = plk_setup_domain_size(s);
+            load_key(ctx, a.get("srs_monomial_form"), g2, false, rk, N);
+            if (!lag.empty()) { uint8_t g2l[256]; load_key(ctx, lag, g2l, true, rk, N); }
+            phase("load key (parse + upload)");
+        }
         if (!s) {
             CK("prepare err", plk_setup_prepare(ctx, c, &s));
             phase("setup_prepare");

@@ -919,6 +919,18 @@ int32_t plk_msm_g1(plk_ctx *ctx, const plk_fr *scalars, uint64_t n, uint64_t bas
     return plk_msm_g1_dev(ctx, ctx->stage.p, n, base_offset, out, nullptr);
 }
 
+int32_t plk_srs_precompute(plk_ctx *ctx) {
+    if (!ctx) { set_error("plk_srs_precompute: null ctx"); return PLK_ERR_ARG; }
+    if (!ctx->srs) { set_error("plk_srs_precompute: no SRS resident"); return PLK_ERR_SRS; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(ensure_base_table(ctx, table_copies_for(ctx->srs_n), ctx->stream));
+    if (ctx->lag.pts) {
+        SrsSlotSwap active(ctx, true);
+        PLK_TRY(ensure_base_table(ctx, table_copies_for(ctx->srs_n), ctx->stream));
+    }
+    return PLK_OK;
+}
+
 int32_t plk_set_kernel_timing(plk_ctx *ctx, int32_t on) {
     if (!ctx) { set_error("null ctx"); return PLK_ERR_ARG; }
     PLK_HIP(hipSetDevice(ctx->device));

@@ -60,6 +60,8 @@ struct EvalArgs {
 int32_t gather(Fr *out, const Fr *values, const uint32_t *vars, uint32_t n, hipStream_t s);
 int32_t sigma_from_index(Fr *out, const uint32_t *packed, uint32_t n, uint32_t log_n, const PowTable &tw, const Fr k[4], hipStream_t s);
 int32_t check_gates(const CheckArgs &a, hipStream_t s);
+// perm.hip: 4 x n packed successors (idx[col * n + row] = col' << 30 | row') of the copy-constraint permutation
+int32_t build_permutation_index(plk_ctx *ctx, const uint32_t *const vars[4], uint32_t n, uint64_t num_vars, uint32_t *idx, hipStream_t st);
 // the transpiler's temporaries on the device: values[first_tmp + i] = constant_i + sum_k coeff * values[var]  for the
 // linear forms recorded at setup (circuit.h: WitnessOp / WitnessTerm, uploaded as they are — 40-byte records)
 int32_t eval_witness_ops(Fr *values, const void *ops_dev, const void *terms_dev, uint32_t n_ops, uint32_t first_tmp, hipStream_t s);

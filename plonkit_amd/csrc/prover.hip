@@ -226,6 +226,7 @@ static int32_t setup_prepare_impl(plk_ctx *ctx, const plk_circuit *c, plk_setup 
             return hip_fail(hipGetLastError(), "H2D witness ops", __FILE__, __LINE__);
         }
     }
+    mark("temporaries (record + upload)");
     // rows of the trace: one gate per public input first (q_a = -1), then the transpiler's gates — viewed in place
     std::vector<Gate> input_rows;
     for (uint64_t i = 1; i <= S->num_inputs; i++) {
@@ -236,7 +237,6 @@ static int32_t setup_prepare_impl(plk_ctx *ctx, const plk_circuit *c, plk_setup 
     }
     const size_t n_in = input_rows.size(), n_rows = n_in + T.gates.size();
     auto row = [&](uint64_t r) -> const Gate & { return r < n_in ? input_rows[r] : T.gates[r - n_in]; };
-    mark("rows");
     Arena A{&S->store};
     size_t total = 22 * ((N * sizeof(Fr) + 255) & ~(size_t)255) + 4 * ((N * 4 + 255) & ~(size_t)255);
     int32_t rc = S->store.reserve(total);
@@ -249,56 +249,54 @@ static int32_t setup_prepare_impl(plk_ctx *ctx, const plk_circuit *c, plk_setup 
 
     hipStream_t st = ctx->stream;
     auto fail = [&](int32_t code) { plk_setup_free(S); return code; };
-    // selectors: values on rows 0..n_real-1, zero elsewhere -> iNTT(N)
+    // ONE pass over the gate records on all host threads fills the seven selector columns and the four variable-index
+    // columns (rows 0 .. n_real - 1, zero / dummy beyond); they are uploaded back to back and interpolated as they land
     {
-        std::vector<HFr> col(N);
+        std::vector<HFr> cols((size_t)7 * N);
+        std::vector<uint32_t> vars((size_t)4 * N);
+        parallel_for(N, 1 << 15, [&](size_t lo, size_t hi) {
+            for (size_t r = lo; r < hi; r++) {
+                if (r < n_rows) {
+                    const Gate &g = row(r);
+                    for (int k = 0; k < 7; k++) cols[(size_t)k * N + r] = g.q[k];
+                    for (int j = 0; j < 4; j++) vars[(size_t)j * N + r] = g.v[j];
+                } else {
+                    for (int k = 0; k < 7; k++) cols[(size_t)k * N + r] = HFr::zero();
+                    for (int j = 0; j < 4; j++) vars[(size_t)j * N + r] = 0;
+                }
+            }
+        });
+        mark("columns (host fill)");
+        for (int j = 0; j < 4; j++)
+            if (hipMemcpyAsync(S->gate_vars[j], vars.data() + (size_t)j * N, N * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D vars", __FILE__, __LINE__));
         for (int k = 0; k < 7; k++) {
-            for (uint64_t r = 0; r < N; r++) col[r] = r < n_rows ? row(r).q[k] : HFr::zero();
-            if (hipMemcpyAsync(S->sel_vals[k], col.data(), N * sizeof(Fr), hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D selector", __FILE__, __LINE__));
+            if (hipMemcpyAsync(S->sel_vals[k], cols.data() + (size_t)k * N, N * sizeof(Fr), hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D selector", __FILE__, __LINE__));
             if (hipMemcpyAsync(S->sel_coef[k], S->sel_vals[k], N * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "D2D selector", __FILE__, __LINE__));
-            if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
             if ((rc = ntt_dev(ctx, S->sel_coef[k], log_n, true, nullptr, st)) != PLK_OK) return fail(rc);
         }
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));   // the host columns go away here
     }
-    mark("selectors (7 iNTT)");
-    // wire -> variable index table and the permutation (rotate-left over each variable's occurrences)
+    mark("selectors (upload + 7 iNTT)");
+    // the permutation (rotate-left over each variable's occurrences) from the variable-index table, on the device (perm.hip)
     {
-        std::vector<uint32_t> vars(N);
-        for (int j = 0; j < 4; j++) {
-            for (uint64_t r = 0; r < N; r++) vars[r] = r < n_rows ? row(r).v[j] : 0;
-            if (hipMemcpyAsync(S->gate_vars[j], vars.data(), N * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D vars", __FILE__, __LINE__));
-            if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
-        }
-        std::vector<uint32_t> cnt(T.num_vars + 1, 0);
-        for (uint64_t r = 0; r < n_rows; r++) { const Gate &g = row(r); for (int j = 0; j < 4; j++) if (g.v[j]) cnt[g.v[j] + 1]++; }
-        for (size_t v = 1; v < cnt.size(); v++) cnt[v] += cnt[v - 1];              // cnt[v] = start of v's list
-        std::vector<uint32_t> pos(cnt.back()), fill(cnt.begin(), cnt.end() - 1);
-        for (uint64_t r = 0; r < n_rows; r++)
-            for (int j = 0; j < 4; j++) { uint32_t v = row(r).v[j]; if (v) pos[fill[v]++] = ((uint32_t)j << 30) | (uint32_t)r; }
-        std::vector<uint32_t> sig((size_t)4 * N);
-        for (int j = 0; j < 4; j++) for (uint64_t r = 0; r < N; r++) sig[(size_t)j * N + r] = ((uint32_t)j << 30) | (uint32_t)r;
-        for (size_t v = 1; v < T.num_vars; v++) {
-            uint32_t b = cnt[v], e = cnt[v + 1];
-            if (e - b < 2) continue;
-            for (uint32_t k = b; k < e; k++) {
-                uint32_t here = pos[k], next = pos[k + 1 < e ? k + 1 : b];
-                sig[(size_t)(here >> 30) * N + (here & 0x3fffffffu)] = next;
-            }
-        }
         Fr kk[4];
         for (int j = 0; j < 4; j++) kk[j] = from_u64<FrParams>(NON_RESIDUES[j]);
-        // reuse sig_coef[j] as the upload buffer for the packed indices (N u32 <= N Fr)
+        // sig_coef[0..3] are contiguous and not yet written: their first 4 * N words take the packed successors
+        static_assert(sizeof(Fr) >= 4, "index scratch inside the sigma buffers");
+        DevBuf idx_buf;
+        if ((rc = idx_buf.reserve((size_t)4 * N * 4)) != PLK_OK) return fail(rc);
+        uint32_t *idx = idx_buf.as<uint32_t>();
+        if ((rc = build_permutation_index(ctx, S->gate_vars, (uint32_t)N, T.num_vars, idx, st)) != PLK_OK) { idx_buf.release(); return fail(rc); }
         for (int j = 0; j < 4; j++) {
-            uint32_t *tmp = reinterpret_cast<uint32_t *>(S->sig_coef[j]);
-            if (hipMemcpyAsync(tmp, sig.data() + (size_t)j * N, N * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D sigma", __FILE__, __LINE__));
-            if ((rc = sigma_from_index(S->sig_vals[j], tmp, (uint32_t)N, log_n, ctx->tw_fwd, kk, st)) != PLK_OK) return fail(rc);
-            if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
-            if (hipMemcpyAsync(S->sig_coef[j], S->sig_vals[j], N * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "D2D sigma", __FILE__, __LINE__));
-            if ((rc = ntt_dev(ctx, S->sig_coef[j], log_n, true, nullptr, st)) != PLK_OK) return fail(rc);
+            if ((rc = sigma_from_index(S->sig_vals[j], idx + (size_t)j * N, (uint32_t)N, log_n, ctx->tw_fwd, kk, st)) != PLK_OK) { idx_buf.release(); return fail(rc); }
+            if (hipMemcpyAsync(S->sig_coef[j], S->sig_vals[j], N * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) { idx_buf.release(); return fail(hip_fail(hipGetLastError(), "D2D sigma", __FILE__, __LINE__)); }
+            if ((rc = ntt_dev(ctx, S->sig_coef[j], log_n, true, nullptr, st)) != PLK_OK) { idx_buf.release(); return fail(rc); }
         }
+        hipError_t e = hipStreamSynchronize(st);
+        idx_buf.release();
+        if (e != hipSuccess) return fail(hip_fail(e, "sync", __FILE__, __LINE__));
     }
-    if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
-    mark("permutation (4 iNTT)");
+    mark("permutation (device sort + 4 iNTT)");
     *out = S;
     return PLK_OK;
 }
