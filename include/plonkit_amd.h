@@ -208,6 +208,11 @@ int32_t plk_circuit_analyse(const plk_circuit *c, char *out_json, uint64_t cap);
 typedef struct plk_setup plk_setup;
 /* SetupForProver::prepare_setup_for_prover (src/plonk.rs:97-119): transpile + setup() = 11 iNTT(N) */
 int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out);
+/* the same in two calls: the host phase (transpile + columns, pure CPU, no context) may run while another thread is still
+ * bringing the GPU up (plk_create, key upload, plk_srs_precompute); plk_setup_upload then moves it to the device
+ * (11 uploads, 11 iNTT, the permutation).  plk_setup_prepare == plk_setup_prepare_host + plk_setup_upload.              */
+int32_t plk_setup_prepare_host(const plk_circuit *c, plk_setup **out);
+int32_t plk_setup_upload(plk_ctx *ctx, plk_setup *s);
 void plk_setup_free(plk_setup *s);
 uint64_t plk_setup_domain_size(const plk_setup *s);                    /* N = n + 1              */
 /* make_verification_key + VerificationKey::write (src/plonk.rs:122-124; src/bin/main.rs:501-502).

@@ -296,15 +296,25 @@ static int run(int argc, char **argv) {
             // the GPU side of the start-up (HIP initialisation, key parse + upload, fixed-base table of the MSM) runs on a
             // second thread while this one parses the circuit and the witness: neither needs the other until the setup
             std::thread gpu([&] {
+                const bool tm = getenv("PLK_CLI_TIMING") != nullptr;
+                double t0 = now_s(), t1;
+                auto lap = [&](const char *what) { if (tm) { t1 = now_s(); fprintf(stderr, "[timing]   gpu thread: %-24s +%.3f s\n", what, t1 - t0); t0 = t1; } };
                 ctx = open_ctx(rk);
+                lap("plk_create (HIP init)");
                 load_key(ctx, a.get("srs_monomial_form"), g2);
                 if (!lag.empty()) { uint8_t g2l[256]; load_key(ctx, lag, g2l, true); }
+                lap("key read + parse + upload");
                 CK("srs precompute", plk_srs_precompute(ctx));
+                lap("MSM table");
             });
             c = load_circuit(resolve_circuit(a), &wf);
             phase("load circuit + witness");
+            CK("prepare err", plk_setup_prepare_host(c, &s));             // pure CPU: does not wait for the GPU either
+            phase("setup: host phase");
             gpu.join();
             phase("HIP init + key + table (other thread)");
+            CK("prepare err", plk_setup_upload(ctx, s));
+            phase("setup: device phase");
         } else {
             c = load_circuit(resolve_circuit(a), &wf);
             phase("load circuit + witness");
@@ -332,6 +342,7 @@ static int run(int argc, char **argv) {
         if (rc == PLK_ERR_UNSAT) { fprintf(stderr, "must satisfy: %s\n", plk_last_error()); return 101; }
         if (rc != PLK_OK) die("prove", rc);
         phase("prove");
+        if (getenv("PLK_CLI_TIMING")) { CK("sync", plk_synchronize(ctx)); phase("device idle"); }
         if (rk.rank != 0) return 0;                                  // every rank holds the same bytes; rank 0 writes them
         std::string out = a.get("proof", "proof.bin");
         refuse_duplicate(a, out, "proof");
@@ -347,6 +358,7 @@ static int run(int argc, char **argv) {
         fprintf(stderr, "Proof json saved to %s\n", pj.c_str());
         spit(ij, reinterpret_cast<const uint8_t *>(is.data()), is.size());
         fprintf(stderr, "Public input json saved to %s\n", ij.c_str());
+        phase("files written");
     } else if (cmd == "verify") {                                    // src/bin/main.rs:425-437 (no GPU involved)
         // VerifyOpts (src/bin/main.rs:125-137): the key is `-v` / `--verification_key` here, while export-verification-key
         // names its output `--vk` (src/bin/main.rs:186-187); `--vk` is kept as an alias on verify

@@ -16,6 +16,7 @@
 #include "circuit.h"
 #include "keccak.h"
 #include <chrono>
+#include <memory>
 #include <thread>
 #include <algorithm>
 #include <cstring>
@@ -178,6 +179,8 @@ struct plk_setup {
     bool ops_independent = false;          // no temporary reads another temporary -> order-free evaluation
     plk::DevBuf ops_dev, terms_dev;        // the same records on the device (only when ops_independent): evaluated there
     std::vector<plk::WitnessTerm> op_terms;
+    std::vector<plk::HFr> h_cols;          // host phase only: 7 selector columns x N, until plk_setup_upload
+    std::vector<uint32_t> h_vars;          // host phase only: 4 variable-index columns x N
 };
 
 using namespace plk;
@@ -191,10 +194,12 @@ extern "C" {
 uint64_t plk_setup_domain_size(const plk_setup *s) { return s ? s->N : 0; }
 void plk_setup_free(plk_setup *s) { if (s) { s->store.release(); s->lde_store.release(); s->ops_dev.release(); s->terms_dev.release(); delete s; } }
 
-static int32_t setup_prepare_impl(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
-    if (!ctx || !c || !out) { set_error("plk_setup_prepare: bad argument"); return PLK_ERR_ARG; }
+// SetupForProver::prepare_setup_for_prover in two phases, so that a host program can run the first one (pure CPU:
+// transpile, selector / variable-index columns) while the GPU side of its start-up is still under way on another thread
+// (HIP initialisation, key upload, MSM table — the `plonkit` binary does exactly that), and the second one when both are done.
+static int32_t setup_host_impl(const plk_circuit *c, plk_setup **out) {
+    if (!c || !out) { set_error("plk_setup_prepare: bad argument"); return PLK_ERR_ARG; }
     *out = nullptr;
-    PLK_HIP(hipSetDevice(ctx->device));
     const bool timing = getenv("PLK_CLI_TIMING") != nullptr;     // phase times of the setup on stderr (tools/cli_scale.sh)
     double t_last = now_ms();
     auto mark = [&](const char *what) { if (timing) { double t = now_ms(); fprintf(stderr, "[timing]   setup: %-22s +%.3f s\n", what, (t - t_last) / 1e3); t_last = t; } };
@@ -202,31 +207,19 @@ static int32_t setup_prepare_impl(plk_ctx *ctx, const plk_circuit *c, plk_setup 
     T.collect_stats = false;                                     // a million std::string names are only wanted by `analyse`
     if (!transpile(c->r1cs, nullptr, &T)) return PLK_ERR_UNSAT;
     mark("transpile");
-    plk_setup *S = new plk_setup();
+    std::unique_ptr<plk_setup> S(new plk_setup());
     S->num_inputs = c->r1cs.num_inputs - 1;
     S->num_gates = T.gates.size();
     S->n_real = S->num_inputs + T.gates.size();
     S->num_vars = T.num_vars;
     uint64_t N = 1; uint32_t log_n = 0;
     while (N < S->n_real + 1) { N <<= 1; log_n++; }
-    if (log_n + 2 > MAX_LOG_N) { delete S; set_error("setup power of two is not in the correct range"); return PLK_ERR_SIZE; }   // src/plonk.rs:109-112
+    if (log_n + 2 > MAX_LOG_N) { set_error("setup power of two is not in the correct range"); return PLK_ERR_SIZE; }   // src/plonk.rs:109-112
     S->N = N; S->n = N - 1; S->log_n = log_n;
     S->num_circuit_vars = c->r1cs.num_variables;
     S->ops.swap(T.ops); S->op_terms.swap(T.op_terms);
     S->ops_independent = true;
     for (const WitnessTerm &t : S->op_terms) if (t.var >= c->r1cs.num_variables) { S->ops_independent = false; break; }
-    static_assert(sizeof(WitnessOp) == 40 && sizeof(WitnessTerm) == 40, "records are uploaded as they are (poly.hip)");
-    if (S->ops_independent && !S->ops.empty()) {                     // temporaries will be evaluated on the device
-        int32_t rc2 = S->ops_dev.reserve(S->ops.size() * sizeof(WitnessOp));
-        if (rc2 == PLK_OK) rc2 = S->terms_dev.reserve(S->op_terms.size() * sizeof(WitnessTerm) + 8);
-        if (rc2 != PLK_OK) { delete S; return rc2; }
-        if (hipMemcpy(S->ops_dev.p, S->ops.data(), S->ops.size() * sizeof(WitnessOp), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(S->terms_dev.p, S->op_terms.data(), S->op_terms.size() * sizeof(WitnessTerm), hipMemcpyHostToDevice) != hipSuccess) {
-            S->ops_dev.release(); S->terms_dev.release(); delete S;
-            return hip_fail(hipGetLastError(), "H2D witness ops", __FILE__, __LINE__);
-        }
-    }
-    mark("temporaries (record + upload)");
     // rows of the trace: one gate per public input first (q_a = -1), then the transpiler's gates — viewed in place
     std::vector<Gate> input_rows;
     for (uint64_t i = 1; i <= S->num_inputs; i++) {
@@ -237,56 +230,76 @@ static int32_t setup_prepare_impl(plk_ctx *ctx, const plk_circuit *c, plk_setup 
     }
     const size_t n_in = input_rows.size(), n_rows = n_in + T.gates.size();
     auto row = [&](uint64_t r) -> const Gate & { return r < n_in ? input_rows[r] : T.gates[r - n_in]; };
+    // ONE pass over the gate records on all host threads fills the seven selector columns and the four variable-index
+    // columns (rows 0 .. n_real - 1, zero / dummy beyond)
+    S->h_cols.resize((size_t)7 * N);
+    S->h_vars.resize((size_t)4 * N);
+    HFr *cols = S->h_cols.data(); uint32_t *vars = S->h_vars.data();
+    parallel_for(N, 1 << 15, [&](size_t lo, size_t hi) {
+        for (size_t r = lo; r < hi; r++) {
+            if (r < n_rows) {
+                const Gate &g = row(r);
+                for (int k = 0; k < 7; k++) cols[(size_t)k * N + r] = g.q[k];
+                for (int j = 0; j < 4; j++) vars[(size_t)j * N + r] = g.v[j];
+            } else {
+                for (int k = 0; k < 7; k++) cols[(size_t)k * N + r] = HFr::zero();
+                for (int j = 0; j < 4; j++) vars[(size_t)j * N + r] = 0;
+            }
+        }
+    });
+    mark("columns (host fill)");
+    *out = S.release();
+    return PLK_OK;
+}
+
+static int32_t setup_upload_impl(plk_ctx *ctx, plk_setup *S) {
+    if (!ctx || !S) { set_error("plk_setup_upload: bad argument"); return PLK_ERR_ARG; }
+    if (S->store.p) return PLK_OK;                               // already resident
+    if (S->h_cols.empty()) { set_error("plk_setup_upload: the host phase has not run"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    const bool timing = getenv("PLK_CLI_TIMING") != nullptr;
+    double t_last = now_ms();
+    auto mark = [&](const char *what) { if (timing) { double t = now_ms(); fprintf(stderr, "[timing]   setup: %-22s +%.3f s\n", what, (t - t_last) / 1e3); t_last = t; } };
+    const uint64_t N = S->N; const uint32_t log_n = S->log_n;
+    static_assert(sizeof(WitnessOp) == 40 && sizeof(WitnessTerm) == 40, "records are uploaded as they are (poly.hip)");
+    hipStream_t st = ctx->stream;
+    auto fail = [&](int32_t code) { S->store.release(); S->ops_dev.release(); S->terms_dev.release(); return code; };
+    int32_t rc;
+    if (S->ops_independent && !S->ops.empty()) {                     // temporaries will be evaluated on the device
+        if ((rc = S->ops_dev.reserve(S->ops.size() * sizeof(WitnessOp))) != PLK_OK) return fail(rc);
+        if ((rc = S->terms_dev.reserve(S->op_terms.size() * sizeof(WitnessTerm) + 8)) != PLK_OK) return fail(rc);
+        if (hipMemcpyAsync(S->ops_dev.p, S->ops.data(), S->ops.size() * sizeof(WitnessOp), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(S->terms_dev.p, S->op_terms.data(), S->op_terms.size() * sizeof(WitnessTerm), hipMemcpyHostToDevice, st) != hipSuccess)
+            return fail(hip_fail(hipGetLastError(), "H2D witness ops", __FILE__, __LINE__));
+    }
     Arena A{&S->store};
     size_t total = 22 * ((N * sizeof(Fr) + 255) & ~(size_t)255) + 4 * ((N * 4 + 255) & ~(size_t)255);
-    int32_t rc = S->store.reserve(total);
-    if (rc != PLK_OK) { delete S; return rc; }
+    if ((rc = S->store.reserve(total)) != PLK_OK) return fail(rc);
     for (int k = 0; k < 7; k++) S->sel_coef[k] = A.take<Fr>(N);
     for (int k = 0; k < 7; k++) S->sel_vals[k] = A.take<Fr>(N);
     for (int j = 0; j < 4; j++) S->sig_coef[j] = A.take<Fr>(N);
     for (int j = 0; j < 4; j++) S->sig_vals[j] = A.take<Fr>(N);
     for (int j = 0; j < 4; j++) S->gate_vars[j] = A.take<uint32_t>(N);
-
-    hipStream_t st = ctx->stream;
-    auto fail = [&](int32_t code) { plk_setup_free(S); return code; };
-    // ONE pass over the gate records on all host threads fills the seven selector columns and the four variable-index
-    // columns (rows 0 .. n_real - 1, zero / dummy beyond); they are uploaded back to back and interpolated as they land
-    {
-        std::vector<HFr> cols((size_t)7 * N);
-        std::vector<uint32_t> vars((size_t)4 * N);
-        parallel_for(N, 1 << 15, [&](size_t lo, size_t hi) {
-            for (size_t r = lo; r < hi; r++) {
-                if (r < n_rows) {
-                    const Gate &g = row(r);
-                    for (int k = 0; k < 7; k++) cols[(size_t)k * N + r] = g.q[k];
-                    for (int j = 0; j < 4; j++) vars[(size_t)j * N + r] = g.v[j];
-                } else {
-                    for (int k = 0; k < 7; k++) cols[(size_t)k * N + r] = HFr::zero();
-                    for (int j = 0; j < 4; j++) vars[(size_t)j * N + r] = 0;
-                }
-            }
-        });
-        mark("columns (host fill)");
-        for (int j = 0; j < 4; j++)
-            if (hipMemcpyAsync(S->gate_vars[j], vars.data() + (size_t)j * N, N * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D vars", __FILE__, __LINE__));
-        for (int k = 0; k < 7; k++) {
-            if (hipMemcpyAsync(S->sel_vals[k], cols.data() + (size_t)k * N, N * sizeof(Fr), hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D selector", __FILE__, __LINE__));
-            if (hipMemcpyAsync(S->sel_coef[k], S->sel_vals[k], N * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "D2D selector", __FILE__, __LINE__));
-            if ((rc = ntt_dev(ctx, S->sel_coef[k], log_n, true, nullptr, st)) != PLK_OK) return fail(rc);
-        }
-        if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));   // the host columns go away here
+    // the columns are uploaded back to back and interpolated as they land
+    for (int j = 0; j < 4; j++)
+        if (hipMemcpyAsync(S->gate_vars[j], S->h_vars.data() + (size_t)j * N, N * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D vars", __FILE__, __LINE__));
+    for (int k = 0; k < 7; k++) {
+        if (hipMemcpyAsync(S->sel_vals[k], S->h_cols.data() + (size_t)k * N, N * sizeof(Fr), hipMemcpyHostToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "H2D selector", __FILE__, __LINE__));
+        if (hipMemcpyAsync(S->sel_coef[k], S->sel_vals[k], N * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "D2D selector", __FILE__, __LINE__));
+        if ((rc = ntt_dev(ctx, S->sel_coef[k], log_n, true, nullptr, st)) != PLK_OK) return fail(rc);
     }
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
+    std::vector<HFr>().swap(S->h_cols);                          // the host columns go away here
+    std::vector<uint32_t>().swap(S->h_vars);
     mark("selectors (upload + 7 iNTT)");
     // the permutation (rotate-left over each variable's occurrences) from the variable-index table, on the device (perm.hip)
     {
         Fr kk[4];
         for (int j = 0; j < 4; j++) kk[j] = from_u64<FrParams>(NON_RESIDUES[j]);
-        // sig_coef[0..3] are contiguous and not yet written: their first 4 * N words take the packed successors
-        static_assert(sizeof(Fr) >= 4, "index scratch inside the sigma buffers");
         DevBuf idx_buf;
         if ((rc = idx_buf.reserve((size_t)4 * N * 4)) != PLK_OK) return fail(rc);
         uint32_t *idx = idx_buf.as<uint32_t>();
-        if ((rc = build_permutation_index(ctx, S->gate_vars, (uint32_t)N, T.num_vars, idx, st)) != PLK_OK) { idx_buf.release(); return fail(rc); }
+        if ((rc = build_permutation_index(ctx, S->gate_vars, (uint32_t)N, S->num_vars, idx, st)) != PLK_OK) { idx_buf.release(); return fail(rc); }
         for (int j = 0; j < 4; j++) {
             if ((rc = sigma_from_index(S->sig_vals[j], idx + (size_t)j * N, (uint32_t)N, log_n, ctx->tw_fwd, kk, st)) != PLK_OK) { idx_buf.release(); return fail(rc); }
             if (hipMemcpyAsync(S->sig_coef[j], S->sig_vals[j], N * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) { idx_buf.release(); return fail(hip_fail(hipGetLastError(), "D2D sigma", __FILE__, __LINE__)); }
@@ -297,6 +310,15 @@ static int32_t setup_prepare_impl(plk_ctx *ctx, const plk_circuit *c, plk_setup 
         if (e != hipSuccess) return fail(hip_fail(e, "sync", __FILE__, __LINE__));
     }
     mark("permutation (device sort + 4 iNTT)");
+    return PLK_OK;
+}
+
+static int32_t setup_prepare_impl(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
+    if (!ctx || !c || !out) { set_error("plk_setup_prepare: bad argument"); return PLK_ERR_ARG; }
+    plk_setup *S = nullptr;
+    PLK_TRY(setup_host_impl(c, &S));
+    const int32_t rc = setup_upload_impl(ctx, S);
+    if (rc != PLK_OK) { plk_setup_free(S); *out = nullptr; return rc; }
     *out = S;
     return PLK_OK;
 }
@@ -308,6 +330,7 @@ static void put_fr(std::vector<uint8_t> &b, const HFr &v) { uint8_t t[32]; v.to_
 static int32_t setup_write_vk_impl(plk_ctx *ctx, const plk_setup *s, const uint8_t g2_bytes[256], uint8_t *out, uint64_t cap, uint64_t *len) {
     if (!ctx || !s || !g2_bytes || !out || !len) { set_error("plk_setup_write_vk: bad argument"); return PLK_ERR_ARG; }
     PLK_HIP(hipSetDevice(ctx->device));
+    if (!s->store.p) { set_error("plk_setup_write_vk: the setup is not on the device yet (plk_setup_upload)"); return PLK_ERR_ARG; }
     PLK_TRY(fifo_must_be_empty(ctx, "plk_setup_write_vk"));
     FifoGuard fifo_guard(ctx);
     std::vector<uint8_t> b;
@@ -347,6 +370,7 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     if (!c->has_witness) { set_error("plk_prove: circuit has no witness"); return PLK_ERR_ARG; }
     PLK_HIP(hipSetDevice(ctx->device));
     if (!ctx->srs || (!ctx->combine && ctx->srs_n < S->N)) { set_error("SRS too small for this circuit"); return PLK_ERR_SRS; }
+    if (!S->store.p) { set_error("plk_prove: the setup is not on the device yet (plk_setup_upload)"); return PLK_ERR_ARG; }
     PLK_TRY(fifo_must_be_empty(ctx, "plk_prove"));
     FifoGuard fifo_guard(ctx);
     ctx->timings.clear();
@@ -740,6 +764,12 @@ int32_t plk_permutation_grand_product_dev(plk_ctx *ctx, const void *const wires_
 // the exported entry points: no C++ exception (std::bad_alloc from a host vector of a 2^26 domain) crosses the boundary
 int32_t plk_setup_prepare(plk_ctx *ctx, const plk_circuit *c, plk_setup **out) {
     return guarded("plk_setup_prepare", PLK_ERR_HIP, [&] { return setup_prepare_impl(ctx, c, out); });
+}
+int32_t plk_setup_prepare_host(const plk_circuit *c, plk_setup **out) {
+    return guarded("plk_setup_prepare_host", PLK_ERR_FORMAT, [&] { return setup_host_impl(c, out); });
+}
+int32_t plk_setup_upload(plk_ctx *ctx, plk_setup *s) {
+    return guarded("plk_setup_upload", PLK_ERR_HIP, [&] { return setup_upload_impl(ctx, s); });
 }
 int32_t plk_setup_write_vk(plk_ctx *ctx, const plk_setup *s, const uint8_t g2_bytes[256], uint8_t *out, uint64_t cap, uint64_t *len) {
     return guarded("plk_setup_write_vk", PLK_ERR_HIP, [&] { return setup_write_vk_impl(ctx, s, g2_bytes, out, cap, len); });
