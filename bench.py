@@ -198,11 +198,10 @@ def reference_binary_baseline(log_domain):
 def sharded_prove(ctx, dist, device, log_n, rank, world):
     """whole prove with every commitment sharded over the ranks (plonkit_amd.sharded.ShardedProver)"""
     import plonkit_amd as pa
-    from plonkit_amd.sharded import ShardedProver
     n = 1 << log_n
     local = n // world
     ctx.srs_generate(local, rank * local, 42)                     # this rank's slice of the 2^log_n key
-    sp = ShardedProver(ctx, dist, device)
+    ctx.comm_set_shard(rank * local)                              # built-in combiner (RCCL all-gather + EC sum in the library)
     circ = pa.Circuit.synthetic(n - 2)
     setup = pa.SetupForProver(ctx, circ)
     proof = setup.prove(circ)                                      # warm-up: tables, allocations, cached extensions
@@ -216,11 +215,11 @@ def sharded_prove(ctx, dist, device, log_n, rank, world):
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         best = float(t.item()) if best is None else min(best, float(t.item()))
-    sp.close()
     setup.close(); circ.close()
     return {"wall_s": round(best, 4), "domain": n, "n_gpus": world, "srs_points_per_gpu": local, "proof_bytes": len(proof),
             "what": "SetupForProver::prove with every commitment computed as the sum over ranks of MSM(slice of the scalars, "
-                    "slice of the SRS): all_gather of the Jacobian partial sums + host EC sum; NTTs and point-wise work replicated"}
+                    "slice of the SRS): ncclAllGather of the Jacobian partial sums inside the library (plk_comm_init) + host EC sum; "
+                    "NTTs and point-wise work replicated"}
 
 
 def strong_scaling_msm(ctx, dist, device, rank, world, log_total=24, reps=5):
@@ -233,7 +232,7 @@ def strong_scaling_msm(ctx, dist, device, rank, world, log_total=24, reps=5):
     scal = rand_scalars(local, 0x24 + rank, device)
     torch.cuda.synchronize()
     ctx.srs_generate(local, rank * local, 42)
-    msm = ShardedMsm(ctx, dist, device)
+    msm = ShardedMsm(ctx, dist, device, native=True)              # the communicator main() created
     stream = torch.cuda.Stream(device=device)
     for _ in msm.commit_stream((scal for _ in range(2)), local, stream=stream):
         pass
@@ -334,7 +333,14 @@ def main():
     scalars = rand_scalars(n, 0x706c6f6e6b6974 + rank, device)
     torch.cuda.synchronize()                             # the scalars are consumed on another stream
     stream = torch.cuda.Stream(device=device)
-    msm = ShardedMsm(ctx, dist if (world > 1 or force_dist) else None, device)
+    multi = world > 1 or force_dist
+    if multi:
+        # the exchange of the partial sums runs inside the library (comm.cpp: ncclAllGather on the context's stream + host
+        # EC sum); torch.distributed only carries the 128-byte RCCL id to the other ranks and the timing barriers
+        box = [pa.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init(rank, world, box[0], rank * n)
+    msm = ShardedMsm(ctx, dist if multi else None, device, native=multi)
     ctx.set_kernel_timing(True)
 
     # W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; the exchange of commitment k

@@ -133,7 +133,10 @@ typedef struct { char bytes[128]; } plk_comm_id;                       /* an ncc
 int32_t plk_comm_unique_id(plk_comm_id *out);
 int32_t plk_comm_init(plk_ctx *ctx, int32_t rank, int32_t world, const plk_comm_id *id, uint64_t first_index);
 int32_t plk_comm_init_tcp(plk_ctx *ctx, int32_t rank, int32_t world, uint16_t port, uint64_t first_index);
+int32_t plk_comm_set_shard(plk_ctx *ctx, uint64_t first_index);         /* same communicator, another slice of the key */
 int32_t plk_comm_destroy(plk_ctx *ctx);                                 /* back to single-GPU commitments */
+/* plk_msm_g1_finish + the combiner: the commitment over all ranks' shards (each rank enqueued its own slice), affine */
+int32_t plk_msm_g1_finish_sharded(plk_ctx *ctx, plk_g1_affine *out);
 /* the combiner on its own (no context, no GPU): the TCP transport opened directly, and the plk_combine_fn it serves —
  * plk_set_commit_shard(ctx, first, plk_comm_combine, comm) is what plk_comm_init_tcp does.  Used by the CPU tests. */
 int32_t plk_comm_open_tcp(int32_t rank, int32_t world, uint16_t port, void **comm_out);

@@ -144,6 +144,15 @@ class Context:
     def comm_init_tcp(self, rank, world, port, first_index):
         _check(lib().plk_comm_init_tcp(self._h, ctypes.c_int32(rank), ctypes.c_int32(world), ctypes.c_uint16(port), ctypes.c_uint64(first_index)))
 
+    def comm_set_shard(self, first_index):
+        _check(lib().plk_comm_set_shard(self._h, ctypes.c_uint64(first_index)))
+
+    def msm_finish_sharded(self):
+        """finish + the built-in exchange: affine commitment over all ranks' shards"""
+        out = np.zeros(8, dtype=np.uint64)
+        _check(lib().plk_msm_g1_finish_sharded(self._h, _np(out)))
+        return out
+
     def comm_destroy(self):
         _check(lib().plk_comm_destroy(self._h))
 

@@ -246,7 +246,7 @@ bool parse_r1cs_json(const uint8_t *data, size_t len, R1cs *out) {
 }
 
 // ------------------------------------------------------------------------------ witness
-bool parse_wtns_bin(const uint8_t *data, size_t len, std::vector<HFr> *out) {
+bool parse_wtns_bin(const uint8_t *data, size_t len, big_vector<HFr> *out) {
     Rd r(data, len);
     if (len < 4 || memcmp(data, "wtns", 4) != 0) { set_error("invalid file header"); return false; }
     r.off = 4;
@@ -273,7 +273,7 @@ bool parse_wtns_bin(const uint8_t *data, size_t len, std::vector<HFr> *out) {
     return true;
 }
 
-bool parse_witness_json(const uint8_t *data, size_t len, std::vector<HFr> *out) {
+bool parse_witness_json(const uint8_t *data, size_t len, big_vector<HFr> *out) {
     JVal root;
     if (!json_parse(data, len, &root) || root.t != JVal::ARR) { set_error("unable to read: witness json is not an array"); return false; }
     out->resize(root.a.size());
@@ -292,7 +292,7 @@ struct Term { uint32_t var; HFr coeff; };
 // the host threads and stitches the pieces in constraint order, shifting every temporary id by the number of temporaries
 // of the pieces before it — the result is what a single serial pass produces (gate order, ids, statistics).
 struct Piece {
-    std::vector<Gate> gates;
+    big_vector<Gate> gates;
     std::vector<HFr> tmp_values;            // per temporary; only when a witness is given
     std::vector<WitnessOp> ops;
     std::vector<WitnessTerm> op_terms;
@@ -303,7 +303,7 @@ struct Piece {
 
 struct Builder {
     Piece *t;
-    const std::vector<HFr> *witness;        // circom wires (index 0 = ONE in the file, the dummy variable here), or null
+    const big_vector<HFr> *witness;         // circom wires (index 0 = ONE in the file, the dummy variable here), or null
     uint64_t first_tmp;                     // r.num_variables
     const HFr zero = HFr::zero(), one = HFr::one(), minus_one = -HFr::one();
     bool have_values() const { return witness != nullptr; }
@@ -438,8 +438,9 @@ struct Builder {
 
 }  // namespace
 
-bool transpile(const R1cs &r, const std::vector<HFr> *witness, Transpiled *out) {
-    out->gates.clear(); out->values.clear(); out->stats.clear(); out->num_hints = 0;
+bool transpile(const R1cs &r, const big_vector<HFr> *witness, Transpiled *out) {
+    out->pieces.clear(); out->gate0.clear(); out->tmp_shift.clear(); out->num_gates = 0; out->first_tmp = r.num_variables;
+    out->values.clear(); out->stats.clear(); out->num_hints = 0;
     out->ops.clear(); out->op_terms.clear();
     out->num_vars = r.num_variables;
     if (witness && witness->size() < r.num_variables) { set_error("witness shorter than the number of variables"); return false; }
@@ -468,7 +469,11 @@ bool transpile(const R1cs &r, const std::vector<HFr> *witness, Transpiled *out) 
         out->num_hints += pieces[k].num_hints;
     }
     if (r.num_variables + t0[chunks] >= (1ull << 32) || o0[chunks] >= (1ull << 32)) { set_error("circuit too large: variable ids do not fit 32 bits"); return false; }
-    out->gates.resize(g0[chunks]); out->ops.resize(t0[chunks]); out->op_terms.resize(o0[chunks]);
+    out->num_gates = g0[chunks];
+    out->gate0.assign(g0.begin(), g0.end());
+    out->tmp_shift.resize(chunks);
+    out->pieces.resize(chunks);
+    out->ops.resize(t0[chunks]); out->op_terms.resize(o0[chunks]);
     if (stats) out->stats.resize(s0[chunks]);
     out->num_vars = r.num_variables + t0[chunks];
     if (witness) {
@@ -481,16 +486,12 @@ bool transpile(const R1cs &r, const std::vector<HFr> *witness, Transpiled *out) 
         for (size_t k = lo; k < hi; k++) {
             Piece &p = pieces[k];
             const uint32_t shift = (uint32_t)t0[k];
-            Gate *gd = out->gates.data() + g0[k];
-            for (size_t i = 0; i < p.gates.size(); i++) {
-                gd[i] = p.gates[i];
-                for (int j = 0; j < 4; j++) if (gd[i].v[j] >= nv) gd[i].v[j] += shift;
-            }
+            out->tmp_shift[k] = shift;
+            out->pieces[k].swap(p.gates);                      // the gates stay where they were produced
             for (size_t i = 0; i < p.ops.size(); i++) { WitnessOp op = p.ops[i]; op.first += (uint32_t)o0[k]; out->ops[t0[k] + i] = op; }
             for (size_t i = 0; i < p.op_terms.size(); i++) { WitnessTerm wt = p.op_terms[i]; if (wt.var >= nv) wt.var += shift; out->op_terms[o0[k] + i] = wt; }
             if (stats) for (size_t i = 0; i < p.stats.size(); i++) out->stats[s0[k] + i] = std::move(p.stats[i]);
             if (witness) std::copy(p.tmp_values.begin(), p.tmp_values.end(), out->values.begin() + r.num_variables + t0[k]);
-            std::vector<Gate>().swap(p.gates);                 // give the memory back as soon as the piece is placed
         }
     }, nt);
     return true;
@@ -499,7 +500,7 @@ bool transpile(const R1cs &r, const std::vector<HFr> *witness, Transpiled *out) 
 std::string analyse_json(const R1cs &r, const Transpiled &t) {
     std::string s = "{\"num_inputs\":" + std::to_string(r.num_inputs) + ",\"num_aux\":" + std::to_string(r.num_aux) +
                     ",\"num_variables\":" + std::to_string(r.num_variables) + ",\"num_constraints\":" + std::to_string(r.num_constraints()) +
-                    ",\"num_nontrivial_constraints\":" + std::to_string(t.stats.size()) + ",\"num_gates\":" + std::to_string(t.gates.size()) +
+                    ",\"num_nontrivial_constraints\":" + std::to_string(t.stats.size()) + ",\"num_gates\":" + std::to_string(t.num_gates) +
                     ",\"num_hints\":" + std::to_string(t.num_hints);
     if (!t.stats.empty()) {
         s += ",\"constraint_stats\":[";
@@ -599,7 +600,7 @@ static int32_t circuit_synthetic_impl(uint64_t target_gates, uint64_t seed, plk_
     std::unique_ptr<plk_circuit> holder(new plk_circuit());
     plk_circuit *c = holder.get();
     Xoshiro256ss rng(seed);
-    std::vector<HFr> &w = c->witness;
+    big_vector<HFr> &w = c->witness;
     w.reserve(target_gates + 8);
     w.push_back(HFr::one()); w.push_back(HFr::zero()); w.push_back(rng.fr()); w.push_back(rng.fr());
     R1cs &R = c->r1cs;

@@ -18,7 +18,36 @@
 #include <exception>
 #include <functional>
 
+#include <cstdlib>
+#include <sys/mman.h>
+
 namespace plk {
+
+// Allocator of the few very large host vectors of the loaders, the transpiler and the setup (hundreds of MB written once by
+// many threads): 2 MiB-aligned blocks marked MADV_HUGEPAGE.  With 4 KiB pages the first touch of 650 MB at the 2^20 domain is
+// 160 K page faults serialised on the address-space lock — a large part of what `plonkit prove` spends outside the GPU.
+template <class T> struct HugeAlloc {
+    using value_type = T;
+    HugeAlloc() = default;
+    template <class U> HugeAlloc(const HugeAlloc<U> &) {}
+    T *allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        void *p = nullptr;
+        if (bytes >= ((size_t)4 << 20)) {
+            const size_t huge = (size_t)2 << 20, rounded = (bytes + huge - 1) & ~(huge - 1);
+            if (posix_memalign(&p, huge, rounded) != 0) throw std::bad_alloc();
+            (void)madvise(p, rounded, MADV_HUGEPAGE);
+        } else {
+            p = malloc(bytes ? bytes : 1);
+            if (!p) throw std::bad_alloc();
+        }
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, size_t) { free(p); }
+    template <class U> bool operator==(const HugeAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const HugeAlloc<U> &) const { return false; }
+};
+template <class T> using big_vector = std::vector<T, HugeAlloc<T>>;
 
 void set_error(const std::string &msg);
 // nothing may unwind through the extern "C" boundary: a std::bad_alloc (a header that announces 2^32 constraints) or any
@@ -47,7 +76,7 @@ struct LcView {                             // one linear combination inside R1c
 // offset table — a 2^20-constraint circuit is three allocations, not three million, and the loaders fill it from many threads
 struct R1cs {
     uint64_t num_inputs = 0, num_aux = 0, num_variables = 0;
-    std::vector<LcTerm> terms;
+    big_vector<LcTerm> terms;
     std::vector<uint64_t> off{0};           // 3 * num_constraints + 1 offsets into terms
     size_t num_constraints() const { return (off.size() - 1) / 3; }
     LcView lc(size_t constraint, int which) const { const uint64_t b = off[3 * constraint + which]; return {terms.data() + b, (size_t)(off[3 * constraint + which + 1] - b)}; }
@@ -73,7 +102,19 @@ struct WitnessTerm { uint32_t var; HFr coeff; };
 struct WitnessOp { uint32_t first, count; HFr constant; };
 
 struct Transpiled {
-    std::vector<Gate> gates;            // without the public-input gates
+    // The gates (without the public-input gates) stay in the pieces the host threads produced, in constraint order: piece k
+    // holds gates [gate0[k], gate0[k + 1]); inside a piece the transpiler's temporaries are numbered from first_tmp as if the
+    // piece were alone, so a consumer adds tmp_shift[k] to every variable id >= first_tmp (gate_at() does).  The setup reads
+    // them once, piece-parallel, straight into its columns — a 2^20-gate circuit never holds a second 250 MB copy.
+    std::vector<big_vector<Gate>> pieces;
+    std::vector<uint64_t> gate0;        // pieces.size() + 1 entries
+    std::vector<uint32_t> tmp_shift;
+    uint64_t num_gates = 0, first_tmp = 0;
+    Gate gate_at(size_t piece, size_t i) const {
+        Gate g = pieces[piece][i];
+        for (int j = 0; j < 4; j++) if (g.v[j] >= first_tmp) g.v[j] += tmp_shift[piece];
+        return g;
+    }
     std::vector<HFr> values;            // per variable id; empty when there is no witness
     std::vector<ConstraintStat> stats;  // per-constraint gate counts (plonk::analyse); skipped when collect_stats is false
     bool collect_stats = true;
@@ -87,7 +128,7 @@ struct Transpiled {
 
 struct plk_circuit {
     plk::R1cs r1cs;
-    std::vector<plk::HFr> witness;
+    plk::big_vector<plk::HFr> witness;
     bool has_witness = false;
     mutable bool witness_registered = false;   // page-locked for fast upload (done lazily by plk_prove)
 };
@@ -97,12 +138,12 @@ namespace plk {
 // parsers: return false and set_error() on malformed input
 bool parse_r1cs_bin(const uint8_t *data, size_t len, R1cs *out);
 bool parse_r1cs_json(const uint8_t *data, size_t len, R1cs *out);
-bool parse_wtns_bin(const uint8_t *data, size_t len, std::vector<HFr> *out);
-bool parse_witness_json(const uint8_t *data, size_t len, std::vector<HFr> *out);
+bool parse_wtns_bin(const uint8_t *data, size_t len, big_vector<HFr> *out);
+bool parse_witness_json(const uint8_t *data, size_t len, big_vector<HFr> *out);
 bool fr_from_decimal(const std::string &s, HFr *out);
 
 // transpile; `witness` may be null.  Returns false (set_error) on an unsatisfiable constant constraint.
-bool transpile(const R1cs &r, const std::vector<HFr> *witness, Transpiled *out);
+bool transpile(const R1cs &r, const big_vector<HFr> *witness, Transpiled *out);
 std::string analyse_json(const R1cs &r, const Transpiled &t);
 
 }  // namespace plk

@@ -262,13 +262,27 @@ static int run(int argc, char **argv) {
     } else if (cmd == "export-verification-key") {                   // src/bin/main.rs:484-504
         Args a = parse(argc, argv, {{"m", "srs_monomial_form"}, {"c", "circuit"}, {"v", "vk"}});
         const Ranks rk = ranks_from_env();
-        plk_circuit *c = load_circuit(resolve_circuit(a), nullptr);
-        plk_ctx *ctx = open_ctx(rk);
         uint8_t g2[256];
+        plk_ctx *ctx = nullptr;
         plk_setup *s = nullptr;
-        CK("prepare err", plk_setup_prepare(ctx, c, &s));
-        join_ranks(ctx, rk, plk_setup_domain_size(s));
-        load_key(ctx, a.get("srs_monomial_form"), g2, false, rk, plk_setup_domain_size(s));
+        plk_circuit *c = nullptr;
+        if (rk.world == 1 && rk.comm.empty()) {                      // as in `prove`: the GPU comes up while the circuit is parsed and transpiled
+            std::thread gpu([&] {
+                ctx = open_ctx(rk);
+                load_key(ctx, a.get("srs_monomial_form"), g2);
+                CK("srs precompute", plk_srs_precompute(ctx));
+            });
+            c = load_circuit(resolve_circuit(a), nullptr);
+            CK("prepare err", plk_setup_prepare_host(c, &s));
+            gpu.join();
+            CK("prepare err", plk_setup_upload(ctx, s));
+        } else {
+            c = load_circuit(resolve_circuit(a), nullptr);
+            ctx = open_ctx(rk);
+            CK("prepare err", plk_setup_prepare(ctx, c, &s));
+            join_ranks(ctx, rk, plk_setup_domain_size(s));
+            load_key(ctx, a.get("srs_monomial_form"), g2, false, rk, plk_setup_domain_size(s));
+        }
         std::vector<uint8_t> buf(4096); uint64_t len = 0;
         CK("make_verification_key", plk_setup_write_vk(ctx, s, g2, buf.data(), buf.size(), &len));
         std::string out = a.get("vk", "vk.bin");

@@ -242,6 +242,11 @@ int32_t plk_comm_init_tcp(plk_ctx *ctx, int32_t rank, int32_t world, uint16_t po
     return plk_set_commit_shard(ctx, first_index, builtin_combine, C);
 }
 
+int32_t plk_comm_set_shard(plk_ctx *ctx, uint64_t first_index) {
+    if (!ctx || !ctx->comm) { set_error("plk_comm_set_shard: no communicator on this context (plk_comm_init)"); return PLK_ERR_ARG; }
+    return plk_set_commit_shard(ctx, first_index, builtin_combine, ctx->comm);
+}
+
 int32_t plk_comm_destroy(plk_ctx *ctx) {
     if (!ctx) { set_error("plk_comm_destroy: null ctx"); return PLK_ERR_ARG; }
     comm_release(ctx);

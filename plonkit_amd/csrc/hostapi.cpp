@@ -59,7 +59,7 @@ void keccak256(const uint8_t *in, size_t len, uint8_t out[32]) {
         in += rate; len -= rate;
     }
     uint8_t last[136] = {0};
-    memcpy(last, in, len);
+    if (len) memcpy(last, in, len);                     // (in may be null for an empty message)
     last[len] ^= 0x01;            // Ethereum keccak padding, not SHA3's 0x06
     last[rate - 1] ^= 0x80;
     for (size_t i = 0; i < rate / 8; i++) { uint64_t w; memcpy(&w, last + 8 * i, 8); st[i] ^= w; }

@@ -868,6 +868,19 @@ int32_t plk_msm_g1_finish(plk_ctx *ctx, plk_g1_jacobian *out) {
     return PLK_OK;
 }
 
+// finish + the context's combiner (plk_comm_init / plk_set_commit_shard): the commitment over ALL ranks' shards, affine.
+// The exchange of commitment k runs while the kernels of commitment k + 1 (enqueued before this call) occupy the GPU.
+int32_t plk_msm_g1_finish_sharded(plk_ctx *ctx, plk_g1_affine *out) {
+    if (!ctx || !out) { set_error("plk_msm_g1_finish_sharded: bad argument"); return PLK_ERR_ARG; }
+    plk_g1_jacobian j;
+    PLK_TRY(plk_msm_g1_finish(ctx, &j));
+    if (ctx->combine) {
+        const int32_t rc = ctx->combine(ctx->combine_user, &j, 1);
+        if (rc != PLK_OK) { set_error("commitment combiner failed"); return rc; }
+    }
+    return plk_g1_sum_jacobian(&j, 1, out);
+}
+
 int32_t plk_msm_g1_partial_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, plk_g1_jacobian *out, void *stream) {
     constexpr uint64_t PIECE = 1ull << 24;                    // one pass of the kernels takes at most 2^24 terms
     if (n <= PIECE) {

@@ -179,8 +179,8 @@ struct plk_setup {
     bool ops_independent = false;          // no temporary reads another temporary -> order-free evaluation
     plk::DevBuf ops_dev, terms_dev;        // the same records on the device (only when ops_independent): evaluated there
     std::vector<plk::WitnessTerm> op_terms;
-    std::vector<plk::HFr> h_cols;          // host phase only: 7 selector columns x N, until plk_setup_upload
-    std::vector<uint32_t> h_vars;          // host phase only: 4 variable-index columns x N
+    plk::big_vector<plk::HFr> h_cols;      // host phase only: 7 selector columns x N, until plk_setup_upload
+    plk::big_vector<uint32_t> h_vars;      // host phase only: 4 variable-index columns x N
 };
 
 using namespace plk;
@@ -209,8 +209,8 @@ static int32_t setup_host_impl(const plk_circuit *c, plk_setup **out) {
     mark("transpile");
     std::unique_ptr<plk_setup> S(new plk_setup());
     S->num_inputs = c->r1cs.num_inputs - 1;
-    S->num_gates = T.gates.size();
-    S->n_real = S->num_inputs + T.gates.size();
+    S->num_gates = T.num_gates;
+    S->n_real = S->num_inputs + T.num_gates;
     S->num_vars = T.num_vars;
     uint64_t N = 1; uint32_t log_n = 0;
     while (N < S->n_real + 1) { N <<= 1; log_n++; }
@@ -220,31 +220,34 @@ static int32_t setup_host_impl(const plk_circuit *c, plk_setup **out) {
     S->ops.swap(T.ops); S->op_terms.swap(T.op_terms);
     S->ops_independent = true;
     for (const WitnessTerm &t : S->op_terms) if (t.var >= c->r1cs.num_variables) { S->ops_independent = false; break; }
-    // rows of the trace: one gate per public input first (q_a = -1), then the transpiler's gates — viewed in place
-    std::vector<Gate> input_rows;
-    for (uint64_t i = 1; i <= S->num_inputs; i++) {
-        Gate g; g.v[0] = (uint32_t)i; g.v[1] = g.v[2] = g.v[3] = 0;
-        for (int k = 0; k < 7; k++) g.q[k] = HFr::zero();
-        g.q[0] = -HFr::one();
-        input_rows.push_back(g);
-    }
-    const size_t n_in = input_rows.size(), n_rows = n_in + T.gates.size();
-    auto row = [&](uint64_t r) -> const Gate & { return r < n_in ? input_rows[r] : T.gates[r - n_in]; };
-    // ONE pass over the gate records on all host threads fills the seven selector columns and the four variable-index
-    // columns (rows 0 .. n_real - 1, zero / dummy beyond)
+    // rows of the trace: one gate per public input first (q_a = -1), then the transpiler's gates, then padding with the dummy
+    // variable.  The gate pieces are read once, piece-parallel, straight into the seven selector columns and the four
+    // variable-index columns.
+    const size_t n_in = S->num_inputs, n_rows = n_in + T.num_gates;
     S->h_cols.resize((size_t)7 * N);
     S->h_vars.resize((size_t)4 * N);
     HFr *cols = S->h_cols.data(); uint32_t *vars = S->h_vars.data();
-    parallel_for(N, 1 << 15, [&](size_t lo, size_t hi) {
-        for (size_t r = lo; r < hi; r++) {
-            if (r < n_rows) {
-                const Gate &g = row(r);
+    const HFr minus_one = -HFr::one();
+    for (size_t r = 0; r < n_in; r++) {
+        for (int k = 0; k < 7; k++) cols[(size_t)k * N + r] = k == 0 ? minus_one : HFr::zero();
+        vars[r] = (uint32_t)(r + 1); vars[N + r] = vars[2 * N + r] = vars[3 * N + r] = 0;
+    }
+    parallel_for(T.pieces.size(), 1, [&](size_t lo, size_t hi) {
+        for (size_t p = lo; p < hi; p++) {
+            const big_vector<Gate> &gs = T.pieces[p];
+            const uint32_t shift = T.tmp_shift[p], first_tmp = (uint32_t)T.first_tmp;
+            size_t r = n_in + T.gate0[p];
+            for (size_t i = 0; i < gs.size(); i++, r++) {
+                const Gate &g = gs[i];
                 for (int k = 0; k < 7; k++) cols[(size_t)k * N + r] = g.q[k];
-                for (int j = 0; j < 4; j++) vars[(size_t)j * N + r] = g.v[j];
-            } else {
-                for (int k = 0; k < 7; k++) cols[(size_t)k * N + r] = HFr::zero();
-                for (int j = 0; j < 4; j++) vars[(size_t)j * N + r] = 0;
+                for (int j = 0; j < 4; j++) vars[(size_t)j * N + r] = g.v[j] >= first_tmp ? g.v[j] + shift : g.v[j];
             }
+        }
+    });
+    parallel_for(N - n_rows, 1 << 15, [&](size_t lo, size_t hi) {
+        for (size_t r = n_rows + lo; r < n_rows + hi; r++) {
+            for (int k = 0; k < 7; k++) cols[(size_t)k * N + r] = HFr::zero();
+            for (int j = 0; j < 4; j++) vars[(size_t)j * N + r] = 0;
         }
     });
     mark("columns (host fill)");
@@ -289,8 +292,8 @@ static int32_t setup_upload_impl(plk_ctx *ctx, plk_setup *S) {
         if ((rc = ntt_dev(ctx, S->sel_coef[k], log_n, true, nullptr, st)) != PLK_OK) return fail(rc);
     }
     if (hipStreamSynchronize(st) != hipSuccess) return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
-    std::vector<HFr>().swap(S->h_cols);                          // the host columns go away here
-    std::vector<uint32_t>().swap(S->h_vars);
+    big_vector<HFr>().swap(S->h_cols);                           // the host columns go away here
+    big_vector<uint32_t>().swap(S->h_vars);
     mark("selectors (upload + 7 iNTT)");
     // the permutation (rotate-left over each variable's occurrences) from the variable-index table, on the device (perm.hip)
     {

@@ -34,13 +34,19 @@ def combine_partials(partial, dist=None, device=None):
 class ShardedMsm:
     """commit(scalars) = sum over ranks of MSM(local scalars, local SRS shard)."""
 
-    def __init__(self, ctx, dist=None, device=None):
-        self.ctx, self.dist, self.device = ctx, dist, device
+    def __init__(self, ctx, dist=None, device=None, native=False):
+        """native=True: the context carries the library's own communicator (Context.comm_init: RCCL all-gather + EC sum in
+        C++, one stream synchronisation per commitment) — no torch.distributed call, no Python in the exchange"""
+        self.ctx, self.dist, self.device, self.native = ctx, dist, device, native
+
+    def _finish(self):
+        if self.native:
+            return self.ctx.msm_finish_sharded()
+        return combine_partials(self.ctx.msm_finish(), self.dist, self.device)
 
     def commit(self, scalars_dev, n, base_offset=0, stream=None):
         self.ctx.msm_enqueue_dev(scalars_dev, n, base_offset, stream=stream)
-        partial = self.ctx.msm_finish()
-        return combine_partials(partial, self.dist, self.device)
+        return self._finish()
 
     def commit_stream(self, batches, n, base_offset=0, stream=None):
         """Generator over a sequence of scalar vectors.  The library keeps two commitments in flight (two scratch
@@ -56,8 +62,7 @@ class ShardedMsm:
             cur = next(it, None)
             if cur is not None:                                # two commitments in flight: k+1 is accumulating while
                 self.ctx.msm_enqueue_dev(cur, n, base_offset, stream=stream)   # k reduces its buckets and is exchanged
-            partial = self.ctx.msm_finish()                    # waits for commitment k, host Horner over the windows
-            yield combine_partials(partial, self.dist, self.device)
+            yield self._finish()                               # waits for commitment k, host Horner over the windows, exchange
 
 
 # Montgomery form of 1 in Fq (R mod q): the Z coordinate of an affine point written back as Jacobian
