@@ -130,7 +130,8 @@ struct plk_circuit {
     plk::R1cs r1cs;
     plk::big_vector<plk::HFr> witness;
     bool has_witness = false;
-    mutable bool witness_registered = false;   // page-locked for fast upload (done lazily by plk_prove)
+    mutable bool witness_registered = false;   // page-locked for fast upload (done by plk_prove from the second proof on)
+    mutable uint32_t proofs_started = 0;
 };
 
 namespace plk {

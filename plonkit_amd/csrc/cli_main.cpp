@@ -373,6 +373,11 @@ static int run(int argc, char **argv) {
         spit(ij, reinterpret_cast<const uint8_t *>(is.data()), is.size());
         fprintf(stderr, "Public input json saved to %s\n", ij.c_str());
         phase("files written");
+        if (getenv("PLK_CLI_FREE")) {                                // (measurement knob: what the exit would otherwise pay for)
+            plk_circuit_free(c); phase("free: circuit (unregister)");
+            plk_setup_free(s); phase("free: setup");
+            plk_destroy(ctx); phase("free: context");
+        }
     } else if (cmd == "verify") {                                    // src/bin/main.rs:425-437 (no GPU involved)
         // VerifyOpts (src/bin/main.rs:125-137): the key is `-v` / `--verification_key` here, while export-verification-key
         // names its output `--vk` (src/bin/main.rs:186-187); `--vk` is kept as an alias on verify

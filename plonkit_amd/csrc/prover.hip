@@ -389,7 +389,11 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     // circom wires are uploaded straight from the (page-locked) witness buffer; only the temporaries are
     // computed here, into a pinned staging area.  id 0 (dummy) is zeroed on the device.
     const uint64_t ncv = S->num_circuit_vars, n_tmp = S->num_vars - ncv;
-    if (!c->witness_registered) {
+    // page-locking the witness (hipHostRegister) makes its upload 2 ms faster at 2^20 but costs ~50 ms once, plus the
+    // un-pinning when the process ends: worth it from the second proof of the same circuit object on, not for the
+    // one-proof-per-process pattern of the CLI (profiles/r02_cli_scale.txt: 0.36 -> 0.29 s whole `plonkit prove`)
+    static const int reg_mode = [] { const char *e = getenv("PLK_HOST_REGISTER"); return !e ? 1 : (!strcmp(e, "always") ? 0 : (!strcmp(e, "never") ? 1 << 30 : 1)); }();
+    if (!c->witness_registered && (int)(c->proofs_started++) >= reg_mode) {
         if (hipHostRegister((void *)c->witness.data(), c->witness.size() * sizeof(HFr), hipHostRegisterDefault) == hipSuccess) c->witness_registered = true;
         else (void)hipGetLastError();                                        // not fatal: the copy is just slower
     }
