@@ -345,8 +345,8 @@ static uint32_t meta_per_task(uint32_t fb) { return (1u << fb) + 2; }
 // Only mixed additions happen here (10 products each, ~25 KB of code).  One wave per SIMD already saturates the
 // VALU (tools/ubench_w: 15 G mixed-adds/s at any occupancy, 25 % less when squeezed into 128 VGPRs with
 // spills), so the register budget is the full 256 and nothing is spilled.  Kernel B folds the partial sums.
-template <uint32_t FB>
-__global__ void __launch_bounds__(MSM_THREADS, 2) msm_accumulate(const G1Affine *bases, const uint32_t *entries,
+template <uint32_t FB, int MINW = 2>
+__global__ void __launch_bounds__(MSM_THREADS, MINW) msm_accumulate(const G1Affine *bases, const uint32_t *entries,
                                                                   const uint32_t *bin_start, const uint32_t *task_start,
                                                                   XyzzW *partials, uint32_t *task_meta, MsmParams p) {
     constexpr uint32_t FINE = Shape<FB>::FINE, SLOT_PRIMARY = Shape<FB>::SLOT_PRIMARY, SLOT_HEAD = Shape<FB>::SLOT_HEAD,
@@ -760,6 +760,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_partition<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<6>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<7>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<6, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
         attr_set = true;
     }
     hipLaunchKernelGGL(msm_partition<false>, dim3(pblocks, total_windows), dim3(PART_THREADS), plds_count, stream, (const int32_t *)digits, p, hist, (const uint32_t *)nullptr, (uint32_t *)nullptr);
@@ -769,6 +770,12 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     const uint32_t rblocks = (max_tasks * RL + MSM_THREADS - 1) / MSM_THREADS;
     auto launch_shape = [&](auto fb_tag) {
         constexpr uint32_t FB = decltype(fb_tag)::value;
+        // PLK_MSM_ONE_WAVE=1 (measurement knob): the same kernel compiled for one wave per SIMD (512 registers, no spill)
+        static const bool one_wave = getenv("PLK_MSM_ONE_WAVE") != nullptr;
+        if (one_wave && FB == 6)
+            hipLaunchKernelGGL((msm_accumulate<6, 1>), dim3(max_tasks), dim3(MSM_THREADS), CHUNK * sizeof(uint32_t), stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
+                               (const uint32_t *)task_start, partials, task_meta, p);
+        else
         hipLaunchKernelGGL(msm_accumulate<FB>, dim3(max_tasks), dim3(MSM_THREADS), CHUNK * sizeof(uint32_t), stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
                            (const uint32_t *)task_start, partials, task_meta, p);
         if (ctx->ev_on) (void)hipEventRecord(S.ev[1], stream);
