@@ -62,6 +62,11 @@ VALU_PEAK_GMADD = MAD_RATE_TLANE_S * 1e3 / MADS_PER_MIXED_ADD
 LOOP_ISOLATED_GMADD = 15.6
 
 
+def red_device(device):
+    """where the timing reductions live: the GPU over RCCL, the host when torch.distributed runs over gloo (shared-device test)"""
+    return torch.device("cpu") if os.environ.get("PLK_BENCH_SHARE_DEVICE") else device
+
+
 def rand_scalars(n, seed, device):
     """uniform 252-bit residues (valid Montgomery Fr representatives), generated on the GPU"""
     g = torch.Generator(device=device)
@@ -212,7 +217,7 @@ def sharded_prove(ctx, dist, device, log_n, rank, world):
         p = setup.prove(circ)
         dt = time.perf_counter() - t0
         assert p == proof
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_device(device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         best = float(t.item()) if best is None else min(best, float(t.item()))
     setup.close(); circ.close()
@@ -242,14 +247,14 @@ def strong_scaling_msm(ctx, dist, device, rank, world, log_total=24, reps=5):
         pass
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    t = torch.tensor([dt], dtype=torch.float64, device=red_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     sharded_ms = float(t.item()) / reps * 1e3
     # latency of a single sharded commitment (nothing else in flight)
     torch.cuda.synchronize(); dist.barrier()
     t0 = time.perf_counter()
     msm.commit(scal, local, stream=stream)
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     single_ms = float(t.item()) * 1e3
     one_gpu_ms = None
@@ -300,6 +305,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the per-GPU commitment size")
     ap.add_argument("--cpu-log-n", type=int, default=20, help="log2 of the CPU-baseline samples (MSM terms, prove domain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong-log-n", type=int, default=24, help="N > 1: log2 of the ONE commitment whose SRS is split over the ranks (configs[2]: 24)")
     ap.add_argument("--pipeline-depth", type=int, default=2, choices=(1, 2),
                     help="commitments in flight in the timed region (2 = the library's two-slot FIFO; 1 = one at a time: "
                          "the region roofline.kernel_ms is taken from)")
@@ -313,6 +319,12 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    # PLK_BENCH_SHARE_DEVICE=1 (test tier with ONE GPU): every rank uses device 0, torch.distributed runs over gloo and the
+    # partial sums travel over the library's TCP transport, because RCCL refuses two ranks on one device.  It exercises the
+    # N > 1 control flow (slicing, strong-scaling leg, sharded prove); its timings mean nothing.
+    share = bool(os.environ.get("PLK_BENCH_SHARE_DEVICE"))
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -322,7 +334,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         # a rank that fails must not leave the others waiting for the default 10 minutes in a collective
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=180))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=180))
 
     import plonkit_amd as pa
     from plonkit_amd.sharded import ShardedMsm
@@ -337,9 +352,12 @@ def main():
     if multi:
         # the exchange of the partial sums runs inside the library (comm.cpp: ncclAllGather on the context's stream + host
         # EC sum); torch.distributed only carries the 128-byte RCCL id to the other ranks and the timing barriers
-        box = [pa.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        ctx.comm_init(rank, world, box[0], rank * n)
+        if share:
+            ctx.comm_init_tcp(rank, world, int(os.environ.get("MASTER_PORT", "29500")) + 17, rank * n)
+        else:
+            box = [pa.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.comm_init(rank, world, box[0], rank * n)
     msm = ShardedMsm(ctx, dist if multi else None, device, native=multi)
     ctx.set_kernel_timing(True)
 
@@ -357,7 +375,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device(device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # the dominant kernel alone: one commitment in flight, so nothing shares the GPU with msm_accumulate
@@ -425,7 +443,7 @@ def main():
         # sliced across the ranks, commitments combined over RCCL, NTTs replicated.  Every rank takes part;
         # a failure here must not cost the headline line.
         try:
-            strong = strong_scaling_msm(ctx, dist, device, rank, world)
+            strong = strong_scaling_msm(ctx, dist, device, rank, world, log_total=args.strong_log_n)
         except Exception as exc:                                   # noqa: BLE001
             strong = {"error": repr(exc)}
         try:

@@ -169,3 +169,26 @@ def test_two_ranks_with_the_builtin_combiner():
     for rank, vk, proof, info in res:
         assert (vk, proof) == want, rank
         assert info == (rank, world, 6)
+
+
+def test_bench_n2_control_flow_on_one_gpu():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), with both ranks on this
+    box's single GPU (PLK_BENCH_SHARE_DEVICE: gloo + the TCP transport instead of RCCL): the weak-scaling headline, the
+    strong-scaling leg (one commitment, SRS split over the ranks, next to the same commitment on rank 0 alone) and the sharded
+    prove all complete and the line has the fields the driver and DESIGN.md §5 name.  Timings are meaningless here."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PLK_BENCH_SHARE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--log-n", "16", "--strong-log-n", "18"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["steps"] == 4
+    assert line["roofline"]["kernel_ms"] > 0 and "cpu_baseline" not in line
+    st = line["strong"]
+    assert "error" not in st and st["terms_total"] == 1 << 18 and st["terms_per_gpu"] == 1 << 17 and st["scaling_vs_1gpu"] > 0
+    assert "error" not in line["prove"] and line["prove"]["n_gpus"] == 2 and line["prove"]["proof_bytes"] == 1144
