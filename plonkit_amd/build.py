@@ -28,7 +28,7 @@ def _headers_digest():
     h = hashlib.sha1()
     for root in (CSRC, os.path.join(HERE, "..", "include")):
         for f in sorted(os.listdir(root)):
-            if f.endswith((".h", ".cuh")):
+            if f.endswith(".h"):
                 h.update(open(os.path.join(root, f), "rb").read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()[:16]

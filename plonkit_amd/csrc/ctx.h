@@ -8,7 +8,7 @@
 #include <vector>
 #include <map>
 #include "../../include/plonkit_amd.h"
-#include "field.cuh"
+#include "field_dev.h"
 #include "hostmath.h"
 
 namespace plk {
@@ -57,7 +57,7 @@ struct plk_ctx {
     // NTT tables (device): omega_{2^28} powers forward / inverse, coset generator 7 and 7^-1
     plk::DevBuf tables;
     plk::PowTable tw_fwd, tw_inv;            // omega_{2^28}^{+-e}, external Montgomery form (R = 2^256)
-    plk::PowTable tw_fwd_w, tw_inv_w;        // the same powers in the 2^261 domain of field29.cuh (NTT passes)
+    plk::PowTable tw_fwd_w, tw_inv_w;        // the same powers in the 2^261 domain of field29_dev.h (NTT passes)
     std::map<std::vector<uint32_t>, plk::PowTable> coset_tabs;   // keyed by the 8 limbs of the shift
     std::vector<void *> coset_allocs;
     std::map<std::vector<uint32_t>, plk::Fr> inv_cache;
@@ -68,7 +68,7 @@ struct plk_ctx {
     const void *srs = nullptr;               // device, Montgomery affine, 64 B per point
     uint64_t srs_n = 0;
     plk::DevBuf srs_own;
-    plk::DevBuf srs_w;                       // the same points in the 2^261 Montgomery domain of field29.cuh (MSM gathers)
+    plk::DevBuf srs_w;                       // the same points in the 2^261 Montgomery domain of field29_dev.h (MSM gathers)
     bool srs_w_valid = false;
     uint32_t srs_w_copies = 0;               // shifted copies 2^(16k) * P held in srs_w (fixed-base table of the MSM)
     // optional second key: Crs<E, CrsForLagrangeForm> (L_i(tau)*G), used by plk_prove for commit_using_values

@@ -1,5 +1,5 @@
-// G1 arithmetic over the 9 x 29-bit lazy field layer (field29.cuh) — the MSM's inner loops.
-// Same formulas as ec.cuh (XYZZ coordinates: madd-2008-s, add-2008-s, dbl-2008-s-1), but every
+// G1 arithmetic over the 9 x 29-bit lazy field layer (field29_dev.h) — the MSM's inner loops.
+// Same formulas as ec_dev.h (XYZZ coordinates: madd-2008-s, add-2008-s, dbl-2008-s-1), but every
 // subtraction is a limb-wise "a - b + k*p" and nothing is conditionally reduced.  Invariants
 // (values as multiples of p; all limbs normalised):
 //     affine input       x, y      < 1.1 p     (resident SRS: canonical, 2^261 domain)
@@ -10,8 +10,8 @@
 //   add :  U,S < 1.05  P,R < 3.05  PP < 1.06  X3 < 5.06  Y3 < 3.2
 //   dbl :  U = 2Y < 12  V < 1.85  W < 1.14  S < 1.07  M = 3X^2 < 3.7  X3 < 5.1  Y3 < 3.2
 #pragma once
-#include "field29.cuh"
-#include "ec.cuh"
+#include "field29_dev.h"
+#include "ec_dev.h"
 
 namespace plk {
 

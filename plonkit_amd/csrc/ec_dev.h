@@ -7,7 +7,7 @@
 // same ~130 v_mad_u64_u32 on gfx950 the count of products is what matters.  Infinity: ZZ == 0.
 // Affine points: (x, y) Montgomery, infinity encoded as x == y == 0 (as in the C ABI).
 #pragma once
-#include "field.cuh"
+#include "field_dev.h"
 
 namespace plk {
 

@@ -2,7 +2,7 @@
 //
 // Why: on gfx950 every carry-producing VALU op (v_add_co/v_addc, 64-bit adds) costs the same
 // ~4.2 cycles per wave as a v_mad_u64_u32, while plain v_add_u32/v_and/v_lshr cost ~2.25
-// (profiles/r01_ubench_int2.txt).  The 8 x 32-bit CIOS product of field.cuh spends 128 mads + 130
+// (profiles/r01_ubench_int2.txt).  The 8 x 32-bit CIOS product of field_dev.h spends 128 mads + 130
 // 64-bit adds + 275 moves per product (~1600 cycles per wave).  With 29-bit limbs a column of
 // 18 partial products fits a 64-bit accumulator without any carry handling: 162 mads + a short
 // normalisation (~900 cycles), and additions/subtractions become 9 plain 32-bit ops.
@@ -17,7 +17,7 @@
 // domain; the MSM keeps its resident SRS and its accumulators in the 2^261 domain and converts
 // at the boundary.  No MFMA: these are 29x29->58-bit integer multiply-adds on the VALU.
 #pragma once
-#include "field.cuh"
+#include "field_dev.h"
 
 namespace plk {
 

@@ -12,8 +12,8 @@
 // all lanes add at the same 85 positions: 255 doublings + 85 additions per multiplication (3500 products instead of
 // 5800 at wave level); the window table {1,2,3,4}*B of every lane lives in LDS, limb-major (conflict-free).
 #include "ctx.h"
-#include "ec.cuh"
-#include "ec29.cuh"
+#include "ec_dev.h"
+#include "ec29_dev.h"
 #include "ntt.h"
 
 namespace plk {
@@ -75,7 +75,7 @@ __device__ __forceinline__ XyzzW g1_mul_scalar(const XyzzW &b, const Fr &k, uint
         XyzzW t = xyzzw_identity();
         if (mag) {
             t = lds_get(tab, (int)mag - 1);
-            if (code & 8u) t.y = sub6(w_zero<FqW>(), t.y);         // 6p - y: y < 6p by the bounds of ec29.cuh
+            if (code & 8u) t.y = sub6(w_zero<FqW>(), t.y);         // 6p - y: y < 6p by the bounds of ec29_dev.h
         }
         xyzzw_add(acc, t);                                        // the one inlined addition site (identity operand: no-op)
     }

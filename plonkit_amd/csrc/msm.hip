@@ -16,7 +16,7 @@
 //     of <= 16384 entries; a workgroup counting-sorts its task inside LDS and cuts the sorted run into 256 EQUAL
 //     pieces, one per lane: one flat loop of mixed additions with XYZZ accumulators in registers, a bucket boundary
 //     inside a piece only flushes the accumulator (PRIMARY / HEAD / TAIL slots).  Points are gathered as 64-byte
-//     affine records.  All field arithmetic is the carry-free 9x29-bit layer (field29.cuh / ec29.cuh).
+//     affine records.  All field arithmetic is the carry-free 9x29-bit layer (field29_dev.h / ec29_dev.h).
 //   * a bucket spread over many lanes (repeated scalars: all-ones, all -1) is folded by a separate small kernel.
 //   * per task T = sum B_f and S = sum (f+1) B_f (running sums + 32-lane shuffle scan), then per bucket set
 //     sum_t S_t and sum_c c * D_c; the remaining shifts (2^7, 2^8) and the Horner over the sets run on the host,
@@ -28,8 +28,8 @@
 // No MFMA (256-bit modular integers), bound by v_mad_u64_u32 issue; HBM sees the algorithmic 96 B/term plus the
 // per-window gathers (64 B x W per term) from the table.
 #include "ctx.h"
-#include "ec.cuh"
-#include "ec29.cuh"
+#include "ec_dev.h"
+#include "ec29_dev.h"
 #include "msm.h"
 #include "hostmath.h"
 #include <cstring>
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(1024) msm_scan_bins(uint32_t *hist, uint32_t *
 }
 
 // --------------------------------------------------------------------- bucket accumulation
-// All group arithmetic below runs on the 9 x 29-bit lazy field layer (ec29.cuh); the resident SRS
+// All group arithmetic below runs on the 9 x 29-bit lazy field layer (ec29_dev.h); the resident SRS
 // copy it gathers from is kept in that layer's 2^261 Montgomery domain (srs_to_w_kernel).
 __device__ __forceinline__ XyzzW shfl_xor_w(const XyzzW &v, int mask) {
     XyzzW r;

@@ -16,7 +16,7 @@
 //   * Every pass is DIT.  Passes 1..p-1 fetch their rows in bit-reversed order (a row is its own memory segment,
 //     so the order is free); the last pass reads contiguous rows, bit-reverses them with its LDS scatter and
 //     writes whole C-element segments to the digit-reversed output index.
-//   * All butterfly arithmetic is the carry-free 9 x 29-bit lazy layer (field29.cuh): data words are re-sliced,
+//   * All butterfly arithmetic is the carry-free 9 x 29-bit lazy layer (field29_dev.h): data words are re-sliced,
 //     never converted; only the constants (twiddles, coset powers, 1/n) live in its 2^261 domain.
 //   * coset shift (g^i on load), 1/n and g^-i (on store) are fused into the first / last pass; powers come
 //     from two-level tables (base^(lo + 2^14*hi)), one multiply per use — none when the low part is zero
@@ -27,7 +27,7 @@
 #include "ctx.h"
 #include "ntt.h"
 #include "poly.h"
-#include "field29.cuh"
+#include "field29_dev.h"
 
 namespace plk {
 
@@ -48,7 +48,7 @@ struct NttPassArgs {
     uint32_t nonzero;                          // first pass: input elements at index >= nonzero are zero and are
 };                                             // neither read nor scaled (zero-padded LDE); 0 = the whole vector
 
-// ---- all butterfly arithmetic runs on the carry-free 9 x 29-bit layer (field29.cuh): data words are
+// ---- all butterfly arithmetic runs on the carry-free 9 x 29-bit layer (field29_dev.h): data words are
 // ---- re-sliced, never converted; the constants (twiddles, coset powers, 1/n) live in its 2^261 domain.
 __device__ __forceinline__ FrW9 ldw(const Fr *p) { return unpack<FrW>(load_fp(p)); }
 
@@ -114,7 +114,7 @@ __device__ __forceinline__ void r4_load(Radix4Group &q, const LdsTile &L, const 
     q.t3 = small_tw(tw, (jl + h) << (log_r - s - 2), log_r);
 }
 
-// Lazy normalisation: mulw takes a left operand with limbs up to 3.28e9 (field29.cuh, MULW_A_LIMB_MAX), so the sums and
+// Lazy normalisation: mulw takes a left operand with limbs up to 3.28e9 (field29_dev.h, MULW_A_LIMB_MAX), so the sums and
 // differences that only feed a product, or another sum, are left as raw limb-wise results; one carry propagation per
 // OUTPUT (4 per group instead of 10).  Limb bounds (normalised = < 2^29 = 0.54e9; PAD2/PAD4 limbs < 2.68e9):
 //     x2 + PAD2 - y3 < 3.22e9 (product operand)      x0 + PAD4 - y1 - b3 < 3.22e9      everything else smaller.
@@ -255,7 +255,7 @@ Fr ntt_omega(uint32_t log_n) {
     return w;
 }
 
-// the same table with every entry moved into the 2^261 domain of field29.cuh (x*2^256 -> x*2^261)
+// the same table with every entry moved into the 2^261 domain of field29_dev.h (x*2^256 -> x*2^261)
 __global__ void table_to_w(Fr *out, const Fr *in, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) store_fp(out + i, pack<FrParams>(csub_p(w_from_s(unpack<FrW>(load_fp(in + i))))));

@@ -17,7 +17,7 @@ struct CheckArgs {
     uint32_t *flag;
 };
 
-// The quotient kernel computes on the 9 x 29-bit layer (field29.cuh), whose product is a*b*2^-261 while vectors in
+// The quotient kernel computes on the 9 x 29-bit layer (field29_dev.h), whose product is a*b*2^-261 while vectors in
 // HBM carry the factor 2^256.  Instead of converting anything per proof, the constant vectors cached in plk_setup
 // are stored pre-scaled (2^261: q_a..q_d, q_dnext, sigma_j, L0, the coset points x; 2^266: q_m, which meets a
 // product of two wires) and the host scales the challenges, so that every term lands on 2^256 by itself:

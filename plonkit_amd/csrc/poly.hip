@@ -6,7 +6,7 @@
 // point) with a handful of modular multiplies per point.
 #include "ctx.h"
 #include "poly.h"
-#include "field29.cuh"
+#include "field29_dev.h"
 
 namespace plk {
 

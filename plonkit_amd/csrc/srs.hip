@@ -4,7 +4,7 @@
 // scalar multiplications.  Each lane owns a run of consecutive powers: one double-and-add to reach
 // tau^(start) * G, then "multiply by tau" steps, each converted to affine with one Fermat inversion.
 #include "ctx.h"
-#include "ec.cuh"
+#include "ec_dev.h"
 
 namespace plk {
 
