@@ -1,7 +1,7 @@
-// Host-side check of the 9 x 29-bit lazy field layer and its group law (field29.cuh / ec29.cuh: the PLK_HD functions
-// compile for the host too) against the 8 x 32-bit layer (field.cuh / ec.cuh), which the GPU tests pin to the oracle.
+// Host-side check of the 9 x 29-bit lazy field layer and its group law (field29_dev.h / ec29_dev.h: the PLK_HD functions
+// compile for the host too) against the 8 x 32-bit layer (field_dev.h / ec_dev.h), which the GPU tests pin to the oracle.
 // Built and run by tests/test_field29_host.py with hipcc; needs no GPU.
-#include "ec29.cuh"
+#include "ec29_dev.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -85,7 +85,7 @@ int main() {
         }
     }
     printf("field29: %d mismatches\n", bad);
-    // EC: random chain of mixed adds, doubles and full adds against ec.cuh
+    // EC: random chain of mixed adds, doubles and full adds against ec_dev.h
     G1Affine g; g.x = from_u64<FqParams>(1); g.y = from_u64<FqParams>(2);
     G1Xyzz acc = xyzz_identity(); XyzzW accw = xyzzw_identity();
     G1Affine pts[8]; AffW ptsw[8];

@@ -1,4 +1,4 @@
-"""The lazy 9 x 29-bit field layer and the XYZZ group law built on it (plonkit_amd/csrc/field29.cuh, ec29.cuh) compiled
+"""The lazy 9 x 29-bit field layer and the XYZZ group law built on it (plonkit_amd/csrc/field29_dev.h, ec29_dev.h) compiled
 for the HOST and compared with the 8 x 32-bit layer on random inputs: products, squarings, fused sums, lazy add/sub
 chains, zero tests, the quotient-estimate reduction, and a random walk of mixed additions / doublings / full additions
 including P + P and P - P.  No GPU involved (hipcc only compiles); the GPU suite pins both layers to the oracle."""

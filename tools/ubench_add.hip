@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "ec29.cuh"
+#include "ec29_dev.h"
 using namespace plk;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 __global__ void k_gen(XyzzW *pts, unsigned n) {   // valid points i*G in XYZZ (W domain) with non-trivial ZZ

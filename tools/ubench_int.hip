@@ -5,7 +5,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
-#include "../plonkit_amd/csrc/field.cuh"
+#include "../plonkit_amd/csrc/field_dev.h"
 using namespace plk;
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)

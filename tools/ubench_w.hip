@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../plonkit_amd/csrc/ec29.cuh"
+#include "../plonkit_amd/csrc/ec29_dev.h"
 using namespace plk;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 template <int CHAINS>
