@@ -106,6 +106,87 @@ def cpu_msm_baseline(ctx, log_sample, seed):
             "sample": "one dense_multiexp (c=ceil(ln n), per-thread buckets) of 2^%d uniform scalars, %.2f s" % (log_sample, dt)}, ref, s
 
 
+def cpu_msm_rows(ctx, device, log_n=20, big_log_n=24):
+    """the four scalar distributions of SURVEY.md §8(d) at 2^20 and uniform scalars at 2^24, the
+    oracle's dense_multiexp restatement (16 threads, its best setting) beside the HIP commitment on the same scalars and
+    bases; every pair of results must be the same group element."""
+    from oracle import oracle_lib as ol
+    n = 1 << log_n
+    keep = ctx.srs_size()
+    ctx.srs_generate(n, 0, 42)
+    bases = ctx.srs_download(0, n)
+    rng = np.random.default_rng(77)
+    uni = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    uni[:, 3] &= np.uint64((1 << 60) - 1)
+    one, minus_one = ol.fr_vec([1])[0], ol.fr_vec([ol.R_MOD - 1])[0]
+    small = ol.fr_vec(list(range(1 << 16)))
+    wl = uni.copy()
+    pick = rng.random(n)
+    wl[pick < 0.5] = 0
+    idx = np.nonzero((pick >= 0.5) & (pick < 0.75))[0]
+    wl[idx] = small[rng.integers(0, 1 << 16, size=idx.shape[0])]
+    cases = {"uniform": uni, "witness_like": wl, "all_ones": np.tile(one, (n, 1)), "all_r_minus_1": np.tile(minus_one, (n, 1))}
+    cores = min(os.cpu_count() or 1, 16)
+    out = {}
+    for name, sc in cases.items():
+        t0 = time.perf_counter()
+        ref = ol.msm(bases, sc, threads=cores)
+        cpu_ms = (time.perf_counter() - t0) * 1e3
+        d = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).to(device)
+        torch.cuda.synchronize()
+        got = ctx.msm_dev(d, n)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.msm_dev(d, n)
+        gpu_ms = (time.perf_counter() - t0) / 3 * 1e3
+        out["2^%d_%s" % (log_n, name)] = {"cpu_ms": round(cpu_ms, 1), "gpu_ms": round(gpu_ms, 3), "cores": cores, "same_point": bool(np.array_equal(got, ref))}
+    del bases
+    m = 1 << big_log_n
+    ctx.srs_generate(m, 0, 42)
+    bases = ctx.srs_download(0, m)
+    big = rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64)
+    big[:, 3] &= np.uint64((1 << 60) - 1)
+    t0 = time.perf_counter()
+    ref = ol.msm(bases, big, threads=cores)
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    d = torch.from_numpy(big.view(np.int64)).to(device)
+    torch.cuda.synchronize()
+    got = ctx.msm_dev(d, m)
+    t0 = time.perf_counter()
+    ctx.msm_dev(d, m)
+    gpu_ms = (time.perf_counter() - t0) * 1e3
+    out["2^%d_uniform" % big_log_n] = {"cpu_ms": round(cpu_ms, 1), "gpu_ms": round(gpu_ms, 3), "cores": cores, "same_point": bool(np.array_equal(got, ref))}
+    del bases, big, d
+    if keep:
+        ctx.srs_generate(keep, 0, 42)
+    return out
+
+
+def cpu_g1_intt_row(ctx, device, log_n=16):
+    """BASELINE.md §3 row B5 on a bounded sample: Crs::<Lagrange>::from_powers (the G1 iNTT of dump-lagrange) of the first
+    2^16 crs_42 points — 2^15 * 16 scalar multiplications of 254 bits, a few seconds on 16 host threads; 2^20 would be ~25x more"""
+    from oracle import oracle_lib as ol
+    n = 1 << log_n
+    keep = ctx.srs_size()
+    ctx.srs_generate(n, 0, 42)
+    pts = ctx.srs_download(0, n)
+    cores = min(os.cpu_count() or 1, 16)
+    t0 = time.perf_counter()
+    ref = ol.g1_intt(pts, log_n, threads=cores)
+    cpu_s = time.perf_counter() - t0
+    out = torch.empty((n, 8), dtype=torch.int64, device=device)
+    ctx.g1_intt_srs_dev(log_n, out)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.g1_intt_srs_dev(log_n, out)
+    ctx.synchronize()
+    gpu_s = time.perf_counter() - t0
+    same = bool(np.array_equal(out.cpu().numpy().view(np.uint64), ref))
+    if keep:
+        ctx.srs_generate(keep, 0, 42)
+    return {"points": n, "cpu_s": round(cpu_s, 2), "gpu_s": round(gpu_s, 4), "cores": cores, "kind": "port", "identical": same}
+
+
 def cpu_ntt_baseline(sizes=(20, 22)):
     """bellman best_fft restatement: serial radix-2 below log2(cpus), the classic split into
     2^log_cpus interleaved sub-FFTs above; timed at 16 threads and at every host core, the better one is reported"""
@@ -126,6 +207,10 @@ def cpu_ntt_baseline(sizes=(20, 22)):
                 best = (dt, cores)
         out["ntt_2^%d" % log_n] = {"ms": round(best[0] * 1e3, 2), "cores": best[1], "kind": "port",
                                    "algorithmic_GBs": round(64 * n / best[0] / 1e9, 2)}
+        if log_n == 22:                                                # the coset NTT on the 4N domain of a 2^20-gate proof
+            t0 = time.perf_counter()
+            ol.ntt(a, log_n, coset=7, threads=best[1])
+            out["coset_ntt_2^22"] = {"ms": round((time.perf_counter() - t0) * 1e3, 2), "cores": best[1], "kind": "port"}
     return out
 
 
@@ -143,6 +228,9 @@ def cpu_prove_baseline(ctx, log_domain):
     ctx.srs_generate(1 << log_domain, 0, 42)
     crs = po.Crs(ctx.srs_download(0, 1 << log_domain), b"\x01" * 256)
     t0 = time.perf_counter()
+    po.load_r1cs_bin(circ.export("r1cs")); po.parse_wtns(circ.export("wtns"))      # (timed once more: row B2 counts the parsing)
+    parse_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
     S = po.setup(r1cs)
     setup_s = time.perf_counter() - t0
     ol.C_SECONDS[0] = 0.0
@@ -159,6 +247,7 @@ def cpu_prove_baseline(ctx, log_domain):
     if srs_keep:
         ctx.srs_generate(srs_keep, 0, 42)
     return {"domain": 1 << log_domain, "cpu_s": round(cpu_s, 3), "cpu_c_kernels_s": round(c_s, 3), "cpu_setup_s": round(setup_s, 2),
+            "cpu_parse_s": round(parse_s, 2), "cpu_whole_s": round(parse_s + setup_s + cpu_s, 1),
             "gpu_s": round(gpu_s, 5), "threads": ol.ncpu(), "kind": "port", "proof_bytes_identical": bool(got == ref),
             "speedup_vs_cpu_total": round(cpu_s / gpu_s, 1), "speedup_vs_cpu_c_kernels": round(c_s / gpu_s, 1),
             "sample": "one prove (rounds 1-5, 11 MSM + 25 NTT-equivalents) of a synthetic 2^%d-gate circuit" % log_domain}
@@ -428,6 +517,8 @@ def main():
             cb, ref, s_host = cpu_msm_baseline(ctx, min(args.cpu_log_n, args.log_n), 1234)
             got = ctx.msm(s_host)                         # same sample through the HIP path
             cb["matches_gpu"] = bool(np.array_equal(got, ref))
+            cb["msm_rows"] = cpu_msm_rows(ctx, device)
+            cb["g1_intt"] = cpu_g1_intt_row(ctx, device)
             cb["ntt"] = cpu_ntt_baseline()
             cb["prove"] = cpu_prove_baseline(ctx, min(args.cpu_log_n, args.log_n))
             rb = reference_binary_baseline(min(args.cpu_log_n, args.log_n))
