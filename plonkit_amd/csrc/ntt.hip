@@ -298,6 +298,24 @@ Fr cached_inverse(plk_ctx *ctx, const Fr &g) {
     return gi;
 }
 
+// four tables in ONE launch (round 4 of the prover needs z, 1/z, z*omega, 1/(z*omega): four launches of 42 us each were
+// pure latency — every thread is a dependent chain of <= 28 squarings)
+struct FourBases { Fr b[4]; Fr *buf[4]; };
+__global__ void fill_pow_tables4(FourBases a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (i >= 2 * POW_TAB) return;
+    Fr *lo = a.buf[k], *hi = lo + POW_TAB;
+    if (i < POW_TAB) store_fp(lo + i, pow_u64(a.b[k], i));
+    else store_fp(hi + (i - POW_TAB), pow_u64(a.b[k], (uint64_t)(i - POW_TAB) << POW_SPLIT));
+}
+int32_t fill_pow_tables4_into(plk_ctx *, const Fr bases[4], Fr *const bufs[4], PowTable out[4], hipStream_t s) {
+    FourBases a;
+    for (int k = 0; k < 4; k++) { a.b[k] = bases[k]; a.buf[k] = bufs[k]; out[k].lo = bufs[k]; out[k].hi = bufs[k] + POW_TAB; }
+    hipLaunchKernelGGL(fill_pow_tables4, dim3(2 * POW_TAB / 256, 4), dim3(256), 0, s, a);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+
 int32_t fill_pow_table_into(plk_ctx *ctx, const Fr &base, Fr *buf, PowTable *out, hipStream_t s) {
     hipLaunchKernelGGL(fill_pow_table, dim3(2 * POW_TAB / 256), dim3(256), 0, s, buf, buf + POW_TAB, base);
     PLK_HIP(hipGetLastError());

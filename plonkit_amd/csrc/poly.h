@@ -76,5 +76,6 @@ int32_t div_finish(Fr *q, const Fr *suffix, const PowTable &zinv, uint32_t n, hi
 int32_t eval_batch(plk_ctx *ctx, EvalArgs a, Fr *results_dev, hipStream_t s);
 // fills a caller-provided 2*POW_TAB table with powers of `base`
 int32_t fill_pow_table_into(plk_ctx *ctx, const Fr &base, Fr *buf, PowTable *out, hipStream_t s);
+int32_t fill_pow_tables4_into(plk_ctx *ctx, const Fr bases[4], Fr *const bufs[4], PowTable out[4], hipStream_t s);
 
 }  // namespace plk

@@ -584,11 +584,12 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     // ---- round 4: evaluations at z and z*omega, linearisation
     const HFr omega = host_omega(log_n), zw = z * omega, zN = z.pow_u64(N);
     if (z.is_zero()) { set_error("challenge z = 0"); return PLK_ERR_UNSAT; }
-    PowTable pt_z, pt_zinv, pt_zw, pt_zwinv;
-    PLK_TRY(fill_pow_table_into(ctx, to_dev(z), tab[0], &pt_z, st));
-    PLK_TRY(fill_pow_table_into(ctx, to_dev(z.inv()), tab[1], &pt_zinv, st));
-    PLK_TRY(fill_pow_table_into(ctx, to_dev(zw), tab[2], &pt_zw, st));
-    PLK_TRY(fill_pow_table_into(ctx, to_dev(zw.inv()), tab[3], &pt_zwinv, st));
+    PowTable pts4[4];
+    {
+        const Fr bases4[4] = {to_dev(z), to_dev(z.inv()), to_dev(zw), to_dev(zw.inv())};
+        PLK_TRY(fill_pow_tables4_into(ctx, bases4, tab, pts4, st));
+    }
+    const PowTable pt_z = pts4[0], pt_zinv = pts4[1], pt_zw = pts4[2], pt_zwinv = pts4[3];
     HFr ev[11];
     {
         EvalArgs ea{};
