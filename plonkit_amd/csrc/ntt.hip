@@ -234,11 +234,13 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
 }
 
 // ------------------------------------------------------------------------------- tables
-__global__ void fill_pow_table(Fr *lo, Fr *hi, Fr base) {
+// w_domain: entries 32 * base^e, i.e. base^e * 2^261 — what the 29-bit layer's products take as a constant (poly.hip)
+__global__ void fill_pow_table(Fr *lo, Fr *hi, Fr base, int w_domain = 0) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * POW_TAB) return;
-    if (i < POW_TAB) store_fp(lo + i, pow_u64(base, i));
-    else store_fp(hi + (i - POW_TAB), pow_u64(base, (uint64_t)(i - POW_TAB) << POW_SPLIT));
+    Fr v = i < POW_TAB ? pow_u64(base, i) : pow_u64(base, (uint64_t)(i - POW_TAB) << POW_SPLIT);
+    if (w_domain) v = mul(v, from_u64<FrParams>(32));
+    store_fp(i < POW_TAB ? lo + i : hi + (i - POW_TAB), v);
 }
 
 // canonical omega_{2^28} — 7^((r-1)/2^28)
@@ -274,7 +276,7 @@ __global__ void table_slice(uint32_t *out, const Fr *in_w, uint32_t n) {
 static int32_t make_pow_table(plk_ctx *ctx, const Fr &base, PowTable *out, PowTable *out_w, void **alloc_out) {
     Fr *buf = nullptr;
     PLK_HIP(hipMalloc(&buf, sizeof(Fr) * 4 * POW_TAB + (size_t)48 * POW_TAB));
-    hipLaunchKernelGGL(fill_pow_table, dim3(2 * POW_TAB / 256), dim3(256), 0, ctx->stream, buf, buf + POW_TAB, base);
+    hipLaunchKernelGGL(fill_pow_table, dim3(2 * POW_TAB / 256), dim3(256), 0, ctx->stream, buf, buf + POW_TAB, base, 0);
     hipLaunchKernelGGL(table_to_w, dim3(2 * POW_TAB / 256), dim3(256), 0, ctx->stream, buf + 2 * POW_TAB, (const Fr *)buf, 2 * POW_TAB);
     PLK_HIP(hipGetLastError());
     out->lo = buf;
@@ -305,8 +307,9 @@ __global__ void fill_pow_tables4(FourBases a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     if (i >= 2 * POW_TAB) return;
     Fr *lo = a.buf[k], *hi = lo + POW_TAB;
-    if (i < POW_TAB) store_fp(lo + i, pow_u64(a.b[k], i));
-    else store_fp(hi + (i - POW_TAB), pow_u64(a.b[k], (uint64_t)(i - POW_TAB) << POW_SPLIT));
+    Fr v = i < POW_TAB ? pow_u64(a.b[k], i) : pow_u64(a.b[k], (uint64_t)(i - POW_TAB) << POW_SPLIT);
+    v = mul(v, from_u64<FrParams>(32));                             // W domain
+    store_fp(i < POW_TAB ? lo + i : hi + (i - POW_TAB), v);
 }
 int32_t fill_pow_tables4_into(plk_ctx *, const Fr bases[4], Fr *const bufs[4], PowTable out[4], hipStream_t s) {
     FourBases a;
@@ -316,8 +319,8 @@ int32_t fill_pow_tables4_into(plk_ctx *, const Fr bases[4], Fr *const bufs[4], P
     return PLK_OK;
 }
 
-int32_t fill_pow_table_into(plk_ctx *ctx, const Fr &base, Fr *buf, PowTable *out, hipStream_t s) {
-    hipLaunchKernelGGL(fill_pow_table, dim3(2 * POW_TAB / 256), dim3(256), 0, s, buf, buf + POW_TAB, base);
+int32_t fill_pow_table_into(plk_ctx *ctx, const Fr &base, Fr *buf, PowTable *out, hipStream_t s) {      // W-domain table
+    hipLaunchKernelGGL(fill_pow_table, dim3(2 * POW_TAB / 256), dim3(256), 0, s, buf, buf + POW_TAB, base, 1);
     PLK_HIP(hipGetLastError());
     out->lo = buf;
     out->hi = buf + POW_TAB;

@@ -2,12 +2,14 @@
 #include "ctx.h"
 namespace plk {
 
+// Scalars marked W are handed over as c * 2^261 (host: 32 * c in the external form), the others in the external form E;
+// power tables marked W are filled with 32 * base^e (poly.hip explains the domains)
 struct PermArgs {
-    Fr *num, *den;
+    Fr *num, *den;                      // out: W domain
     const Fr *w[4], *sigma[4];
-    Fr beta, gamma, beta_k[4];          // beta_k[j] = beta * k_j
+    Fr beta, gamma, beta_k[4], fix;     // beta: W; gamma, beta_k[j] = beta * k_j: E; fix = E(2^25), i.e. 2^281
     uint32_t n, log_n;
-    PowTable tw;
+    PowTable tw;                        // omega table, W
 };
 
 struct CheckArgs {
@@ -43,7 +45,7 @@ constexpr uint32_t LINCOMB_MAX = 14;
 struct LinCombArgs {
     Fr *out;
     const Fr *p[LINCOMB_MAX];
-    Fr s[LINCOMB_MAX];
+    Fr s[LINCOMB_MAX];                  // W
     uint32_t unit[LINCOMB_MAX];         // 1: coefficient is one (skip the multiply)
     uint32_t count, n;
 };
@@ -52,7 +54,7 @@ constexpr uint32_t EVAL_MAX = 12;
 struct EvalArgs {
     const Fr *poly[EVAL_MAX];
     uint32_t len[EVAL_MAX];
-    PowTable pt[EVAL_MAX];              // power table of the evaluation point
+    PowTable pt[EVAL_MAX];              // power table of the evaluation point, W
     uint32_t count, max_blocks;
     Fr *partials;
 };
@@ -76,6 +78,7 @@ int32_t div_finish(Fr *q, const Fr *suffix, const PowTable &zinv, uint32_t n, hi
 int32_t eval_batch(plk_ctx *ctx, EvalArgs a, Fr *results_dev, hipStream_t s);
 // fills a caller-provided 2*POW_TAB table with powers of `base`
 int32_t fill_pow_table_into(plk_ctx *ctx, const Fr &base, Fr *buf, PowTable *out, hipStream_t s);
+// W-domain tables: entries 32 * base^e in the external form
 int32_t fill_pow_tables4_into(plk_ctx *ctx, const Fr bases[4], Fr *const bufs[4], PowTable out[4], hipStream_t s);
 
 }  // namespace plk

@@ -17,6 +17,13 @@ constexpr int BLOCK_ELEMS = PT * EPT;
 __device__ __forceinline__ Fr pow2l_(const PowTable &t, uint32_t e) {
     return mul(load_fp(t.lo + (e & (POW_TAB - 1))), load_fp(t.hi + (e >> POW_SPLIT)));
 }
+__device__ __forceinline__ FrW9 ldw(const Fr *p) { return unpack<FrW>(load_fp(p)); }
+__device__ __forceinline__ FrW9 cw(const Fr &c) { return unpack<FrW>(c); }
+// base^e from a table filled in the W domain: W(lo) * W(hi) * 2^-261 = W(lo * hi)
+__device__ __forceinline__ FrW9 pow2l_w_(const PowTable &t, uint32_t e) {
+    return mulw(ldw(t.lo + (e & (POW_TAB - 1))), ldw(t.hi + (e >> POW_SPLIT)));
+}
+__device__ __forceinline__ void stw(Fr *p, const FrW9 &v) { store_fp(p, pack<FrParams>(v)); }     // v normalised, < 2^256
 
 // ------------------------------------------------------------------ gather / permutation
 __global__ void __launch_bounds__(PT) k_gather(Fr *out, const Fr *values, const uint32_t *vars, uint32_t n) {
@@ -34,31 +41,43 @@ __global__ void __launch_bounds__(PT) k_sigma_from_index(Fr *out, const uint32_t
     store_fp(out + i, col == 0 ? w : mul(w, k));
 }
 
-// num_i = prod_j (w_j + beta*k_j*omega^i + gamma) ; den_i = prod_j (w_j + beta*sigma_j + gamma)
+// num_i = prod_j (w_j + beta*k_j*omega^i + gamma) ; den_i = prod_j (w_j + beta*sigma_j + gamma), both written in the W
+// domain (the product scans that follow are closed there).  a.tw = omega table in the W domain, a.beta = W(beta), a.beta_k[j]
+// and a.gamma in E; a.fix = 2^281: three E x E products leave 2^241, the fourth by 2^281 lands on 2^261.
+// 17 products of the 29-bit layer per row (the 8 x 32-bit version: 15 products of 1.8x the cost).
 __global__ void __launch_bounds__(PT) k_perm_terms(PermArgs a) {
     uint32_t i = blockIdx.x * PT + threadIdx.x;
     if (i >= a.n) return;
-    Fr wi = pow2l_(a.tw, i << (MAX_LOG_N - a.log_n));
-    Fr num = Fr::one(), den = Fr::one();
+    const FrW9 wi = pow2l_w_(a.tw, i << (MAX_LOG_N - a.log_n));
+    const FrW9 gamma = cw(a.gamma), beta = cw(a.beta), fix = cw(a.fix);
+    FrW9 num, den;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        Fr w = add(load_fp(a.w[j] + i), a.gamma);
-        num = mul(num, add(w, mul(wi, a.beta_k[j])));
-        den = mul(den, add(w, mul(load_fp(a.sigma[j] + i), a.beta)));
+        const FrW9 wg = addw(ldw(a.w[j] + i), gamma);                                   // raw sums: limbs < 3 * 2^29 feed mulw's left side
+        const FrW9 fn = addw(wg, mulw(wi, cw(a.beta_k[j])));
+        const FrW9 fd = addw(wg, mulw(ldw(a.sigma[j] + i), beta));
+        if (j == 0) { num = fn; den = fd; }
+        else { num = mulw(num, normw(fn)); den = mulw(den, normw(fd)); }
     }
-    store_fp(a.num + i, num);
-    store_fp(a.den + i, den);
+    stw(a.num + i, csub_p(mulw(num, fix)));
+    stw(a.den + i, csub_p(mulw(den, fix)));
 }
 
-// z_i = A_i * C_i * inv_total
+// z_i = A_i * C_i * s:  A, C in the W domain (scan outputs), s = E(1 / total)  ->  E, canonical
 __global__ void __launch_bounds__(PT) k_mul3(Fr *out, const Fr *a, const Fr *b, Fr s, uint32_t n) {
     uint32_t i = blockIdx.x * PT + threadIdx.x;
-    if (i < n) store_fp(out + i, mul(mul(load_fp(a + i), load_fp(b + i)), s));
+    if (i < n) stw(out + i, csub_p(mulw(mulw(ldw(a + i), ldw(b + i)), cw(s))));
 }
 
 // -------------------------------------------------------------------------------- scans
-template <bool MULT> __device__ __forceinline__ Fr op(const Fr &a, const Fr &b) { return MULT ? mul(a, b) : add(a, b); }
-template <bool MULT> __device__ __forceinline__ Fr ident() { return MULT ? Fr::one() : Fr::zero(); }
+// product scans: elements in the W domain (closed under mulw), kept lazily reduced (< 1.01 p < 2^256) in registers, LDS and
+// the intermediate arrays, canonical in the final store of phase 3 / phase 1; sums: the 8 x 32-bit modular addition
+template <bool MULT> __device__ __forceinline__ Fr op(const Fr &a, const Fr &b) {
+    if (MULT) return pack<FrParams>(mulw(unpack<FrW>(a), unpack<FrW>(b)));
+    return add(a, b);
+}
+template <bool MULT> __device__ __forceinline__ Fr fin(const Fr &a) { return MULT ? pack<FrParams>(csub_p(unpack<FrW>(a))) : a; }
+template <bool MULT> __device__ __forceinline__ Fr ident() { return MULT ? pack<FrParams>(w_one<FrW>()) : Fr::zero(); }   // W(1) for products
 
 // phase 1: per-block scan of BLOCK_ELEMS elements; writes the block-local (inclusive or exclusive)
 // result and the block total.  reverse: logical index i maps to memory n-1-i (suffix scans).
@@ -89,7 +108,7 @@ __global__ void __launch_bounds__(PT) k_scan_local(Fr *out, const Fr *in, Fr *bl
 #pragma unroll
     for (int k = 0; k < EPT; k++) {
         uint32_t i = base + k;
-        if (i < n) store_fp(out + (reverse ? n - 1 - i : i), op<MULT>(excl, v[k]));
+        if (i < n) store_fp(out + (reverse ? n - 1 - i : i), fin<MULT>(op<MULT>(excl, v[k])));
     }
 }
 
@@ -124,7 +143,7 @@ __global__ void __launch_bounds__(PT) k_scan_apply(Fr *out, const Fr *tot, uint3
 #pragma unroll
     for (int k = 0; k < EPT; k++) {
         uint32_t i = base + k;
-        if (i < n) { Fr *p = out + (reverse ? n - 1 - i : i); store_fp(p, op<MULT>(pre, load_fp(p))); }
+        if (i < n) { Fr *p = out + (reverse ? n - 1 - i : i); store_fp(p, fin<MULT>(op<MULT>(pre, load_fp(p)))); }
     }
 }
 
@@ -173,8 +192,6 @@ int32_t eval_witness_ops(Fr *values, const void *ops_dev, const void *terms_dev,
 }
 
 // ----------------------------------------------------------------------------- quotient
-__device__ __forceinline__ FrW9 ldw(const Fr *p) { return unpack<FrW>(load_fp(p)); }
-__device__ __forceinline__ FrW9 cw(const Fr &c) { return unpack<FrW>(c); }
 
 // out_i = in_i * c as ONE product of the 29-bit layer (c given with the scale the caller wants, see QuotientArgs)
 __global__ void __launch_bounds__(PT) k_scale_const(Fr *out, const Fr *in, Fr c, uint32_t n) {
@@ -225,21 +242,29 @@ __global__ void __launch_bounds__(PT) k_quotient(QuotientArgs a) {
 }
 
 // ------------------------------------------------------------------- linear combinations
+// out_i = sum_k s_k * p_k[i]; a.s[k] = W(s_k) (unit[k]: the coefficient is one, the term is only added).  Two products share
+// one Montgomery reduction (mul2addw: 243 multiply-adds instead of 324).
 __global__ void __launch_bounds__(PT) k_lincomb(LinCombArgs a) {
     uint32_t i = blockIdx.x * PT + threadIdx.x;
     if (i >= a.n) return;
-    Fr acc = Fr::zero();
+    FrW9 acc = w_zero<FrW>();
+    FrW9 pv = w_zero<FrW>(), ps = w_zero<FrW>();
+    bool pending = false;
     for (uint32_t k = 0; k < a.count; k++) {
-        Fr v = load_fp(a.p[k] + i);
-        acc = add(acc, a.unit[k] ? v : mul(v, a.s[k]));
+        const FrW9 v = ldw(a.p[k] + i);
+        if (a.unit[k]) { acc = addn(acc, v); continue; }
+        const FrW9 sk = cw(a.s[k]);
+        if (!pending) { pv = v; ps = sk; pending = true; }
+        else { acc = addn(acc, mul2addw(pv, ps, v, sk)); pending = false; }
     }
-    store_fp(a.out + i, acc);
+    if (pending) acc = addn(acc, mulw(pv, ps));
+    stw(a.out + i, reduce_small(acc));                                                  // < 16 p here
 }
 
-// out_i = in_i * base^(i + shift)     (base given by its power table)
+// out_i = in_i * base^(i + shift)     (base given by its W-domain power table)
 __global__ void __launch_bounds__(PT) k_mul_powers(Fr *out, const Fr *in, PowTable t, uint32_t shift, uint32_t n) {
     uint32_t i = blockIdx.x * PT + threadIdx.x;
-    if (i < n) store_fp(out + i, mul(load_fp(in + i), pow2l_(t, i + shift)));
+    if (i < n) stw(out + i, csub_p(mulw(ldw(in + i), pow2l_w_(t, i + shift))));
 }
 
 // q_k = S_{k+1} * zinv^(k+1), q_{n-1} = 0       (synthetic division by (x - z), see prover.hip)
@@ -247,11 +272,13 @@ __global__ void __launch_bounds__(PT) k_div_finish(Fr *q, const Fr *suffix, PowT
     uint32_t k = blockIdx.x * PT + threadIdx.x;
     if (k >= n) return;
     if (k == n - 1) { store_fp(q + k, Fr::zero()); return; }
-    store_fp(q + k, mul(load_fp(suffix + k + 1), pow2l_(zinv, k + 1)));
+    stw(q + k, csub_p(mulw(ldw(suffix + k + 1), pow2l_w_(zinv, k + 1))));
 }
 
 // ------------------------------------------------------------------------- evaluation
-// partial[b] = sum over the block's BLOCK_ELEMS coefficients c_i * x^i
+// partial[b] = sum over the block's BLOCK_ELEMS coefficients c_i * x^i; Horner inside a thread with W(x) (the raw sum
+// acc * x + c feeds the next product's left side un-normalised), then one product by W(x^start); canonical before the
+// 8 x 32-bit tree sum
 __global__ void __launch_bounds__(PT) k_eval_partial(EvalArgs a) {
     __shared__ __attribute__((aligned(16))) Fr sh[PT];
     const uint32_t e = blockIdx.y, tid = threadIdx.x;
@@ -260,10 +287,11 @@ __global__ void __launch_bounds__(PT) k_eval_partial(EvalArgs a) {
     Fr acc = Fr::zero();
     if (start < n) {
         const Fr *c = a.poly[e];
-        Fr x = load_fp(a.pt[e].lo + 1);
+        const FrW9 x = ldw(a.pt[e].lo + 1);
         uint32_t hi = start + EPT < n ? start + EPT : n;
-        for (int i = (int)hi - 1; i >= (int)start; i--) acc = add(mul(acc, x), load_fp(c + i));
-        acc = mul(acc, pow2l_(a.pt[e], start));
+        FrW9 h = ldw(c + hi - 1);
+        for (int i = (int)hi - 2; i >= (int)start; i--) h = addw(mulw(h, x), ldw(c + i));
+        acc = pack<FrParams>(csub_p(mulw(normw(h), pow2l_w_(a.pt[e], start))));
     }
     sh[tid] = acc;
     __syncthreads();

@@ -494,7 +494,8 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
         PermArgs pa;
         pa.num = t1; pa.den = t2;
         for (int j = 0; j < 4; j++) { pa.w[j] = w_vals[j]; pa.sigma[j] = S->sig_vals[j]; pa.beta_k[j] = to_dev(beta * kk[j]); }
-        pa.beta = to_dev(beta); pa.gamma = to_dev(gamma); pa.n = (uint32_t)N; pa.log_n = log_n; pa.tw = ctx->tw_fwd;
+        pa.beta = to_dev(beta * HFr::from_u64(32)); pa.gamma = to_dev(gamma); pa.fix = to_dev(HFr::from_u64(1u << 25));   // domains: poly.h
+        pa.n = (uint32_t)N; pa.log_n = log_n; pa.tw = ctx->tw_fwd_w;
         PLK_TRY(perm_terms(pa, st));
         PLK_TRY(scan(ctx, t1, t1, (uint32_t)N, true, false, true, st));
         PLK_TRY(scan(ctx, t2, t2, (uint32_t)N, true, true, false, st));
@@ -502,7 +503,8 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
         PLK_HIP(hipMemcpyAsync(total.l, t2, sizeof(Fr), hipMemcpyDeviceToHost, st));
         PLK_HIP(hipStreamSynchronize(st));
         if (total.is_zero()) { set_error("grand product denominator vanished (probability ~2^-230)"); return PLK_ERR_UNSAT; }
-        PLK_TRY(mul3(z_coef, t1, t2, to_dev(total.inv()), (uint32_t)N, st));
+        // the scans live in the W domain: what was read is 32 * C_0, so E(1 / C_0) = 32 * E(1 / (32 C_0))
+        PLK_TRY(mul3(z_coef, t1, t2, to_dev(total.inv() * HFr::from_u64(32)), (uint32_t)N, st));
         if (use_lagrange) PLK_HIP(hipMemcpyAsync(t1, z_coef, N * sizeof(Fr), hipMemcpyDeviceToDevice, st));   // keep the values
         PLK_TRY(ntt_dev(ctx, z_coef, log_n, true, nullptr, st));
     }
@@ -612,7 +614,7 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
         la.out = r_poly; la.n = (uint32_t)N; la.count = 9;
         const Fr *ps[9] = {S->sel_coef[5], S->sel_coef[0], S->sel_coef[1], S->sel_coef[2], S->sel_coef[3], S->sel_coef[4], S->sel_coef[6], z_coef, S->sig_coef[3]};
         HFr sc[9] = {HFr::one(), wz[0], wz[1], wz[2], wz[3], wz[0] * wz[1], w3zw, fz, -fs};
-        for (int k = 0; k < 9; k++) { la.p[k] = ps[k]; la.s[k] = to_dev(sc[k]); la.unit[k] = (k == 0); }
+        for (int k = 0; k < 9; k++) { la.p[k] = ps[k]; la.s[k] = to_dev(sc[k] * HFr::from_u64(32)); la.unit[k] = (k == 0); }
         PLK_TRY(lincomb(la, st));
         EvalArgs ea{};
         ea.poly[0] = r_poly; ea.len[0] = (uint32_t)N; ea.pt[0] = pt_z; ea.count = 1;
@@ -638,7 +640,7 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
         const Fr *ps[12] = {t_ext, t_ext + N, t_ext + 2 * N, t_ext + 3 * N, r_poly, w_coef[0], w_coef[1], w_coef[2], w_coef[3],
                             S->sig_coef[0], S->sig_coef[1], S->sig_coef[2]};
         HFr sc[12] = {HFr::one(), zN, zN * zN, zN * zN * zN, vp[1], vp[2], vp[3], vp[4], vp[5], vp[6], vp[7], vp[8]};
-        for (int k = 0; k < 12; k++) { la.p[k] = ps[k]; la.s[k] = to_dev(sc[k]); la.unit[k] = (k == 0); }
+        for (int k = 0; k < 12; k++) { la.p[k] = ps[k]; la.s[k] = to_dev(sc[k] * HFr::from_u64(32)); la.unit[k] = (k == 0); }
         PLK_TRY(lincomb(la, st));
         PLK_TRY(mul_powers(t1, agg, pt_z, 0, (uint32_t)N, st));
         PLK_TRY(scan(ctx, t1, t1, (uint32_t)N, false, true, false, st));
@@ -646,7 +648,7 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
 
         LinCombArgs lb{};
         lb.out = agg; lb.n = (uint32_t)N; lb.count = 2;
-        lb.p[0] = z_coef; lb.s[0] = to_dev(vp[9]); lb.p[1] = w_coef[3]; lb.s[1] = to_dev(vp[10]);
+        lb.p[0] = z_coef; lb.s[0] = to_dev(vp[9] * HFr::from_u64(32)); lb.p[1] = w_coef[3]; lb.s[1] = to_dev(vp[10] * HFr::from_u64(32));
         PLK_TRY(lincomb(lb, st));
         PLK_TRY(mul_powers(t1, agg, pt_zw, 0, (uint32_t)N, st));
         PLK_TRY(scan(ctx, t1, t1, (uint32_t)N, false, true, false, st));
@@ -755,7 +757,8 @@ int32_t plk_permutation_grand_product_dev(plk_ctx *ctx, const void *const wires_
     PermArgs pa;
     pa.num = tmp.as<Fr>(); pa.den = tmp.as<Fr>() + N;
     for (int j = 0; j < 4; j++) { pa.w[j] = (const Fr *)wires_dev[j]; pa.sigma[j] = (const Fr *)sigmas_dev[j]; pa.beta_k[j] = to_dev(hb * HFr::from_u64(NON_RESIDUES[j])); }
-    pa.beta = to_dev(hb); pa.gamma = to_dev(hg); pa.n = (uint32_t)N; pa.log_n = log_n; pa.tw = ctx->tw_fwd;
+    pa.beta = to_dev(hb * HFr::from_u64(32)); pa.gamma = to_dev(hg); pa.fix = to_dev(HFr::from_u64(1u << 25));
+    pa.n = (uint32_t)N; pa.log_n = log_n; pa.tw = ctx->tw_fwd_w;
     int32_t rc = perm_terms(pa, st);
     if (rc == PLK_OK) rc = scan(ctx, pa.num, pa.num, (uint32_t)N, true, false, true, st);
     if (rc == PLK_OK) rc = scan(ctx, pa.den, pa.den, (uint32_t)N, true, true, false, st);
@@ -763,7 +766,7 @@ int32_t plk_permutation_grand_product_dev(plk_ctx *ctx, const void *const wires_
     if (rc == PLK_OK && hipMemcpyAsync(total.l, pa.den, sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess) rc = hip_fail(hipGetLastError(), "D2H", __FILE__, __LINE__);
     if (rc == PLK_OK && hipStreamSynchronize(st) != hipSuccess) rc = hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__);
     if (rc == PLK_OK && total.is_zero()) { set_error("grand product denominator vanished"); rc = PLK_ERR_UNSAT; }
-    if (rc == PLK_OK) rc = mul3((Fr *)z_values_dev, pa.num, pa.den, to_dev(total.inv()), (uint32_t)N, st);
+    if (rc == PLK_OK) rc = mul3((Fr *)z_values_dev, pa.num, pa.den, to_dev(total.inv() * HFr::from_u64(32)), (uint32_t)N, st);
     if (hipStreamSynchronize(st) != hipSuccess && rc == PLK_OK) rc = hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__);
     tmp.release();
     return rc;
