@@ -18,6 +18,7 @@
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <sys/socket.h>
+#include <poll.h>
 #include <unistd.h>
 #include <cstring>
 #include <chrono>
@@ -61,6 +62,14 @@ int32_t rccl_fail(ncclResult_t e, const char *what) {
     Rccl *R = rccl();
     set_error(std::string("RCCL: ") + what + ": " + (R && R->GetErrorString ? R->GetErrorString(e) : "error") );
     return PLK_ERR_HIP;
+}
+
+// a rank that died must not leave the others blocked for ever: every socket operation gives up after COMM_TIMEOUT_S
+constexpr int COMM_TIMEOUT_S = 180;
+void set_timeouts(int fd) {
+    timeval tv{COMM_TIMEOUT_S, 0};
+    ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    ::setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
 }
 
 bool send_all(int fd, const void *p, size_t n) {
@@ -201,7 +210,9 @@ int32_t plk_comm_open_tcp(int32_t rank, int32_t world, uint16_t port, void **out
         if (C->listen_fd < 0 || ::bind(C->listen_fd, reinterpret_cast<sockaddr *>(&addr), sizeof addr) != 0 || ::listen(C->listen_fd, world) != 0) {
             comm_free(C); set_error("plk_comm_open_tcp: cannot listen on 127.0.0.1"); return PLK_ERR_IO; }
         for (int k = 1; k < world; k++) {
-            int fd = ::accept(C->listen_fd, nullptr, nullptr);
+            pollfd pf{C->listen_fd, POLLIN, 0};
+            int fd = ::poll(&pf, 1, COMM_TIMEOUT_S * 1000) > 0 ? ::accept(C->listen_fd, nullptr, nullptr) : -1;
+            if (fd >= 0) set_timeouts(fd);
             int32_t peer = -1;
             if (fd < 0 || !recv_all(fd, &peer, 4) || peer < 1 || peer >= world || C->fds[peer] >= 0) { if (fd >= 0) ::close(fd); comm_free(C); set_error("plk_comm_init_tcp: bad peer"); return PLK_ERR_IO; }
             ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
@@ -217,6 +228,7 @@ int32_t plk_comm_open_tcp(int32_t rank, int32_t world, uint16_t port, void **out
             std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
         int32_t me = rank;
+        if (fd >= 0) set_timeouts(fd);
         if (fd < 0 || !send_all(fd, &me, 4)) { if (fd >= 0) ::close(fd); comm_free(C); set_error("plk_comm_init_tcp: cannot reach rank 0"); return PLK_ERR_IO; }
         ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
         C->fds[0] = fd;
