@@ -327,8 +327,9 @@ def test_poseidon_shaped_circuits(ctx, perms, rp, log_n):
 
 def test_commitments_longer_than_one_msm_call(ctx):
     """domains above 2^24 (the reference allows 2^26) are committed in pieces of at most 2^24 terms against successive
-    SRS ranges; with PLK_MSM_MAX_TERMS=4096 the same code path cuts a 2^14-term commitment into four pieces — same
-    verification key and proof bytes as the one-piece run (the override is read once per process, hence the subprocess)"""
+    SRS ranges, one commitment at a time, and without the cached coset-point vector; with PLK_MSM_MAX_TERMS=4096 and
+    PLK_NO_COSET_CACHE=1 the same code paths run at the 2^14 domain (four pieces per commitment) — same verification key
+    and proof bytes as the ordinary run (the overrides are read once per process, hence the subprocess)"""
     import subprocess
     import sys
     import plonkit_amd as pa
@@ -342,7 +343,8 @@ def test_commitments_longer_than_one_msm_call(ctx):
             "k = pa.Circuit.synthetic(%d); s = pa.SetupForProver(c, k); "
             "print(s.verification_key_bytes(pa.crs42_g2_bytes()).hex() + s.prove(k).hex())") % (
                 os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n, n - 2)
-    env = dict(os.environ, PLK_MSM_MAX_TERMS="4096")
+    # PLK_NO_COSET_CACHE: the quotient kernel then computes the coset points on the fly — the branch domains above 2^24 take
+    env = dict(os.environ, PLK_MSM_MAX_TERMS="4096", PLK_NO_COSET_CACHE="1")
     got = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert got.returncode == 0, got.stderr[-2000:]
     assert got.stdout.strip().splitlines()[-1] == want
