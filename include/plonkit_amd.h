@@ -96,6 +96,13 @@ int32_t plk_msm_g1_partial_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n
  * or a finish with nothing in flight, returns PLK_ERR_ARG.                                                          */
 int32_t plk_msm_g1_enqueue_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, void *stream);
 int32_t plk_msm_g1_finish(plk_ctx *ctx, plk_g1_jacobian *out);
+/* the same FIFO with a BATCH of `count` (<= 8) commitments of equal length against the same bases per slot — the shape of the
+ * prover's rounds (4 wire, 4 quotient, 2 opening commitments): one pass of the kernels serves the whole batch.
+ * _finish_batch returns the count Jacobian sums in order; _finish_batch_sharded additionally runs the context's combiner
+ * (plk_comm_init / plk_set_commit_shard: one exchange for the batch) and returns affine points.                           */
+int32_t plk_msm_g1_enqueue_batch_dev(plk_ctx *ctx, const void *const *scalars_dev, uint32_t count, uint64_t n, uint64_t base_offset, void *stream);
+int32_t plk_msm_g1_finish_batch(plk_ctx *ctx, plk_g1_jacobian *out, uint32_t count);
+int32_t plk_msm_g1_finish_batch_sharded(plk_ctx *ctx, plk_g1_affine *out, uint32_t count);
 /* tracing hook: HIP events around the bucket-accumulation kernel of the last MSM (bench roofline) */
 int32_t plk_set_kernel_timing(plk_ctx *ctx, int32_t on);
 int32_t plk_msm_last_kernel_ms(plk_ctx *ctx, float *accumulate_ms);

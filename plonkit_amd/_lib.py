@@ -245,6 +245,21 @@ class Context:
     def msm_enqueue_dev(self, ptr, n, base_offset=0, stream=None):
         _check(lib().plk_msm_g1_enqueue_dev(self._h, _devptr(ptr), ctypes.c_uint64(n), ctypes.c_uint64(base_offset), _stream(stream)))
 
+    def msm_enqueue_batch_dev(self, ptrs, n, base_offset=0, stream=None):
+        arr = (ctypes.c_void_p * len(ptrs))(*[_devptr(p) for p in ptrs])
+        _check(lib().plk_msm_g1_enqueue_batch_dev(self._h, arr, ctypes.c_uint32(len(ptrs)), ctypes.c_uint64(n), ctypes.c_uint64(base_offset), _stream(stream)))
+
+    def msm_finish_batch(self, count):
+        out = np.zeros((count, 12), dtype=np.uint64)
+        _check(lib().plk_msm_g1_finish_batch(self._h, _np(out), ctypes.c_uint32(count)))
+        return out
+
+    def msm_finish_batch_sharded(self, count):
+        """finish + the installed combiner (one exchange for the batch): [count, 8] affine commitments over all ranks' shards"""
+        out = np.zeros((count, 8), dtype=np.uint64)
+        _check(lib().plk_msm_g1_finish_batch_sharded(self._h, _np(out), ctypes.c_uint32(count)))
+        return out
+
     def msm_finish(self):
         out = np.zeros(12, dtype=np.uint64)
         _check(lib().plk_msm_g1_finish(self._h, _np(out)))

@@ -867,6 +867,38 @@ int32_t plk_msm_g1_enqueue_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n
     return msm_enqueue(ctx, (const Fr *)scalars_dev, n, base_offset, stream ? (hipStream_t)stream : ctx->stream);
 }
 
+// the same FIFO for a batch of `count` (<= 8) commitments of equal length against the same bases: one pass of the kernels
+int32_t plk_msm_g1_enqueue_batch_dev(plk_ctx *ctx, const void *const *scalars_dev, uint32_t count, uint64_t n, uint64_t base_offset, void *stream) {
+    if (!ctx || !scalars_dev || count == 0 || count > MSM_MAX_BATCH) { set_error("plk_msm_g1_enqueue_batch_dev: bad argument"); return PLK_ERR_ARG; }
+    for (uint32_t k = 0; k < count; k++) if (!scalars_dev[k] && n) { set_error("plk_msm_g1_enqueue_batch_dev: null vector"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    return msm_enqueue_batch(ctx, reinterpret_cast<const Fr *const *>(scalars_dev), count, n, base_offset, stream ? (hipStream_t)stream : ctx->stream);
+}
+static int32_t finish_batch_checked(plk_ctx *ctx, uint32_t count, host::HJac *j) {
+    if (ctx->msm_fin == ctx->msm_enq) { set_error("msm: nothing in flight"); return PLK_ERR_ARG; }
+    if (ctx->slot[ctx->msm_fin & 1].batch != count) { set_error("plk_msm_g1_finish_batch: the commitment in flight holds a different batch size"); return PLK_ERR_ARG; }
+    return msm_finish_batch(ctx, nullptr, j);
+}
+int32_t plk_msm_g1_finish_batch(plk_ctx *ctx, plk_g1_jacobian *out, uint32_t count) {
+    if (!ctx || !out || count == 0 || count > MSM_MAX_BATCH) { set_error("plk_msm_g1_finish_batch: bad argument"); return PLK_ERR_ARG; }
+    host::HJac j[MSM_MAX_BATCH];
+    PLK_TRY(finish_batch_checked(ctx, count, j));
+    for (uint32_t k = 0; k < count; k++) { memcpy(out[k].x, j[k].x.l, 32); memcpy(out[k].y, j[k].y.l, 32); memcpy(out[k].z, j[k].z.l, 32); }
+    return PLK_OK;
+}
+// finish + the context's combiner (one exchange for the whole batch), affine results
+int32_t plk_msm_g1_finish_batch_sharded(plk_ctx *ctx, plk_g1_affine *out, uint32_t count) {
+    if (!ctx || !out || count == 0 || count > MSM_MAX_BATCH) { set_error("plk_msm_g1_finish_batch_sharded: bad argument"); return PLK_ERR_ARG; }
+    plk_g1_jacobian j[MSM_MAX_BATCH];
+    PLK_TRY(plk_msm_g1_finish_batch(ctx, j, count));
+    if (ctx->combine) {
+        const int32_t rc = ctx->combine(ctx->combine_user, j, count);
+        if (rc != PLK_OK) { set_error("commitment combiner failed"); return rc; }
+    }
+    for (uint32_t k = 0; k < count; k++) PLK_TRY(plk_g1_sum_jacobian(&j[k], 1, &out[k]));
+    return PLK_OK;
+}
+
 int32_t plk_msm_g1_finish(plk_ctx *ctx, plk_g1_jacobian *out) {
     if (!ctx || !out) { set_error("plk_msm_g1_finish: bad argument"); return PLK_ERR_ARG; }
     host::HJac j;

@@ -65,6 +65,27 @@ class ShardedMsm:
             yield self._finish()                               # waits for commitment k, host Horner over the windows, exchange
 
 
+    def commit_batches(self, batches, n, base_offset=0, stream=None):
+        """the same pipeline with a BATCH of vectors per slot (the prover's shape: 4 wire / 4 quotient commitments share one
+        pass of the kernels): `batches` yields lists of up to 8 scalar vectors; yields [count, 8] affine commitments per
+        batch, two batches in flight.  Needs native=True when ranks > 1 (one exchange per batch inside the library)."""
+        it = iter(batches)
+        cur = next(it, None)
+        if cur is None:
+            return
+        self.ctx.msm_enqueue_batch_dev(cur, n, base_offset, stream=stream)
+        while cur is not None:
+            nxt = next(it, None)
+            if nxt is not None:
+                self.ctx.msm_enqueue_batch_dev(nxt, n, base_offset, stream=stream)
+            if self.native:
+                out = self.ctx.msm_finish_batch_sharded(len(cur))
+            else:
+                out = np.stack([combine_partials(p, self.dist, self.device) for p in self.ctx.msm_finish_batch(len(cur))])
+            yield out
+            cur = nxt
+
+
 # Montgomery form of 1 in Fq (R mod q): the Z coordinate of an affine point written back as Jacobian
 _FQ_ONE = np.array([0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f], dtype=np.uint64)
 

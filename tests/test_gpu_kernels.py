@@ -277,3 +277,31 @@ def test_msm_differential_fuzz():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "msm_fuzz.py"), "24", "11"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout
+
+
+def test_batches_in_flight(ctx, srs16):
+    """plk_msm_g1_enqueue_batch_dev / plk_msm_g1_finish_batch: the two-slot FIFO with a batch of vectors per slot (the shape
+    of the prover's rounds); results equal the one-at-a-time commitments, a finish with the wrong batch size is refused and
+    leaves the batch in flight"""
+    import torch
+    import plonkit_amd as pa
+    from plonkit_amd.sharded import ShardedMsm
+    ctx.srs_upload(srs16)
+    n = 1 << 15
+    dev = torch.device("cuda:0")
+    vecs = [torch.from_numpy(_rand_fr(n, 900 + k).view(np.int64)).to(dev) for k in range(6)]
+    torch.cuda.synchronize()
+    single = [np.asarray(ctx.msm_dev(v, n)) for v in vecs]
+    ctx.msm_enqueue_batch_dev(vecs[:4], n)
+    ctx.msm_enqueue_batch_dev(vecs[4:], n)
+    with pytest.raises(pa.PlkError):
+        ctx.msm_finish_batch(3)                                   # the batch in flight holds four
+    a = ctx.msm_finish_batch(4)
+    b = ctx.msm_finish_batch_sharded(2)                           # no combiner installed: plain affine results
+    assert all(np.array_equal(pa.g1_sum_jacobian(a[k]), single[k]) for k in range(4))
+    assert all(np.array_equal(b[k], single[4 + k]) for k in range(2))
+    msm = ShardedMsm(ctx, None, dev)
+    outs = list(msm.commit_batches([vecs[:3], vecs[3:], vecs[:1]], n))
+    assert [o.shape[0] for o in outs] == [3, 3, 1]
+    got = [o[k] for o in outs for k in range(o.shape[0])]
+    assert all(np.array_equal(g, s) for g, s in zip(got, single + single[:1]))
