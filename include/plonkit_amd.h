@@ -14,8 +14,8 @@
  *   - plk_g1_jacobian = X || Y || Z, infinity is Z = 0.
  *   - every function returns int32_t: PLK_OK or an error code; text via plk_last_error().
  *     Nothing throws across the boundary.  Calls are blocking unless a stream is passed.
- *   - one plk_ctx drives ONE GPU (one process per GPU; multi-GPU MSM = ranks exchanging the
- *     96-byte partial sums of plk_msm_g1_partial_dev over RCCL, see plonkit_amd/sharded.py).
+ *   - one plk_ctx drives ONE GPU (one process per GPU; multi-GPU = ranks joined by plk_comm_init: the
+ *     96-byte partial sums of every commitment are all-gathered over RCCL and added, inside the library).
  *   - `*_dev` entry points take HIP device pointers (e.g. torch tensors' data_ptr()) and a
  *     hipStream_t passed as void* (NULL = the context's own stream); `host` ones take host memory.
  *   - There is NO CPU fallback: without a gfx950 device plk_create fails with PLK_ERR_HIP.

@@ -12,16 +12,18 @@
 //     to 17 * (sets - 1) doublings.
 //   * two-level bucket sort without a global sort: (1) a coarse partition by the top bits of the bucket index:
 //     per (window, 16K-scalar chunk) workgroup an LDS counting sort, one global reservation per (block, bin) and
-//     contiguous copy-out of every bin's run; (2) a coarse bin (128 consecutive buckets) is cut into equal tasks
-//     of <= 16384 entries; a workgroup counting-sorts its task inside LDS and cuts the sorted run into 256 EQUAL
-//     pieces, one per lane: one flat loop of mixed additions with XYZZ accumulators in registers, a bucket boundary
-//     inside a piece only flushes the accumulator (PRIMARY / HEAD / TAIL slots).  Points are gathered as 64-byte
-//     affine records.  All field arithmetic is the carry-free 9x29-bit layer (field29_dev.h / ec29_dev.h).
-//   * a bucket spread over many lanes (repeated scalars: all-ones, all -1) is folded by a separate small kernel.
+//     contiguous copy-out of every bin's run; (2) a coarse bin (2^FB consecutive buckets; FB = 6: 1024 bins of ~15 K
+//     entries at 2^20 terms, i.e. one task per bin) is cut into equal tasks of <= 16384 entries; a workgroup
+//     counting-sorts its task inside LDS and cuts the sorted run into 256 EQUAL pieces, one per lane: one flat loop of
+//     mixed additions with XYZZ accumulators in registers, a bucket boundary inside a piece only flushes the accumulator
+//     (PRIMARY / HEAD / TAIL slots).  Points are gathered as 64-byte affine records.  All field arithmetic is the
+//     carry-free 9x29-bit layer (field29_dev.h / ec29_dev.h).
+//   * a bucket spread over many lanes (repeated scalars: all-ones, all -1) is folded by a separate small kernel
+//     (msm_fold_hot), a coarse bin spread over many tasks by another (msm_bin_fold).
 //   * per task T = sum B_f and S = sum (f+1) B_f (running sums + 32-lane shuffle scan), then per bucket set
-//     sum_t S_t and sum_c c * D_c; the remaining shifts (2^7, 2^8) and the Horner over the sets run on the host,
-//     where one serial EC chain is 20x faster than on a GPU lane.  The reduce kernels are chains of full
-//     additions issued from one inlined call site each.
+//     sum_t S_t, sum_t t * E_t and F_1..F_3 (msm_window_sums); the remaining shifts (2^FB, 2^8), sum u * F_u and the
+//     Horner over the sets run on the host, where one serial EC chain is 20x faster than on a GPU lane.  The reduce
+//     kernels are chains of full additions issued from one inlined call site each.
 //   * up to 8 commitments over the same bases share every kernel launch (batch dimension), and two commitments
 //     (or batches) may be in flight on two streams with their own scratch: the latency-bound reduction of one
 //     overlaps the accumulation of the next.
