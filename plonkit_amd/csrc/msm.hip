@@ -561,19 +561,23 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_bin_fold(XyzzW *task_out, con
 // ------------------------------------------------------------------------ window reduction
 // W_w = sum_t S_t + 2^FB * sum_c c * D_c,  D_c = sum of T_t over the tasks of coarse bin c.
 // 256 threads; thread t serves bins t, t + 256, .. (nbins <= 1024: up to four of them).  With c = 256 u + t:
-//     sum_c c * D_c = sum_t t * E_t + 256 * sum_{u >= 1} u * F_u,   E_t = sum_u D_{t + 256 u},   F_u = sum_t D_{t + 256 u}.
-// One workgroup per role, side by side: role 0 tree-sums the S_t; role 1 forms sum_t t * E_t as the sum of the suffix
-// sums of E (Hillis-Steele scan through LDS, then a tree); role 1 + u (u >= 1) tree-sums F_u.  All are pure chains of
-// full additions issued from one inlined call site (operands in registers, see msm_task_reduce); the weights 2^FB, 2^8
-// and u are left to the host, which doubles anyway.  Results leave in the library's external form (canonical, R = 2^256).
+//     sum_c c * D_c = sum_t t * E_t + 256 * sum_{u >= 1} u * F_u,   E_t = sum_u D_{t + 256 u},   F_u = sum_t D_{t + 256 u},
+//     sum_t t * E_t = sum_{b < 8} 2^b * G_b,                          G_b = sum of E_t over the t with bit b set.
+// One workgroup per role, side by side, each a plain tree sum (its threads first add up their own bins, then 8 tree steps):
+// role 0: sum of the S_t; roles 1..8: G_0..G_7; roles 9..: F_1.. .  Round 1 formed sum_t t * E_t with a suffix scan in one
+// workgroup (8 more dependent additions of ~8 us on the tail of every commitment); the weights 2^b, 2^FB, 2^8 and u are a
+// few dozen host operations.  Pure chains of full additions from one inlined call site (operands in registers, see
+// msm_task_reduce).  Results leave in the library's external form (canonical, R = 2^256).
 constexpr uint32_t THREADS_LOG = 8;
 static_assert((1u << THREADS_LOG) == MSM_THREADS, "THREADS_LOG");
+constexpr uint32_t WS_BIT_ROLES = THREADS_LOG, WS_FIRST_F_ROLE = 1 + WS_BIT_ROLES;
 __global__ void __launch_bounds__(MSM_THREADS, 2) msm_window_sums(const XyzzW *task_out, const uint32_t *task_start, G1Xyzz *window_out, uint32_t nbins, uint32_t roles) {
     __shared__ __attribute__((aligned(16))) XyzzW sh[MSM_THREADS];
     const uint32_t tid = threadIdx.x, w = blockIdx.x, role = blockIdx.y;
     const uint32_t halves = (nbins + MSM_THREADS - 1) / MSM_THREADS;            // 1 .. 4
-    uint32_t u = role >= 2 ? role - 1 : 0;
-    const uint32_t u_end = role >= 2 ? role : halves;
+    const bool takes_part = role == 0 || role >= WS_FIRST_F_ROLE || ((tid >> (role - 1)) & 1);
+    uint32_t u = role >= WS_FIRST_F_ROLE ? role - WS_FIRST_F_ROLE + 1 : 0;
+    const uint32_t u_end = !takes_part ? u : (role >= WS_FIRST_F_ROLE ? u + 1 : halves);
     uint32_t t = 0, t_end = 0;
     auto open_bin = [&]() {                                   // next non-empty bin of this thread
         for (; u < u_end; u++) {
@@ -586,11 +590,10 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_window_sums(const XyzzW *t
     };
     open_bin();
     XyzzW X = xyzzw_identity();
-    const uint32_t scan_steps = role == 1 ? THREADS_LOG : 0, usteps = scan_steps + THREADS_LOG;
     uint32_t ustep = 0;
     for (;;) {
         const bool lockstep = __syncthreads_and(t >= t_end);  // (also the barrier that lets sh be rewritten)
-        if (lockstep && ustep == usteps) break;
+        if (lockstep && ustep == THREADS_LOG) break;
         XyzzW O = xyzzw_identity();
         if (!lockstep) {
             if (t < t_end) {
@@ -598,16 +601,10 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_window_sums(const XyzzW *t
                 if (++t == t_end) { u++; open_bin(); }
             }
         } else {
-            if (role == 1 && ustep == scan_steps && tid == 0) X = xyzzw_identity();    // sum_t t*E_t = sum_{k>=1} suffix_k
             sh[tid] = X;
             __syncthreads();
-            if (ustep < scan_steps) {                          // inclusive suffix scan over the bins
-                const uint32_t off = 1u << ustep;
-                if (tid + off < MSM_THREADS) O = sh[tid + off];
-            } else {
-                const uint32_t off = (MSM_THREADS / 2) >> (ustep - scan_steps);
-                if (tid < off) O = sh[tid + off];
-            }
+            const uint32_t off = (MSM_THREADS / 2) >> ustep;
+            if (tid < off) O = sh[tid + off];
             ustep++;
         }
         xyzzw_add(X, O);                                      // the one addition site of the kernel
@@ -742,7 +739,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     const uint32_t META_PER_TASK = meta_per_task(p.fine_bits), SLOTS_PER_TASK = slots_per_task(p.fine_bits);
     PLK_TRY(S.c.reserve((size_t)max_tasks * 2 * sizeof(XyzzW) + (size_t)max_tasks * META_PER_TASK * 4));  // per-task (S, T) + bucket offsets
     PLK_TRY(S.e.reserve((size_t)max_tasks * SLOTS_PER_TASK * sizeof(XyzzW)));             // lane partial sums
-    PLK_TRY(S.d.reserve((size_t)5 * total_sets * sizeof(G1Xyzz)));                     // per bucket set: sum S, sum t*E_t, F_1..F_3
+    PLK_TRY(S.d.reserve((size_t)12 * total_sets * sizeof(G1Xyzz)));                    // per bucket set: sum S, G_0..G_7, F_1..F_3
     uint32_t *hist = S.a.as<uint32_t>(), *bin_start = hist + total_bins, *task_start = bin_start + total_bins + 1;
     uint32_t *entries = S.b.as<uint32_t>();
     XyzzW *task_out = S.c.as<XyzzW>();
@@ -787,7 +784,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     };
     if (p.fine_bits == 6) launch_shape(std::integral_constant<uint32_t, 6>{}); else launch_shape(std::integral_constant<uint32_t, 7>{});
     hipLaunchKernelGGL(msm_bin_fold, dim3((total_bins + MSM_THREADS / 64 - 1) / (MSM_THREADS / 64)), dim3(MSM_THREADS), 0, stream, task_out, (const uint32_t *)task_start, total_bins);
-    const uint32_t roles = 1 + (p.nbins + MSM_THREADS - 1) / MSM_THREADS;   // points per bucket set left for the host: S, sum t*E_t, F_1 ..
+    const uint32_t roles = WS_FIRST_F_ROLE + (p.nbins + MSM_THREADS - 1) / MSM_THREADS - 1;   // points per bucket set left for the host: S, G_0..G_7, F_1 ..
     hipLaunchKernelGGL(msm_window_sums, dim3(total_sets, roles), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins, roles);
     PLK_HIP(hipGetLastError());
     PLK_TRY(slot_pinned(S, (size_t)roles * total_sets * sizeof(G1Xyzz)));
@@ -827,19 +824,15 @@ int32_t msm_finish_batch(plk_ctx *ctx, hipStream_t, host::HJac *out) {
     for (uint32_t m = 0; m < S.batch; m++) {
         HJac acc = HJac::inf();
         if (S.windows) {
-            // per bucket set the device leaves (sum S, sum_t t*E_t, F_1, .., F_{halves-1});
-            // W = sum S + 2^FB * (sum_t t*E_t + 2^8 * sum_u u*F_u)
+            // per bucket set the device leaves (sum S, G_0..G_7, F_1, .., F_{halves-1});
+            // W = sum S + 2^FB * (sum_b 2^b G_b + 2^8 * sum_u u*F_u)
             const size_t per = (size_t)16 * S.roles;
             const uint64_t *raw = reinterpret_cast<const uint64_t *>(S.pinned) + per * m * S.windows;
             for (int w = (int)S.windows - 1; w >= 0; w--) {
                 for (uint32_t i = 0; i < S.c_bits; i++) acc = jac_double(acc);
-                HJac d = xyzz_host_to_jac(raw + per * w + 16);
-                if (S.roles > 2) {
-                    HJac run = HJac::inf(), up = HJac::inf();             // sum_u u*F_u = sum of the suffix sums of F
-                    for (uint32_t r = S.roles - 1; r >= 2; r--) { run = jac_add(run, xyzz_host_to_jac(raw + per * w + 16 * r)); up = jac_add(up, run); }
-                    for (uint32_t i = 0; i < THREADS_LOG; i++) up = jac_double(up);
-                    d = jac_add(d, up);
-                }
+                HJac run = HJac::inf(), d = HJac::inf();                  // sum_u u*F_u = sum of the suffix sums of F
+                for (uint32_t r = S.roles - 1; r >= WS_FIRST_F_ROLE; r--) { run = jac_add(run, xyzz_host_to_jac(raw + per * w + 16 * r)); d = jac_add(d, run); }
+                for (int b = (int)WS_BIT_ROLES - 1; b >= 0; b--) d = jac_add(jac_double(d), xyzz_host_to_jac(raw + per * w + 16 * (1 + b)));   // Horner over the bit sums
                 for (uint32_t i = 0; i < S.fine_bits; i++) d = jac_double(d);
                 acc = jac_add(acc, jac_add(xyzz_host_to_jac(raw + per * w), d));
             }
