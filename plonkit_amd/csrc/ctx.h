@@ -53,6 +53,7 @@ struct DevBuf {
 struct plk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t flag_ready = nullptr;         // the satisfiability verdict of plk_prove has reached `pinned`
     int num_cus = 0;
     // NTT tables (device): omega_{2^28} powers forward / inverse, coset generator 7 and 7^-1
     plk::DevBuf tables;

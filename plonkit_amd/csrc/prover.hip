@@ -460,10 +460,12 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
         for (int j = 0; j < 4; j++) ca.vars[j] = S->gate_vars[j];
         PLK_HIP(hipMemsetAsync(d_flag, 0, 4, st));
         PLK_TRY(check_gates(ca, st));
-        uint32_t bad = 0;
-        PLK_HIP(hipMemcpyAsync(&bad, d_flag, 4, hipMemcpyDeviceToHost, st));
-        PLK_HIP(hipStreamSynchronize(st));
-        if (bad) { set_error("must satisfy: witness does not satisfy the circuit"); return PLK_ERR_UNSAT; }
+        // the verdict is read back into the pinned result buffer and looked at after round 1 has been enqueued (before any
+        // commitment is used): the host does not stall the GPU for it.  An unsatisfied witness still ends the call with
+        // PLK_ERR_UNSAT and no proof bytes — the commitments under way are drained by the FIFO guard.
+        PLK_HIP(hipMemcpyAsync(ctx->pinned, d_flag, 4, hipMemcpyDeviceToHost, st));
+        if (!ctx->flag_ready) PLK_HIP(hipEventCreateWithFlags(&ctx->flag_ready, hipEventDisableTiming));
+        PLK_HIP(hipEventRecord(ctx->flag_ready, st));
     }
 
     // ---- round 1: wire polynomials, 4 x iNTT(N), 4 x MSM(N)
@@ -479,6 +481,8 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     HAffine wire_c[4];
     PLK_TRY(commit_begin(ctx, use_lagrange ? w_vals : w_coef, 4, N, use_lagrange));
     for (int j = 0; j < 4; j++) PLK_TRY(lde4_dev(ctx, w_coef[j], log_n, ext[j], st));      // round-3 work that needs no challenge
+    PLK_HIP(hipEventSynchronize(ctx->flag_ready));
+    if (*reinterpret_cast<volatile uint32_t *>(ctx->pinned)) { set_error("must satisfy: witness does not satisfy the circuit"); return PLK_ERR_UNSAT; }
     PLK_TRY(commit_end(ctx, 4, wire_c));
     RollingKeccak tr;
     for (const HFr &x : inputs) tr.absorb_fr(x);

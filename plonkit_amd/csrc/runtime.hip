@@ -123,6 +123,7 @@ void plk_destroy(plk_ctx *ctx) {
     ctx->stage.release(); ctx->poly_tmp.release(); ctx->poly_tmp2.release(); ctx->prove_ws.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned2) (void)hipHostFree(ctx->pinned2);
+    if (ctx->flag_ready) (void)hipEventDestroy(ctx->flag_ready);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
