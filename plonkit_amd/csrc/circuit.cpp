@@ -457,7 +457,7 @@ bool transpile(const R1cs &r, const big_vector<HFr> *witness, Transpiled *out) {
     parallel_for(chunks, 1, [&](size_t lo, size_t hi) {
         for (size_t k = lo; k < hi; k++) {
             Builder B{&pieces[k], witness, r.num_variables};
-            B.run(r, k * per, std::min(nc, (k + 1) * per), stats);
+            B.run(r, std::min(nc, k * per), std::min(nc, (k + 1) * per), stats);
         }
     }, nt);
     for (const Piece &p : pieces) if (p.failed) { set_error("unsatisfiable constant constraint"); return false; }
