@@ -143,7 +143,19 @@ def _native_rank(rank, world, port, log_n, q):
     ctx.comm_init_tcp(rank, world, port, rank * local)
     circ = pa.Circuit.synthetic(n - 2)
     setup = pa.SetupForProver(ctx, circ)
-    q.put((rank, setup.verification_key_bytes(pa.crs42_g2_bytes()), setup.prove(circ), ctx.comm_info()))
+    vk, proof, info = setup.verification_key_bytes(pa.crs42_g2_bytes()), setup.prove(circ), ctx.comm_info()
+    # the commitment-level form: every rank enqueues ITS slice of three global scalar vectors (a batch), the built-in
+    # combiner joins the partial sums — one exchange for the batch
+    import numpy as np
+    import torch
+    from plonkit_amd.sharded import ShardedMsm
+    rng = np.random.default_rng(4242)                               # the same global vectors on every rank
+    glob = rng.integers(0, 1 << 62, size=(3, n, 4), dtype=np.uint64)
+    glob[:, :, 3] &= np.uint64((1 << 60) - 1)
+    mine = [torch.from_numpy(np.ascontiguousarray(glob[k, rank * local:(rank + 1) * local]).view(np.int64)).to("cuda:0") for k in range(3)]
+    torch.cuda.synchronize()
+    outs = list(ShardedMsm(ctx, None, None, native=True).commit_batches([mine], local))
+    q.put((rank, vk, proof, info, outs[0].tobytes()))
     ctx.close()
 
 
@@ -157,6 +169,10 @@ def test_two_ranks_with_the_builtin_combiner():
     circ = pa.Circuit.synthetic(n - 2)
     setup = pa.SetupForProver(ctx, circ)
     want = (setup.verification_key_bytes(pa.crs42_g2_bytes()), setup.prove(circ))
+    rng = np.random.default_rng(4242)
+    glob = rng.integers(0, 1 << 62, size=(3, n, 4), dtype=np.uint64)
+    glob[:, :, 3] &= np.uint64((1 << 60) - 1)
+    want_commitments = np.stack([ctx.msm(glob[k]) for k in range(3)]).tobytes()
     port = _free_port()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
@@ -166,9 +182,10 @@ def test_two_ranks_with_the_builtin_combiner():
     res = sorted(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
-    for rank, vk, proof, info in res:
+    for rank, vk, proof, info, commitments in res:
         assert (vk, proof) == want, rank
         assert info == (rank, world, 6)
+        assert commitments == want_commitments, rank
 
 
 def test_bench_n2_control_flow_on_one_gpu():
