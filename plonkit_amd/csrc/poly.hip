@@ -230,10 +230,25 @@ __global__ void __launch_bounds__(PT) k_quotient(QuotientArgs a) {
     }
     const FrW9 z = ldw(a.z + i), gamma = cw(a.gamma), beta = cw(a.beta);
     FrW9 pa = z, pb = ldw(a.z + nxt);
+    // beta * k_j * x for the coset representatives k = (1, 5, 7, 10) (prover.hip NON_RESIDUES): ONE product
+    // beta * x and three small multiples formed limb-wise (5 = 4 + 1, 7 = 8 - 1, 10 = 2 * 5; limbs stay below 2^32) instead
+    // of four products
+    FrW9 bkx[4];
+    bkx[0] = mulw(x, beta);
+    {
+        FrW9 t5, t7;
+#pragma unroll
+        for (int l = 0; l < 9; l++) { t5.l[l] = (bkx[0].l[l] << 2) + bkx[0].l[l]; t7.l[l] = (bkx[0].l[l] << 3) - bkx[0].l[l]; }
+        bkx[1] = normw(t5); bkx[2] = normw(t7);
+        FrW9 t10;
+#pragma unroll
+        for (int l = 0; l < 9; l++) t10.l[l] = bkx[1].l[l] << 1;
+        bkx[3] = normw(t10);
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const FrW9 wg = addn(w[j], gamma);
-        pa = mulw(pa, addn(wg, mulw(x, cw(a.beta_k[j]))));
+        pa = mulw(pa, addn(wg, bkx[j]));
         pb = mulw(pb, addn(wg, mulw(ldw(a.sigma[j] + i), beta)));
     }
     FrW9 t = addn(g, mulw(cw(a.alpha_pp), sub2(pa, pb)));

@@ -24,7 +24,7 @@
 namespace plk {
 using namespace host;
 
-static const uint64_t NON_RESIDUES[4] = {1, 5, 7, 10};     // k_j (vk.bin stores 5, 7, 10)
+static const uint64_t NON_RESIDUES[4] = {1, 5, 7, 10};     // k_j (vk.bin stores 5, 7, 10); k_quotient (poly.hip) forms 5x, 7x, 10x by shifts
 
 static inline Fr to_dev(const HFr &h) { Fr f; memcpy(f.l, h.l, 32); return f; }
 int32_t ensure_pinned2(plk_ctx *ctx, size_t bytes);
@@ -174,6 +174,8 @@ struct plk_setup {
     mutable plk::DevBuf lde_store;
     mutable plk::Fr *lde[13] = {nullptr};       // 7 selectors, 4 sigma, L0 (pre-scaled, see QuotientArgs), coset points
     mutable bool lde_ready = false;
+    mutable bool zh_inv_ready = false;
+    mutable plk::HFr zh_inv[4];
     uint64_t num_circuit_vars = 0;         // circom wires; temporaries follow
     std::vector<plk::WitnessOp> ops;       // linear forms defining the transpiler's temporaries
     bool ops_independent = false;          // no temporary reads another temporary -> order-free evaluation
@@ -571,8 +573,12 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
         const HFr two5 = HFr::from_u64(1u << 5), two25 = HFr::from_u64(1u << 25);
         qa.beta = to_dev(beta); qa.gamma = to_dev(gamma);
         qa.alpha_pp = to_dev(alpha * two25); qa.alpha2_w = to_dev(alpha * alpha * two5);
-        HFr gN = coset.pow_u64(N), iota = host_omega(log_m).pow_u64(N), ip = HFr::one();
-        for (int k = 0; k < 4; k++) { qa.zh_inv_w[k] = to_dev((gN * ip - HFr::one()).inv() * two5); ip = ip * iota; }
+        if (!S->zh_inv_ready) {                                   // 1 / Z_H on the four cosets of <omega_N> inside the 4N domain: circuit constants
+            HFr gN = coset.pow_u64(N), iota = host_omega(log_m).pow_u64(N), ip = HFr::one();
+            for (int k = 0; k < 4; k++) { S->zh_inv[k] = (gN * ip - HFr::one()).inv(); ip = ip * iota; }
+            S->zh_inv_ready = true;
+        }
+        for (int k = 0; k < 4; k++) qa.zh_inv_w[k] = to_dev(S->zh_inv[k] * two5);
         qa.m = (uint32_t)M; qa.log_m = log_m;
         PLK_TRY(quotient(qa, st));
         Fr g = to_dev(coset);
@@ -590,9 +596,15 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     // ---- round 4: evaluations at z and z*omega, linearisation
     const HFr omega = host_omega(log_n), zw = z * omega, zN = z.pow_u64(N);
     if (z.is_zero()) { set_error("challenge z = 0"); return PLK_ERR_UNSAT; }
+    // the three inversions of this round (1/z, 1/(z omega), 1/(N (z - 1)) for L_0(z)) share one: the host inversion is what the
+    // GPU waits for between the rounds
+    const HFr l0_den = HFr::from_u64(N) * (z - HFr::one());
+    if (l0_den.is_zero()) { set_error("challenge z = 1"); return PLK_ERR_UNSAT; }
+    const HFr inv_all = (z * zw * l0_den).inv();
+    const HFr z_inv = inv_all * zw * l0_den, zw_inv = inv_all * z * l0_den, l0_den_inv = inv_all * z * zw;
     PowTable pts4[4];
     {
-        const Fr bases4[4] = {to_dev(z), to_dev(z.inv()), to_dev(zw), to_dev(zw.inv())};
+        const Fr bases4[4] = {to_dev(z), to_dev(z_inv), to_dev(zw), to_dev(zw_inv)};
         PLK_TRY(fill_pow_tables4_into(ctx, bases4, tab, pts4, st));
     }
     const PowTable pt_z = pts4[0], pt_zinv = pts4[1], pt_zw = pts4[2], pt_zwinv = pts4[3];
@@ -607,7 +619,7 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
         PLK_HIP(hipStreamSynchronize(st));
     }
     const HFr *wz = ev, w3zw = ev[4], *sz = ev + 5, tz = ev[8], zzw = ev[9];
-    HFr l0z = (zN - HFr::one()) * (HFr::from_u64(N) * (z - HFr::one())).inv();
+    HFr l0z = (zN - HFr::one()) * l0_den_inv;
     HFr fz = alpha;
     for (int j = 0; j < 4; j++) fz = fz * (wz[j] + beta * kk[j] * z + gamma);
     fz = fz + alpha * alpha * l0z;
