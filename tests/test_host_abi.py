@@ -272,3 +272,27 @@ def test_synthetic_circuit_generator_is_stable():
         assert hashlib.sha1(c.export("r1cs")).hexdigest()[:16] == h_r1cs, n
         assert hashlib.sha1(c.export("wtns")).hexdigest()[:16] == h_wtns, n
         c.close()
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/plonkit_amd.h is the boundary a cgo / Rust-bindgen / C caller sees: it must compile as C99 (no C++ in it) and
+    a C program linked against the shared library must resolve the symbols (the calls made here need no GPU)"""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not on PATH")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "plonkit_amd.h"\n#include <stdio.h>\n#include <string.h>\n'
+                   'int main(void) {\n'
+                   '  plk_transcript t; plk_fr c; unsigned char h[32];\n'
+                   '  plk_transcript_init(&t); plk_transcript_challenge(&t, &c);\n'
+                   '  plk_keccak256((const unsigned char *)"", 0, h);\n'
+                   '  plk_ctx *ctx = 0; int rc = plk_create(0, &ctx);            /* PLK_ERR_HIP without a GPU: no CPU fallback */\n'
+                   '  printf("%s %02x%02x %d %d\\n", plk_version(), h[0], h[1], rc == PLK_OK || rc == PLK_ERR_HIP, (int)sizeof(plk_comm_id));\n'
+                   '  if (ctx) plk_destroy(ctx);\n  return 0;\n}\n')
+    exe = str(tmp_path / "abi")
+    libdir = os.path.dirname(pa.lib_path())
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", exe,
+                           "-L" + libdir, "-lplonkit_amd", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout.split()
+    assert out[0] == "plonkit_amd" and out[-3] == "c5d2" and out[-2] == "1" and out[-1] == "128", out   # keccak256("") = c5d2..., ncclUniqueId is 128 bytes
