@@ -61,6 +61,7 @@ uint64_t plk_srs_size(const plk_ctx *ctx);
 /* Crs::crs_42(size, &Worker) generalised (src/plonk.rs:30-48, `plonkit setup`): fills the resident SRS
  * with tau^(start+i)*G, i < n, computed on the GPU; tau = 42 reproduces the reference's local keys. */
 int32_t plk_srs_generate(plk_ctx *ctx, uint64_t n, uint64_t start, uint32_t tau);
+int32_t plk_srs_generate_fr(plk_ctx *ctx, uint64_t n, uint64_t start, const plk_fr *tau);     /* any tau (test keys only: tau is public) */
 int32_t plk_srs_download(plk_ctx *ctx, uint64_t offset, uint64_t n, plk_g1_affine *out_host);
 /* optional: builds now what the first commitment against the resident key(s) would build — the fixed-base table of the
  * MSM (15 shifted copies of the points, ~40 ms at 2^20 points).  A host program calls it on a second thread while it is

@@ -180,6 +180,10 @@ class Context:
         """Crs::crs_42 on the GPU (src/plonk.rs:30-48): resident SRS <- tau^(start+i) * G."""
         _check(lib().plk_srs_generate(self._h, ctypes.c_uint64(n), ctypes.c_uint64(start), ctypes.c_uint32(tau)))
 
+    def srs_generate_fr(self, n, start, tau_mont):
+        t = np.ascontiguousarray(tau_mont, dtype=np.uint64)
+        _check(lib().plk_srs_generate_fr(self._h, ctypes.c_uint64(n), ctypes.c_uint64(start), _np(t)))
+
     def srs_download(self, offset, n):
         out = np.zeros((n, 8), dtype=np.uint64)
         _check(lib().plk_srs_download(self._h, ctypes.c_uint64(offset), ctypes.c_uint64(n), _np(out)))

@@ -5,6 +5,7 @@
 // tau^(start) * G, then "multiply by tau" steps, each converted to affine with one Fermat inversion.
 #include "ctx.h"
 #include "ec_dev.h"
+#include <cstring>
 
 namespace plk {
 
@@ -38,9 +39,41 @@ __global__ void __launch_bounds__(256) srs_powers_kernel(G1Affine *out, uint64_t
     }
 }
 
+// general tau (any field element): one full double-and-add per point, no run sharing — 16x the work of the small-tau kernel,
+// still a fraction of a second at 2^20 points
+__global__ void __launch_bounds__(256) srs_powers_general_kernel(G1Affine *out, uint64_t start, uint64_t n, Fr tau) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr k = to_canonical(pow_u64(tau, start + i));
+    G1Affine g; g.x = from_u64<FqParams>(1); g.y = from_u64<FqParams>(2);
+    G1Xyzz p = xyzz_identity();
+    for (int bit = 253; bit >= 0; bit--) {
+        p = xyzz_double(p);
+        if ((k.l[bit >> 5] >> (bit & 31)) & 1) xyzz_add_mixed(p, g, false);
+    }
+    const G1Affine a = xyzz_to_affine_dev(p);
+    store_fp(&out[i].x, a.x);
+    store_fp(&out[i].y, a.y);
+}
+
 }  // namespace plk
 
 using namespace plk;
+
+// the same for an arbitrary tau given as a field element (Montgomery, as everywhere at this boundary)
+extern "C" int32_t plk_srs_generate_fr(plk_ctx *ctx, uint64_t n, uint64_t start, const plk_fr *tau) {
+    if (!ctx || n == 0 || !tau) { set_error("plk_srs_generate_fr: bad argument"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(ctx->srs_own.reserve(n * sizeof(G1Affine)));
+    Fr t; memcpy(t.l, tau->l, 32);
+    hipLaunchKernelGGL(srs_powers_general_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->srs_own.as<G1Affine>(), start, n, t);
+    PLK_HIP(hipGetLastError());
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->srs = ctx->srs_own.p;
+    ctx->srs_n = n;
+    ctx->srs_w_valid = false;
+    return PLK_OK;
+}
 
 // Fills the context's resident SRS with tau^(start+i) * G, i < n, tau a small integer (42 for crs_42).
 extern "C" int32_t plk_srs_generate(plk_ctx *ctx, uint64_t n, uint64_t start, uint32_t tau) {

@@ -107,6 +107,20 @@ def test_crs42_generation_matches_golden_key(ctx, golden_crs):
     assert np.array_equal(ctx.srs_download(0, 24), golden_crs.g1[1000:1024])
 
 
+def test_srs_generation_with_a_general_tau(ctx):
+    """plk_srs_generate_fr: tau as a field element; point i = tau^(start + i) * G, and the MSM trapdoor identity holds"""
+    tau = 0x1234567890abcdef1234567890abcdef1234567890abcdef % R_MOD
+    ctx.srs_generate_fr(300, 5, ol.fr_mont(tau))
+    pts = ctx.srs_download(0, 300)
+    for i in (0, 1, 17, 299):
+        assert np.array_equal(pts[i], ol.g1_mul(ol.g1_generator(), pow(tau, 5 + i, R_MOD))), i
+    ks = [(7 * i + 3) % R_MOD for i in range(300)]
+    want = ol.g1_mul(ol.g1_generator(), sum(k * pow(tau, 5 + i, R_MOD) for i, k in enumerate(ks)) % R_MOD)
+    assert np.array_equal(ctx.msm(ol.fr_vec(ks)), want)
+    ctx.srs_generate_fr(40, 0, ol.fr_mont(42))
+    assert np.array_equal(ctx.srs_download(0, 40), ol.crs42(40))
+
+
 def test_native_synthetic_circuit_prove_matches_oracle(ctx):
     """the bench's native circuit generator, exported in the reference's own .r1cs/.wtns formats,
     proves to the same bytes as the oracle run on those files"""
