@@ -184,6 +184,10 @@ class Context:
         t = np.ascontiguousarray(tau_mont, dtype=np.uint64)
         _check(lib().plk_srs_generate_fr(self._h, ctypes.c_uint64(n), ctypes.c_uint64(start), _np(t)))
 
+    def srs_precompute(self):
+        """builds the MSM's fixed-base table of the resident key(s) now instead of at the first commitment"""
+        _check(lib().plk_srs_precompute(self._h))
+
     def srs_download(self, offset, n):
         out = np.zeros((n, 8), dtype=np.uint64)
         _check(lib().plk_srs_download(self._h, ctypes.c_uint64(offset), ctypes.c_uint64(n), _np(out)))
@@ -371,6 +375,20 @@ class SetupForProver:
         self.ctx = ctx
         self._h = ctypes.c_void_p()
         _check(lib().plk_setup_prepare(ctx._h, circuit._h, ctypes.byref(self._h)))
+
+    @classmethod
+    def prepare_host(cls, circuit):
+        """the CPU half only (transpile + columns): no context, no GPU; finish with upload(ctx)"""
+        self = cls.__new__(cls)
+        self.ctx = None
+        self._h = ctypes.c_void_p()
+        _check(lib().plk_setup_prepare_host(circuit._h, ctypes.byref(self._h)))
+        return self
+
+    def upload(self, ctx):
+        _check(lib().plk_setup_upload(ctx._h, self._h))
+        self.ctx = ctx
+        return self
 
     @property
     def domain_size(self):

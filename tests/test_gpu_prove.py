@@ -107,6 +107,30 @@ def test_crs42_generation_matches_golden_key(ctx, golden_crs):
     assert np.array_equal(ctx.srs_download(0, 24), golden_crs.g1[1000:1024])
 
 
+def test_two_phase_setup_and_table_precompute(ctx):
+    """plk_setup_prepare_host (pure CPU) + plk_setup_upload == plk_setup_prepare; plk_srs_precompute changes nothing but when
+    the MSM table is built; a setup that is not on the device yet is refused by prove / write_vk"""
+    import ctypes
+    import plonkit_amd as pa
+    n = 1 << 13
+    circ = pa.Circuit.synthetic(n - 2)
+    ctx.srs_generate(n, 0, 42)
+    ctx.srs_lagrange_clear()
+    one = pa.SetupForProver(ctx, circ)
+    want = (one.verification_key_bytes(pa.crs42_g2_bytes()), one.prove(circ))
+    two = pa.SetupForProver.prepare_host(circ)
+    assert two.domain_size == n
+    buf, ln = ctypes.create_string_buffer(1 << 16), ctypes.c_uint64(0)
+    assert pa.lib().plk_prove(ctx._h, two._h, circ._h, buf, ctypes.c_uint64(1 << 16), ctypes.byref(ln)) == 1      # PLK_ERR_ARG: not uploaded
+    fresh = pa.Context(0)
+    fresh.srs_generate(n, 0, 42)
+    fresh.srs_precompute()
+    two.upload(fresh)
+    two.upload(fresh)                                                  # idempotent
+    assert (two.verification_key_bytes(pa.crs42_g2_bytes()), two.prove(circ)) == want
+    two.close(); one.close(); fresh.close()
+
+
 def test_srs_generation_with_a_general_tau(ctx):
     """plk_srs_generate_fr: tau as a field element; point i = tau^(start + i) * G, and the MSM trapdoor identity holds"""
     tau = 0x1234567890abcdef1234567890abcdef1234567890abcdef % R_MOD
