@@ -28,6 +28,7 @@
 #include "ntt.h"
 #include "poly.h"
 #include "field29_dev.h"
+#include <cstdlib>
 
 namespace plk {
 
@@ -46,7 +47,11 @@ struct NttPassArgs {
     Fr scale;                                  // optional 1/n on the last pass
     uint32_t has_scale;
     uint32_t nonzero;                          // first pass: input elements at index >= nonzero are zero and are
-};                                             // neither read nor scaled (zero-padded LDE); 0 = the whole vector
+                                               // neither read nor scaled (zero-padded LDE); 0 = the whole vector
+    const Fr *tw_direct;                       // optional (ntt_pass_cols): the inter-pass twiddles of this pass as a table,
+                                               // entry (k << log_inner | column), W domain, 1/n folded in on inverse transforms
+    uint32_t quarter;                          // first pass of an LDE by 4 with an even number of stages: only every fourth
+};                                             // (bit-reversed) row is non-zero, the first pair of stages is a broadcast
 
 // ---- all butterfly arithmetic runs on the carry-free 9 x 29-bit layer (field29_dev.h): data words are
 // ---- re-sliced, never converted; the constants (twiddles, coset powers, 1/n) live in its 2^261 domain.
@@ -139,9 +144,20 @@ __device__ __forceinline__ void r4_finish(const Radix4Group &q, const LdsTile &L
     L.put(q.a1, normw(o1)); L.put(q.a3, normw(o3));
 }
 
-__device__ __forceinline__ void dit_stages(const LdsTile &L, const PowTable &tw, uint32_t log_r, uint32_t log_c, uint32_t pitch, uint32_t tid) {
+__device__ __forceinline__ void dit_stages(const LdsTile &L, const PowTable &tw, uint32_t log_r, uint32_t log_c, uint32_t pitch, uint32_t tid,
+                                           bool quarter = false) {
     const uint32_t C = 1u << log_c, half_tile = 1u << (log_r + log_c - 1), quarter_tile = half_tile >> 1;
     uint32_t s = 0;
+    if (quarter) {                                            // rows 4j+1..4j+3 hold zeros: stages 0 and 1 copy row 4j into them
+        for (uint32_t g = tid; g < quarter_tile; g += NTT_THREADS) {
+            const uint32_t c = g & (C - 1), j = g >> log_c;
+            const uint32_t a0 = (j << 2) * pitch + c;
+            const FrW9 x = L.get(a0);
+            L.put(a0 + pitch, x); L.put(a0 + 2 * pitch, x); L.put(a0 + 3 * pitch, x);
+        }
+        __syncthreads();
+        s = 2;
+    }
     if (log_r & 1) {                                          // odd number of stages: one twiddle-free radix-2 stage first
         for (uint32_t b = tid; b < half_tile; b += NTT_THREADS) {
             uint32_t c = b & (C - 1), j = b >> log_c;
@@ -185,13 +201,15 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
         L.put(idx, v);
     }
     __syncthreads();
-    dit_stages(L, a.tw, log_r, log_c, C, tid);
+    dit_stages(L, a.tw, log_r, log_c, C, tid, a.quarter != 0);
     const uint32_t eshift = MAX_LOG_N - (log_r + a.log_inner);
     for (uint32_t idx = tid; idx < T; idx += NTT_THREADS) {
         uint32_t c = idx & (C - 1), k = idx >> log_c;
         uint32_t e = (k * (c0 + c)) << eshift;
-        // sub-transforms of <= 2^14 points only touch the hi table (the low 14 exponent bits are zero): no composition
-        const FrW9 t = eshift >= POW_SPLIT ? ldw(a.tw.hi + (e >> POW_SPLIT)) : pow2l_w(a.tw, e);
+        // sub-transforms of <= 2^14 points only touch the hi table (the low 14 exponent bits are zero): no composition;
+        // larger ones read the twiddle from the pass's own table when there is one (one load instead of a product)
+        const FrW9 t = a.tw_direct ? ldw(a.tw_direct + ((size_t)k << a.log_inner) + c0 + c)
+                     : eshift >= POW_SPLIT ? ldw(a.tw.hi + (e >> POW_SPLIT)) : pow2l_w(a.tw, e);
         FrW9 v = mulw(L.get(idx), t);                                         // < 1.1p: fits 256 bits, stays lazy
         store_fp(a.out + base + ((size_t)k << a.log_inner) + c, pack<FrParams>(v));
     }
@@ -355,6 +373,53 @@ int32_t ntt_coset_table(plk_ctx *ctx, const Fr &g, PowTable *out) {
     return PLK_OK;
 }
 
+// ------------------------------------------------------------------------------- inter-pass twiddle tables
+// A pass over a sub-transform of more than 2^14 points used to compose every inter-pass twiddle from the two-level
+// table (one product per element, a tenth of the transform's arithmetic at 2^20).  The passes are bound by
+// instruction issue and use 6 % of the HBM bandwidth, so the twiddles of such a pass are kept as a table of their
+// own instead — 32 B more read per element and pass — with 1/n folded into the first table of an inverse transform
+// (the last pass then only canonicalises).  Built at the first use of a (direction, digit plan) pair, kept for
+// the life of the context; 32 MiB per table at 2^20, capped at 1 GiB (2^25 entries): beyond that, and with
+// PLK_NTT_DIRECT=0, the passes compose as before.
+__global__ void ntt_fill_direct(Fr *out, PowTable tw, uint32_t log_r, uint32_t log_inner, Fr scale_w, uint32_t has_scale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> (log_r + log_inner)) return;
+    const uint32_t k = (uint32_t)(i >> log_inner), col = (uint32_t)i & ((1u << log_inner) - 1);
+    const uint32_t e = (k * col) << (MAX_LOG_N - (log_r + log_inner));
+    FrW9 v = pow2l_w(tw, e);
+    if (has_scale) v = mulw(csub_p(v), unpack<FrW>(scale_w));
+    store_fp(out + i, pack<FrParams>(csub_p(v)));
+}
+
+constexpr uint32_t NTT_DIRECT_MAX_LOG = 25;
+
+static bool ntt_direct_enabled() {
+    static const int on = [] { const char *e = getenv("PLK_NTT_DIRECT"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+
+// returns nullptr (and PLK_OK) when the pass should compose its twiddles
+static int32_t ntt_direct_table(plk_ctx *ctx, bool inverse, uint32_t log_r, uint32_t log_inner, bool scaled, uint32_t log_n,
+                                hipStream_t stream, const Fr **out) {
+    *out = nullptr;
+    const uint32_t bits = log_r + log_inner;
+    if (!ntt_direct_enabled() || MAX_LOG_N - bits >= POW_SPLIT || bits > NTT_DIRECT_MAX_LOG) return PLK_OK;
+    const uint32_t key = (inverse ? 1u << 31 : 0) | (scaled ? log_n << 16 : 0) | log_r << 8 | log_inner;
+    auto it = ctx->ntt_direct.find(key);
+    if (it != ctx->ntt_direct.end()) { *out = static_cast<const Fr *>(it->second); return PLK_OK; }
+    Fr *buf = nullptr;
+    if (hipMalloc(&buf, sizeof(Fr) << bits) != hipSuccess) { (void)hipGetLastError(); return PLK_OK; }   // no room: compose
+    const PowTable &tw = inverse ? ctx->tw_inv_w : ctx->tw_fwd_w;
+    hipLaunchKernelGGL(ntt_fill_direct, dim3((uint32_t)((((size_t)1 << bits) + 255) / 256)), dim3(256), 0, stream, buf, tw, log_r, log_inner,
+                       scaled ? ctx->n_inv_w[log_n] : Fr::zero(), scaled ? 1u : 0u);
+    PLK_HIP(hipGetLastError());
+    PLK_HIP(hipStreamSynchronize(stream));                 // other streams may use the table right after this call
+    ctx->ntt_direct[key] = buf;
+    ctx->coset_allocs.push_back(buf);
+    *out = buf;
+    return PLK_OK;
+}
+
 // ------------------------------------------------------------------------------- driver
 static bool g_attr_set = false;
 
@@ -400,6 +465,7 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *src, uint64_t nonzero, Fr *data, 
     a.tw = inverse ? ctx->tw_inv_w : ctx->tw_fwd_w;
     // ping-pong: pass 1 data -> scratch, middle passes in place in scratch, last pass scratch -> data
     uint32_t rem = log_n;
+    bool scale_folded = false;
     for (uint32_t i = 0; i + 1 < p; i++) {
         rem -= d[i];
         a.in = (i == 0) ? src : scratch; a.out = scratch;
@@ -408,6 +474,9 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *src, uint64_t nonzero, Fr *data, 
         a.log_c = (LOG_TILE - d[i]) < rem ? (LOG_TILE - d[i]) : rem;
         a.pre = (i == 0) ? pre : PowTable{};
         a.post = PowTable{}; a.has_scale = 0;
+        PLK_TRY(ntt_direct_table(ctx, inverse, d[i], rem, inverse && i == 0, log_n, stream, &a.tw_direct));
+        if (a.tw_direct && inverse && i == 0) scale_folded = true;
+        a.quarter = (i == 0 && nonzero && nonzero == (n >> 2) && !(d[0] & 1) && d[0] >= 2) ? 1 : 0;
         uint32_t tiles = (uint32_t)(n >> (a.log_r + a.log_c));
         size_t lds = (size_t)36 << (a.log_r + a.log_c);
         hipLaunchKernelGGL(ntt_pass_cols, dim3(tiles), dim3(NTT_THREADS), lds, stream, a);
@@ -425,8 +494,9 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *src, uint64_t nonzero, Fr *data, 
         }
         a.pre = (p == 1) ? pre : PowTable{};
         a.post = post;
-        a.has_scale = inverse ? 1 : 0;
-        if (inverse) a.scale = ctx->n_inv_w[log_n];
+        a.tw_direct = nullptr; a.quarter = 0;
+        a.has_scale = (inverse && !scale_folded) ? 1 : 0;
+        if (a.has_scale) a.scale = ctx->n_inv_w[log_n];
         uint32_t tiles = (uint32_t)(n >> (a.log_r + a.log_c));
         size_t lds = (size_t)36 << (a.log_r + a.log_c);
         hipLaunchKernelGGL(ntt_pass_rows, dim3(tiles), dim3(NTT_THREADS), lds, stream, a);
