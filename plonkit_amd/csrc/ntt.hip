@@ -20,9 +20,11 @@
 //     never converted; only the constants (twiddles, coset powers, 1/n) live in its 2^261 domain.
 //   * coset shift (g^i on load), 1/n and g^-i (on store) are fused into the first / last pass; powers come
 //     from two-level tables (base^(lo + 2^14*hi)), one multiply per use — none when the low part is zero
-//     (sub-transforms of <= 2^14 points).  A zero-padded input (LDE) is read in place: indices beyond the
-//     coefficient count are neither loaded nor scaled.  Outputs are made canonical by a quotient-estimate
-//     reduction, not by a product.
+//     (sub-transforms of <= 2^14 points).  The twiddles between the passes of a larger transform are read from
+//     a table built per (direction, digit plan) at first use (ntt_direct_table below; 1/n folded in).  A
+//     zero-padded input (LDE) is read in place: indices beyond the coefficient count are neither loaded nor
+//     scaled, and the first pair of stages of its first pass is a copy.  Outputs are made canonical by a
+//     quotient-estimate reduction, not by a product.
 //   * No MFMA: this is 256-bit modular integer arithmetic, bound by v_mad_u64_u32 issue.
 #include "ctx.h"
 #include "ntt.h"
