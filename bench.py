@@ -439,7 +439,7 @@ def main():
     stream = torch.cuda.Stream(device=device)
     multi = world > 1 or force_dist
     if multi:
-        # the exchange of the partial sums runs inside the library (comm.cpp: ncclAllGather on the context's stream + host
+        # the exchange of the partial sums runs inside the library (comm.cpp: ncclAllGather on the communicator's own stream + host
         # EC sum); torch.distributed only carries the 128-byte RCCL id to the other ranks and the timing barriers
         if share:
             ctx.comm_init_tcp(rank, world, int(os.environ.get("MASTER_PORT", "29500")) + 17, rank * n)

@@ -132,7 +132,7 @@ int32_t plk_set_commit_shard(plk_ctx *ctx, uint64_t first_index, plk_combine_fn 
  *                 plk_srs_upload(ctx, key + first_index, n_local)      (or plk_srs_generate(ctx, n_local, first_index, tau))
  *                 plk_setup_prepare / plk_setup_write_vk / plk_prove as on one GPU: identical bytes on every rank
  *      plk_comm_init creates the communicator on the context's device (ncclCommInitRank — collective: every rank must
- *      call it) and installs the built-in combiner: one ncclAllGather of count x 96 bytes on the context's stream per
+ *      call it) and installs the built-in combiner: one ncclAllGather of count x 96 bytes on a stream of its own per
  *      batch of commitments, then world-1 host EC additions each (EC addition is not an RCCL reduction op).
  *      RCCL is bound at run time (librccl.so.1); without it these calls return PLK_ERR_HIP and everything else works.
  *      plk_comm_init_tcp is the same combiner over a TCP hub on 127.0.0.1:port (rank 0 listens) for the one case RCCL

@@ -89,7 +89,8 @@ struct Comm {
     int rank = 0, world = 1;
     // RCCL transport
     ncclComm_t nccl = nullptr;
-    DevBuf d_send, d_recv;
+    hipStream_t stream = nullptr;            // the exchange has a stream of its own: synchronising the context's main stream
+    DevBuf d_send, d_recv;                   // would wait for whatever the prover overlaps with the commitments (LDEs)
     // TCP hub transport (rank 0 listens; fds[r] = connection of rank r on the hub, fds[0] = the hub's socket on a spoke)
     bool tcp = false;
     int listen_fd = -1;
@@ -116,7 +117,8 @@ static int32_t gather(Comm *C, const plk_g1_jacobian *mine, uint32_t count, plk_
         return PLK_OK;
     }
     Rccl *R = rccl();
-    hipStream_t st = C->ctx->stream;
+    PLK_HIP(hipSetDevice(C->ctx->device));
+    hipStream_t st = C->stream;
     PLK_TRY(C->d_send.reserve(8 * sizeof(plk_g1_jacobian)));
     PLK_TRY(C->d_recv.reserve((size_t)C->world * 8 * sizeof(plk_g1_jacobian)));
     PLK_HIP(hipMemcpyAsync(C->d_send.p, mine, bytes, hipMemcpyHostToDevice, st));
@@ -148,6 +150,7 @@ static int32_t builtin_combine(void *user, plk_g1_jacobian *sums, uint32_t count
 static void comm_free(Comm *C) {
     if (!C) return;
     if (C->nccl) { Rccl *R = rccl(); if (R) (void)R->CommDestroy(C->nccl); }
+    if (C->stream) (void)hipStreamDestroy(C->stream);
     C->d_send.release(); C->d_recv.release();
     for (int fd : C->fds) if (fd >= 0) ::close(fd);
     if (C->listen_fd >= 0) ::close(C->listen_fd);
@@ -191,6 +194,7 @@ int32_t plk_comm_init(plk_ctx *ctx, int32_t rank, int32_t world, const plk_comm_
     memcpy(nid.internal, id->bytes, sizeof nid.internal);
     ncclResult_t e = R->CommInitRank(&C->nccl, world, nid, rank);
     if (e != ncclSuccess) { C->nccl = nullptr; comm_free(C); return rccl_fail(e, "ncclCommInitRank (one rank per GPU: RCCL refuses two ranks on one device)"); }
+    if (hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); comm_free(C); set_error("plk_comm_init: cannot create a stream"); return PLK_ERR_HIP; }
     ctx->comm = C;
     return plk_set_commit_shard(ctx, first_index, builtin_combine, C);
 }
