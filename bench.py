@@ -31,7 +31,7 @@ import sys
 import tempfile
 import time
 
-# the library keeps two commitments in flight on two streams; with HIP's default of 4 hardware queues per device
+# the library keeps up to three commitments in flight on three streams; with HIP's default of 4 hardware queues per device
 # those streams can land on one queue and serialise (measured: 2.04 ms per commitment instead of 1.66 ms)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -371,12 +371,12 @@ def strong_scaling_msm(ctx, dist, device, rank, world, log_total=24, reps=5):
 
 
 def time_commitments(ctx, msm, scalars, n, steps, stream, depth):
-    """K commitments back to back.  depth 2: two in flight (ShardedMsm.commit_stream); depth 1: one at a time."""
+    """K commitments back to back.  depth 2 / 3: that many in flight (ShardedMsm.commit_stream); depth 1: one at a time."""
     kernel_ms = []
     out = None
     t0 = time.perf_counter()
-    if depth == 2:
-        for out in msm.commit_stream((scalars for _ in range(steps)), n, stream=stream):
+    if depth >= 2:
+        for out in msm.commit_stream((scalars for _ in range(steps)), n, stream=stream, depth=depth):
             kernel_ms.append(ctx.msm_last_kernel_ms())
     else:
         for _ in range(steps):
@@ -395,8 +395,8 @@ def main():
     ap.add_argument("--cpu-log-n", type=int, default=20, help="log2 of the CPU-baseline samples (MSM terms, prove domain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strong-log-n", type=int, default=24, help="N > 1: log2 of the ONE commitment whose SRS is split over the ranks (configs[2]: 24)")
-    ap.add_argument("--pipeline-depth", type=int, default=2, choices=(1, 2),
-                    help="commitments in flight in the timed region (2 = the library's two-slot FIFO; 1 = one at a time: "
+    ap.add_argument("--pipeline-depth", type=int, default=3, choices=(1, 2, 3),
+                    help="commitments in flight in the timed region (3 = the library's three-slot FIFO; 1 = one at a time: "
                          "the region roofline.kernel_ms is taken from)")
     ap.add_argument("--msm-only", action="store_true", help="only the timed commitments (no cpu_baseline / prove / kernels legs): "
                                                             "the command the rocprofv3 summary under profiles/ is taken from")
@@ -478,7 +478,7 @@ def main():
         value = world * n / (elapsed / args.steps) / 1e6
         k_pipe = float(np.mean(kernel_ms))
         k_solo = float(np.mean(solo_kernel_ms))
-        k_ms = k_solo if args.pipeline_depth == 2 else k_pipe
+        k_ms = k_solo if args.pipeline_depth >= 2 else k_pipe
         achieved = ALGO_BYTES_PER_TERM * n / (k_ms * 1e-3) / 1e9
         gmadd = n * MSM_WINDOWS / (k_ms * 1e-3) / 1e9
         line = {
@@ -506,9 +506,9 @@ def main():
                                                 "loop_isolated = the same loop with its 817 non-mad instructions, alone on the chip"},
                          "note": "kernel_ms = HIP-event duration of msm_accumulate with one commitment in flight (the region timed right "
                                  "after the headline one; rocprofv3 of `bench.py --msm-only --pipeline-depth 1` agrees, profiles/); "
-                                 "kernel_ms_pipelined = the same kernel inside the headline region, where two commitments are in flight "
-                                 "and it shares the GPU with the bucket reduction of the previous one (its duration there can exceed the "
-                                 "step time: kernels of consecutive commitments overlap).  The kernel is bound by v_mad_u64_u32 issue, "
+                                 "kernel_ms_pipelined = the same kernel inside the headline region, where up to three commitments are in "
+                                 "flight and it shares the GPU with the bucket reduction of the previous one and the partition of the next "
+                                 "(its duration there can exceed the step time: kernels of consecutive commitments overlap).  The kernel is bound by v_mad_u64_u32 issue, "
                                  "not HBM (SURVEY.md §8d); `traffic` is 11x the algorithmic bytes because Pippenger gathers one "
                                  "64-byte point per (term, window): 15 windows, each from its own shifted copy of the SRS "
                                  "(0.94 GiB fixed-base table in HBM)"},

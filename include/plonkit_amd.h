@@ -89,12 +89,14 @@ int32_t plk_msm_g1_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64
 int32_t plk_msm_g1_batch_dev(plk_ctx *ctx, const void *const *scalars_dev, uint32_t count, uint64_t n, uint64_t base_offset, plk_g1_affine *out, void *stream);
 /* the same sum left in Jacobian form, for cross-rank combination (multi-GPU shards) */
 int32_t plk_msm_g1_partial_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, plk_g1_jacobian *out, void *stream);
-/* enqueue only (no host sync); finish with _finish.  The pair is a FIFO of depth TWO: the context owns two sets of MSM
- * scratch, result buffers and streams, so a second commitment can be enqueued before the first is finished — its
- * accumulation then overlaps the latency-bound bucket reduction of the first (2^20 terms: 1.5 ms per commitment back
- * to back instead of 1.85 ms).  `stream` is where the scalars were produced: the kernels run on the slot's own stream
- * after an event recorded there, and the scalars must stay untouched until the matching _finish.  A third enqueue,
- * or a finish with nothing in flight, returns PLK_ERR_ARG.                                                          */
+/* enqueue only (no host sync); finish with _finish.  The pair is a FIFO of depth THREE: the context owns three sets of
+ * MSM scratch, result buffers and streams, so two more commitments can be enqueued before the first is finished — the
+ * accumulation of commitment k then shares the GPU with the latency-bound bucket reduction of k-1 and the digit /
+ * partition kernels of k+1 (2^20 terms: 1.39 ms per commitment back to back, 1.46-1.50 with two in flight, 1.66 one
+ * at a time).  A slot is taken lowest index first: a caller that keeps two in flight never allocates the third set.
+ * `stream` is where the scalars were produced: the kernels run on the slot's own stream after an event recorded there,
+ * and the scalars must stay untouched until the matching _finish.  A fourth enqueue, or a finish with nothing in
+ * flight, returns PLK_ERR_ARG.                                                                                      */
 int32_t plk_msm_g1_enqueue_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, void *stream);
 int32_t plk_msm_g1_finish(plk_ctx *ctx, plk_g1_jacobian *out);
 /* the same FIFO with a BATCH of `count` (<= 8) commitments of equal length against the same bases per slot — the shape of the

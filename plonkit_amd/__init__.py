@@ -7,7 +7,7 @@ CPU fallback: creating a Context without a gfx950 device raises.
 """
 import os as _os
 
-# two commitments may be in flight on two HIP streams (MSM slots); give them distinct hardware queues.  Only effective
+# up to three commitments may be in flight on three HIP streams (MSM slots); give them distinct hardware queues.  Only effective
 # when set before the HIP runtime initialises, i.e. before the first GPU call of the process (import time is fine).
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 

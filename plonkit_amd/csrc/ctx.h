@@ -79,8 +79,11 @@ struct plk_ctx {
         const void *pts = nullptr; uint64_t n = 0;
         plk::DevBuf own, w; bool w_valid = false; uint32_t w_copies = 0;
     } lag;
-    // MSM: two commitments (or batches) may be in flight, each with its own scratch, result buffer and stream, so that
-    // the latency-bound tail of one (bucket reduction: <= 1 wave per SIMD) overlaps the accumulation of the next
+    // MSM: up to three commitments (or batches) may be in flight, each with its own scratch, result buffer and stream:
+    // the latency-bound tail of commitment k-1 (bucket reduction) and the digit / partition kernels of k+1 then share the
+    // GPU with the accumulation of k, which starts the moment the previous accumulation ends.  A slot is taken lowest
+    // index first, so a caller that keeps at most two in flight (the prover) never allocates the third slot's scratch.
+    static constexpr uint32_t MSM_SLOTS = 3;
     struct MsmSlot {
         plk::DevBuf a, b, c, d, e, f;
         void *pinned = nullptr; size_t pinned_cap = 0;
@@ -88,8 +91,12 @@ struct plk_ctx {
         hipStream_t stream = nullptr;        // the kernels of this commitment; ordered after the caller's stream by `ready`
         hipEvent_t ready = nullptr;
         hipEvent_t ev[2] = {nullptr, nullptr};   // optional bracket around msm_accumulate (bench roofline)
-    } slot[2];
-    uint64_t msm_enq = 0, msm_fin = 0;       // FIFO: enqueue uses slot[msm_enq & 1], finish slot[msm_fin & 1]
+        bool busy = false;
+    } slot[MSM_SLOTS];
+    uint64_t msm_enq = 0, msm_fin = 0;       // FIFO counters; commitment number k lives in slot[fifo[k % MSM_SLOTS]]
+    uint8_t fifo[MSM_SLOTS] = {0, 0, 0};
+    uint32_t last_slot = 0;                  // slot of the commitment finished last (plk_msm_last_kernel_ms)
+    MsmSlot &front_slot() { return slot[fifo[msm_fin % MSM_SLOTS]]; }
     plk::DevBuf prove_ws;                    // workspace of the prover rounds (grows only)
     plk::DevBuf poly_tmp, poly_tmp2;         // scan block totals / evaluation partials
     plk::DevBuf stage;                       // host<->device staging for the host-pointer API

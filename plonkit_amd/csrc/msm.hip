@@ -24,9 +24,9 @@
 //     sum_t S_t, sum_t t * E_t and F_1..F_3 (msm_window_sums); the remaining shifts (2^FB, 2^8), sum u * F_u and the
 //     Horner over the sets run on the host, where one serial EC chain is 20x faster than on a GPU lane.  The reduce
 //     kernels are chains of full additions issued from one inlined call site each.
-//   * up to 8 commitments over the same bases share every kernel launch (batch dimension), and two commitments
-//     (or batches) may be in flight on two streams with their own scratch: the latency-bound reduction of one
-//     overlaps the accumulation of the next.
+//   * up to 8 commitments over the same bases share every kernel launch (batch dimension), and three commitments
+//     (or batches) may be in flight on three streams with their own scratch: the latency-bound reduction of one and
+//     the digit / partition kernels of the one after next share the GPU with the accumulation in between.
 // No MFMA (256-bit modular integers), bound by v_mad_u64_u32 issue; HBM sees the algorithmic 96 B/term plus the
 // per-window gathers (64 B x W per term) from the table.
 #include "ctx.h"
@@ -673,8 +673,11 @@ static int32_t slot_pinned(plk_ctx::MsmSlot &S, size_t bytes) {
 // `caller` is the stream on which the scalars were produced; the commitment runs on its slot's own stream after an
 // event recorded there.  The caller must leave the scalars alone until the matching msm_finish_batch.
 int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t batch, uint64_t n, uint64_t base_offset, hipStream_t caller) {
-    if (ctx->msm_enq - ctx->msm_fin >= 2) { set_error("msm: two commitments are already in flight (call the finish function first)"); return PLK_ERR_ARG; }
-    plk_ctx::MsmSlot &S = ctx->slot[ctx->msm_enq & 1];
+    if (ctx->msm_enq - ctx->msm_fin >= plk_ctx::MSM_SLOTS) { set_error("msm: three commitments are already in flight (call the finish function first)"); return PLK_ERR_ARG; }
+    uint32_t slot_index = 0;
+    while (ctx->slot[slot_index].busy) slot_index++;          // lowest free slot (there is one: fewer than MSM_SLOTS are in flight)
+    plk_ctx::MsmSlot &S = ctx->slot[slot_index];
+    auto in_flight = [&]() { ctx->fifo[ctx->msm_enq % plk_ctx::MSM_SLOTS] = (uint8_t)slot_index; S.busy = true; ctx->msm_enq++; };
     if (!S.stream) {
         PLK_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
         PLK_HIP(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
@@ -703,7 +706,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     S.pending_parts = 0;
     S.windows = 0;
     S.batch = batch;
-    if (n == 0) { ctx->msm_enq++; return PLK_OK; }
+    if (n == 0) { in_flight(); return PLK_OK; }
     if (n < 4096) {
         uint32_t blocks = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
         PLK_TRY(S.d.reserve((size_t)batch * blocks * sizeof(G1Xyzz)));
@@ -714,7 +717,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
         S.c_bits = 0;
         PLK_TRY(slot_pinned(S, (size_t)batch * blocks * sizeof(G1Xyzz)));
         PLK_HIP(hipMemcpyAsync(S.pinned, S.d.p, (size_t)batch * blocks * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
-        ctx->msm_enq++;
+        in_flight();
         return PLK_OK;
     }
     MsmParams p;
@@ -793,7 +796,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     S.windows = p.groups;
     S.c_bits = p.c;
     S.fine_bits = p.fine_bits;
-    ctx->msm_enq++;
+    in_flight();
     return PLK_OK;
 }
 
@@ -818,8 +821,10 @@ static host::HJac xyzz_host_to_jac(const uint64_t *v) {
 int32_t msm_finish_batch(plk_ctx *ctx, hipStream_t, host::HJac *out) {
     using namespace host;
     if (ctx->msm_fin == ctx->msm_enq) { set_error("msm: nothing in flight"); return PLK_ERR_ARG; }
-    plk_ctx::MsmSlot &S = ctx->slot[ctx->msm_fin & 1];
+    plk_ctx::MsmSlot &S = ctx->front_slot();
+    ctx->last_slot = ctx->fifo[ctx->msm_fin % plk_ctx::MSM_SLOTS];
     ctx->msm_fin++;
+    S.busy = false;
     PLK_HIP(hipStreamSynchronize(S.stream));
     for (uint32_t m = 0; m < S.batch; m++) {
         HJac acc = HJac::inf();
@@ -846,7 +851,7 @@ int32_t msm_finish_batch(plk_ctx *ctx, hipStream_t, host::HJac *out) {
 }
 
 int32_t msm_finish(plk_ctx *ctx, hipStream_t stream, host::HJac *out) {
-    if (ctx->msm_fin != ctx->msm_enq && ctx->slot[ctx->msm_fin & 1].batch != 1) { set_error("msm_finish: a batch is pending"); return PLK_ERR_ARG; }
+    if (ctx->msm_fin != ctx->msm_enq && ctx->front_slot().batch != 1) { set_error("msm_finish: a batch is pending"); return PLK_ERR_ARG; }
     return msm_finish_batch(ctx, stream, out);
 }
 
@@ -871,7 +876,7 @@ int32_t plk_msm_g1_enqueue_batch_dev(plk_ctx *ctx, const void *const *scalars_de
 }
 static int32_t finish_batch_checked(plk_ctx *ctx, uint32_t count, host::HJac *j) {
     if (ctx->msm_fin == ctx->msm_enq) { set_error("msm: nothing in flight"); return PLK_ERR_ARG; }
-    if (ctx->slot[ctx->msm_fin & 1].batch != count) { set_error("plk_msm_g1_finish_batch: the commitment in flight holds a different batch size"); return PLK_ERR_ARG; }
+    if (ctx->front_slot().batch != count) { set_error("plk_msm_g1_finish_batch: the commitment in flight holds a different batch size"); return PLK_ERR_ARG; }
     return msm_finish_batch(ctx, nullptr, j);
 }
 int32_t plk_msm_g1_finish_batch(plk_ctx *ctx, plk_g1_jacobian *out, uint32_t count) {
@@ -988,7 +993,7 @@ int32_t plk_set_kernel_timing(plk_ctx *ctx, int32_t on) {
 int32_t plk_msm_last_kernel_ms(plk_ctx *ctx, float *accumulate_ms) {
     if (!ctx || !accumulate_ms) { set_error("plk_msm_last_kernel_ms: bad argument"); return PLK_ERR_ARG; }
     if (!ctx->ev_on || ctx->msm_fin == 0) { set_error("kernel timing is off (plk_set_kernel_timing) or no commitment finished yet"); return PLK_ERR_ARG; }
-    plk_ctx::MsmSlot &S = ctx->slot[(ctx->msm_fin - 1) & 1];                  // the commitment finished last
+    plk_ctx::MsmSlot &S = ctx->slot[ctx->last_slot];                          // the commitment finished last
     if (!S.ev[0]) { set_error("the last commitment was enqueued with kernel timing off"); return PLK_ERR_ARG; }
     PLK_HIP(hipEventSynchronize(S.ev[1]));
     PLK_HIP(hipEventElapsedTime(accumulate_ms, S.ev[0], S.ev[1]));

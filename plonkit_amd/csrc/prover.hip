@@ -69,7 +69,7 @@ static int32_t enqueue_pieces(plk_ctx *ctx, const Fr *const *vecs, uint32_t cnt,
     return PLK_OK;
 }
 static int32_t finish_pieces(plk_ctx *ctx, uint32_t cnt, HJac *j) {
-    if (ctx->msm_fin != ctx->msm_enq && ctx->slot[ctx->msm_fin & 1].batch != cnt) {      // never pop somebody else's commitment
+    if (ctx->msm_fin != ctx->msm_enq && ctx->front_slot().batch != cnt) {      // never pop somebody else's commitment
         set_error("commitment FIFO out of step: the slot in flight holds a different batch than the prover enqueued"); return PLK_ERR_ARG; }
     PLK_TRY(msm_finish_batch(ctx, nullptr, j));
     if (!ctx->commit_pieces.empty()) {

@@ -75,7 +75,7 @@ int32_t plk_device_count(void) {
 }
 
 int32_t plk_create(int32_t device, plk_ctx **out) {
-    // two commitments may be in flight on two streams (MsmSlot): ask for enough hardware queues that they do not
+    // up to three commitments may be in flight on three streams (MsmSlot): ask for enough hardware queues that they do not
     // share one (HIP's default is 4 per device; no effect if the runtime is already initialised by the host program)
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
     if (!out) { set_error("plk_create: null out"); return PLK_ERR_ARG; }

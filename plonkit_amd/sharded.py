@@ -8,6 +8,8 @@ the sharded commitment is mathematically the same sum commit_using_monomials com
 """
 import os
 
+import collections
+
 import numpy as np
 import torch
 
@@ -48,42 +50,54 @@ class ShardedMsm:
         self.ctx.msm_enqueue_dev(scalars_dev, n, base_offset, stream=stream)
         return self._finish()
 
-    def commit_stream(self, batches, n, base_offset=0, stream=None):
-        """Generator over a sequence of scalar vectors.  The library keeps two commitments in flight (two scratch
-        sets, two streams): k+1 is enqueued before k is finished, so the latency-bound bucket reduction of k, its
-        host Horner and its exchange (all_gather + host EC sum) all overlap the accumulation of k+1 — the overlap
-        SURVEY.md §8(e) asks for.  The scalars of a commitment must stay untouched until it has been yielded."""
+    def commit_stream(self, batches, n, base_offset=0, stream=None, depth=3):
+        """Generator over a sequence of scalar vectors.  The library keeps up to three commitments in flight (three
+        scratch sets, three streams): k+1 and k+2 are enqueued before k is finished, so the latency-bound bucket
+        reduction of k, its host Horner and its exchange (all_gather + host EC sum) overlap the accumulation of k+1, and
+        the digit / partition kernels of k+2 are done by the time that accumulation ends — the overlap SURVEY.md §8(e)
+        asks for.  depth = 2 or 1 keeps fewer in flight.  The scalars of a commitment must stay untouched until it has
+        been yielded (the generator holds a reference to them until then)."""
         it = iter(batches)
-        cur = next(it, None)
-        if cur is None:
-            return
-        self.ctx.msm_enqueue_dev(cur, n, base_offset, stream=stream)
-        while cur is not None:
-            cur = next(it, None)
-            if cur is not None:                                # two commitments in flight: k+1 is accumulating while
-                self.ctx.msm_enqueue_dev(cur, n, base_offset, stream=stream)   # k reduces its buckets and is exchanged
-            yield self._finish()                               # waits for commitment k, host Horner over the windows, exchange
+        held = collections.deque()
+        exhausted = False
+        while True:
+            while not exhausted and len(held) < depth:
+                cur = next(it, None)
+                if cur is None:
+                    exhausted = True
+                    break
+                self.ctx.msm_enqueue_dev(cur, n, base_offset, stream=stream)
+                held.append(cur)
+            if not held:
+                return
+            out = self._finish()                               # waits for the oldest commitment, host Horner over the windows, exchange
+            held.popleft()
+            yield out
 
-
-    def commit_batches(self, batches, n, base_offset=0, stream=None):
+    def commit_batches(self, batches, n, base_offset=0, stream=None, depth=3):
         """the same pipeline with a BATCH of vectors per slot (the prover's shape: 4 wire / 4 quotient commitments share one
         pass of the kernels): `batches` yields lists of up to 8 scalar vectors; yields [count, 8] affine commitments per
-        batch, two batches in flight.  Needs native=True when ranks > 1 (one exchange per batch inside the library)."""
+        batch, up to `depth` batches in flight.  Needs native=True when ranks > 1 (one exchange per batch inside the library)."""
         it = iter(batches)
-        cur = next(it, None)
-        if cur is None:
-            return
-        self.ctx.msm_enqueue_batch_dev(cur, n, base_offset, stream=stream)
-        while cur is not None:
-            nxt = next(it, None)
-            if nxt is not None:
-                self.ctx.msm_enqueue_batch_dev(nxt, n, base_offset, stream=stream)
+        held = collections.deque()
+        exhausted = False
+        while True:
+            while not exhausted and len(held) < depth:
+                cur = next(it, None)
+                if cur is None:
+                    exhausted = True
+                    break
+                self.ctx.msm_enqueue_batch_dev(cur, n, base_offset, stream=stream)
+                held.append(cur)
+            if not held:
+                return
+            cur = held[0]
             if self.native:
                 out = self.ctx.msm_finish_batch_sharded(len(cur))
             else:
                 out = np.stack([combine_partials(p, self.dist, self.device) for p in self.ctx.msm_finish_batch(len(cur))])
+            held.popleft()
             yield out
-            cur = nxt
 
 
 # Montgomery form of 1 in Fq (R mod q): the Z coordinate of an affine point written back as Jacobian

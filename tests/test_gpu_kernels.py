@@ -203,32 +203,41 @@ def test_msm_above_2pow20_on_a_fresh_context(log_n):
     c.close()
 
 
-def test_two_commitments_in_flight(ctx, srs16):
-    """plk_msm_g1_enqueue_dev / plk_msm_g1_finish are a FIFO of depth two (two scratch sets, two streams): results come
-    back in order and equal the one-at-a-time results; a third enqueue is refused until something is finished;
-    batches and single commitments may alternate."""
+def test_commitments_in_flight(ctx, srs16):
+    """plk_msm_g1_enqueue_dev / plk_msm_g1_finish are a FIFO of depth three (three scratch sets, three streams): results
+    come back in order and equal the one-at-a-time results; a fourth enqueue is refused until something is finished;
+    slots are reused in any interleaving of enqueue and finish; every pipeline depth of commit_stream gives the same."""
     import torch
     import plonkit_amd as pa
     from plonkit_amd.sharded import ShardedMsm
     ctx.srs_upload(srs16)
     n = 1 << 16
     dev = torch.device("cuda:0")
-    vecs = [torch.from_numpy(_rand_fr(n, 500 + k).view(np.int64)).to(dev) for k in range(5)]
+    vecs = [torch.from_numpy(_rand_fr(n, 500 + k).view(np.int64)).to(dev) for k in range(7)]
     torch.cuda.synchronize()
     single = [np.asarray(ctx.msm_dev(v, n)) for v in vecs]
+    fin = lambda: pa.g1_sum_jacobian(ctx.msm_finish())
     ctx.msm_enqueue_dev(vecs[0], n)
     ctx.msm_enqueue_dev(vecs[1], n)
-    with pytest.raises(pa.PlkError):
-        ctx.msm_enqueue_dev(vecs[2], n)
-    a = pa.g1_sum_jacobian(ctx.msm_finish())
     ctx.msm_enqueue_dev(vecs[2], n)
-    b = pa.g1_sum_jacobian(ctx.msm_finish())
-    c = pa.g1_sum_jacobian(ctx.msm_finish())
-    assert np.array_equal(a, single[0]) and np.array_equal(b, single[1]) and np.array_equal(c, single[2])
+    with pytest.raises(pa.PlkError):
+        ctx.msm_enqueue_dev(vecs[3], n)
+    a = fin()
+    ctx.msm_enqueue_dev(vecs[3], n)                               # takes the slot commitment 0 left
+    b = fin()
+    c = fin()
+    ctx.msm_enqueue_dev(vecs[4], n)
+    ctx.msm_enqueue_dev(vecs[5], n)
+    d, e = fin(), fin()
+    ctx.msm_enqueue_dev(vecs[6], n)
+    f, g = fin(), fin()
+    for got, want in zip((a, b, c, d, e, f, g), single):
+        assert np.array_equal(got, want)
     with pytest.raises(pa.PlkError):
         ctx.msm_finish()                                          # nothing in flight
-    got = list(ShardedMsm(ctx, None, dev).commit_stream(iter(vecs), n))
-    assert len(got) == 5 and all(np.array_equal(g, s) for g, s in zip(got, single))
+    for depth in (1, 2, 3):
+        got = list(ShardedMsm(ctx, None, dev).commit_stream(iter(vecs), n, depth=depth))
+        assert len(got) == 7 and all(np.array_equal(g, s) for g, s in zip(got, single)), depth
     assert all(np.array_equal(np.asarray(g), s) for g, s in zip(ctx.msm_batch_dev(vecs, n), single))
 
 

@@ -93,10 +93,15 @@ def _stream_worker(rank, world, port, n_per_rank, q):
             vecs.append(s)
         shard = _OracleShard(srs[lo:hi])
         msm = ShardedMsm(shard, dist, None)
-        got = list(msm.commit_stream((v[lo:hi] for v in vecs), n_per_rank))
+        got = list(msm.commit_stream((v[lo:hi] for v in vecs), n_per_rank, depth=2))
         ok = all(np.array_equal(g, ol.msm(srs, v, threads=2)) for g, v in zip(got, vecs))
         # two in flight: commitment k+1 is enqueued before commitment k is finished and exchanged
         ok = ok and shard.log == ["enqueue", "enqueue", "finish", "enqueue", "finish", "finish"]
+        # the default keeps three in flight (the library's FIFO depth)
+        shard.log.clear()
+        got3 = list(msm.commit_stream((v[lo:hi] for v in vecs + vecs[:1]), n_per_rank))
+        ok = ok and len(got3) == 4 and all(np.array_equal(a, b) for a, b in zip(got3, got + got[:1]))
+        ok = ok and shard.log == ["enqueue"] * 3 + ["finish", "enqueue"] + ["finish"] * 3
         q.put((rank, bool(ok), len(got)))
     finally:
         dist.destroy_process_group()

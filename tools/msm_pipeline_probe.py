@@ -1,4 +1,4 @@
-"""back-to-back commitments: one at a time vs two in flight (ShardedMsm.commit_stream)"""
+"""back-to-back commitments: one at a time vs several in flight (ShardedMsm.commit_stream)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
