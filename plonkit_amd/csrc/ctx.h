@@ -94,7 +94,7 @@ struct plk_ctx {
         bool busy = false;
     } slot[MSM_SLOTS];
     uint64_t msm_enq = 0, msm_fin = 0;       // FIFO counters; commitment number k lives in slot[fifo[k % MSM_SLOTS]]
-    uint8_t fifo[MSM_SLOTS] = {0, 0, 0};
+    uint8_t fifo[MSM_SLOTS] = {};
     uint32_t last_slot = 0;                  // slot of the commitment finished last (plk_msm_last_kernel_ms)
     MsmSlot &front_slot() { return slot[fifo[msm_fin % MSM_SLOTS]]; }
     plk::DevBuf prove_ws;                    // workspace of the prover rounds (grows only)

@@ -673,7 +673,7 @@ static int32_t slot_pinned(plk_ctx::MsmSlot &S, size_t bytes) {
 // `caller` is the stream on which the scalars were produced; the commitment runs on its slot's own stream after an
 // event recorded there.  The caller must leave the scalars alone until the matching msm_finish_batch.
 int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t batch, uint64_t n, uint64_t base_offset, hipStream_t caller) {
-    if (ctx->msm_enq - ctx->msm_fin >= plk_ctx::MSM_SLOTS) { set_error("msm: three commitments are already in flight (call the finish function first)"); return PLK_ERR_ARG; }
+    if (ctx->msm_enq - ctx->msm_fin >= plk_ctx::MSM_SLOTS) { set_error("msm: " + std::to_string(plk_ctx::MSM_SLOTS) + " commitments are already in flight (call the finish function first)"); return PLK_ERR_ARG; }
     uint32_t slot_index = 0;
     while (ctx->slot[slot_index].busy) slot_index++;          // lowest free slot (there is one: fewer than MSM_SLOTS are in flight)
     plk_ctx::MsmSlot &S = ctx->slot[slot_index];
