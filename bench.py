@@ -8,7 +8,10 @@
 A step = one KZG commitment (G1 MSM) of 2^20 uniform scalars per GPU against that GPU's resident
 shard of a tau = 42 monomial SRS (BASELINE.json configs[1]; with N GPUs the job is one commitment
 of N*2^20 terms with the bases split across ranks, partial sums exchanged over RCCL — "weak").
-`value` = total scalar·muls per second over all ranks, inputs resident in HBM.
+`value` = total scalar·muls per second over all ranks, inputs resident in HBM.  Up to three commitments are in flight
+(the library's FIFO).  Before the W warm-up steps the same loop runs `--settle-steps` (50) untimed commitments: at
+1.4 ms a step, W = 5 is 7 ms of load, and the GPU reaches its sustained rate only after ~70 ms of it; the timed region is
+still exactly K steps between barrier + synchronize brackets and `config.settle_steps` says what was run.
 
 The one JSON line also carries
   roofline      dominant kernel msm_accumulate.  `kernel_ms` is its HIP-event duration with ONE commitment in flight
@@ -398,6 +401,10 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=3, choices=(1, 2, 3),
                     help="commitments in flight in the timed region (3 = the library's three-slot FIFO; 1 = one at a time: "
                          "the region roofline.kernel_ms is taken from)")
+    ap.add_argument("--settle-steps", type=int, default=50,
+                    help="untimed commitments run before the W warm-up steps: a step is 1.4 ms, so the W = 5 the driver passes is 7 ms "
+                         "of load, and the GPU needs ~70 ms of it before the loop reaches its sustained rate (DESIGN.md §5, "
+                         "profiles/r02_msm_three_in_flight_ab.txt: 1.48-1.51 ms per step without, 1.41-1.43 with, same box); 0 = off")
     ap.add_argument("--msm-only", action="store_true", help="only the timed commitments (no cpu_baseline / prove / kernels legs): "
                                                             "the command the rocprofv3 summary under profiles/ is taken from")
     args = ap.parse_args()
@@ -452,6 +459,8 @@ def main():
 
     # W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; the exchange of commitment k
     # overlaps the kernels of k+1 (ShardedMsm.commit_stream)
+    if args.settle_steps:                                 # sustained load first (see --settle-steps); reported in the line
+        time_commitments(ctx, msm, scalars, n, args.settle_steps, stream, args.pipeline_depth)
     time_commitments(ctx, msm, scalars, n, args.warmup, stream, args.pipeline_depth)
     torch.cuda.synchronize()
     if dist:
@@ -489,7 +498,7 @@ def main():
             "config": {"workload": "Pippenger G1 MSM, 2^%d uniform scalars per GPU, tau=42 monomial SRS sharded by rank "
                                    "(BASELINE.json configs[1]: SRS 2^20, single MI355X at N=1)" % args.log_n,
                        "terms_per_gpu": n, "parallelism": "srs-shard x%d + all_gather of partial sums" % world,
-                       "pipeline_depth": args.pipeline_depth,
+                       "pipeline_depth": args.pipeline_depth, "settle_steps": args.settle_steps,
                        "result_x_be": pa.g1_to_bytes(out).hex()[:64]},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
