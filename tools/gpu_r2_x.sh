@@ -1,0 +1,18 @@
+#!/bin/bash
+# accumulations in sequence only while the FIFO fills (PLK_MSM_FILL_EDGE): the driver's region (warm-up 5, 20 steps, default settle)
+cd "$(dirname "$0")/.."
+O=gpurun_out/r2x; mkdir -p $O
+show='import json,sys
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith("{")][-1]); r=d["roofline"]
+print("value %.1f M/s  ms_per_step %.4f  kernel_ms %.4f  pipelined %.4f  one_in_flight %.4f" % (d["value"], d["ms_per_step"], r["kernel_ms"], r["kernel_ms_pipelined"], r["ms_per_step_one_in_flight"]))'
+timeout 300 python tools/msm_fuzz.py 60 79 2>&1 | tail -1 | tee $O/fuzz.txt
+for rep in 1 2 3; do
+  for e in 1 0; do
+    echo "== fill edge $e, warmup 5 steps 20" | tee -a $O/ab.txt
+    PLK_MSM_FILL_EDGE=$e timeout 300 python bench.py --msm-only --warmup 5 --steps 20 2>/dev/null | python -c "$show" | tee -a $O/ab.txt
+  done
+done
+for e in 1 0; do
+  echo "== fill edge $e, warmup 5 steps 100" | tee -a $O/ab.txt
+  PLK_MSM_FILL_EDGE=$e timeout 300 python bench.py --msm-only --warmup 5 --steps 100 2>/dev/null | python -c "$show" | tee -a $O/ab.txt
+done
