@@ -122,10 +122,18 @@ __global__ void __launch_bounds__(PART_THREADS) msm_partition(const int32_t *dig
     const uint32_t w = gw % p.windows, set = (gw / p.windows) * p.groups + w % p.groups;    // bucket set of this window
     const uint32_t copy_tag = (w / p.groups) << p.nbits;                                     // which table copy its points come from
     hist_or_cursor += set * p.nbins;
+    // the thread's 16 digits are loaded up front, all loads in flight together (one dependent load per loop iteration kept a
+    // workgroup resident for ~50 us of pure memory latency — time during which it displaces an accumulate workgroup of the
+    // commitment it overlaps), and serve both passes
+    constexpr uint32_t PER = DIGIT_CHUNK / PART_THREADS;
+    int32_t dreg[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) { const uint32_t i = first + tid + k * PART_THREADS; dreg[k] = i < last ? dg[i] : 0; }
     for (uint32_t b = tid; b < p.nbins; b += PART_THREADS) lcnt[b] = 0;
     __syncthreads();
-    for (uint32_t i = first + tid; i < last; i += PART_THREADS) {
-        int32_t d = dg[i];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const int32_t d = dreg[k];
         if (d) { uint32_t mg = (uint32_t)(d < 0 ? -d : d) - 1; atomicAdd(&lcnt[mg >> p.fine_bits], 1u); }
     }
     __syncthreads();
@@ -150,9 +158,11 @@ __global__ void __launch_bounds__(PART_THREADS) msm_partition(const int32_t *dig
         lcnt[b] = 0;                                                   // reused as the in-bin cursor
     }
     __syncthreads();
-    for (uint32_t i = first + tid; i < last; i += PART_THREADS) {
-        int32_t d = dg[i];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const int32_t d = dreg[k];
         if (d) {
+            const uint32_t i = first + tid + k * PART_THREADS;
             uint32_t mg = (uint32_t)(d < 0 ? -d : d) - 1, bin = mg >> p.fine_bits;
             staged[lstart[bin] + atomicAdd(&lcnt[bin], 1u)] = ((copy_tag | i) << 8) | (d < 0 ? 0x80u : 0u) | (mg & ((1u << p.fine_bits) - 1));
         }
@@ -370,7 +380,16 @@ __global__ void __launch_bounds__(MSM_THREADS, MINW) msm_accumulate(const G1Affi
 
     if (tid < FINE) { cnt[tid] = 0; cursor[tid] = 0; }
     __syncthreads();
-    for (uint32_t idx = tid; idx < nc; idx += MSM_THREADS) atomicAdd(&cnt[entries[s + idx] & (FINE - 1)], 1u);
+    // (both passes over the entries load eight per lane before touching LDS: one dependent global load per iteration left the
+    //  wave waiting on memory 64 times per pass, and at the start of a launch every workgroup of the chip is in this phase)
+    constexpr uint32_t SORT_UNROLL = 8;
+    for (uint32_t base = tid; base < nc; base += SORT_UNROLL * MSM_THREADS) {
+        uint32_t e[SORT_UNROLL];
+#pragma unroll
+        for (uint32_t k = 0; k < SORT_UNROLL; k++) { const uint32_t idx = base + k * MSM_THREADS; e[k] = idx < nc ? entries[s + idx] : 0u; }
+#pragma unroll
+        for (uint32_t k = 0; k < SORT_UNROLL; k++) if (base + k * MSM_THREADS < nc) atomicAdd(&cnt[e[k] & (FINE - 1)], 1u);
+    }
     __syncthreads();
     if (tid < 64) {                                           // exclusive scan of the FINE counts by one wave
         constexpr uint32_t PER = FINE / 64;                   // 1 or 2 buckets per lane
@@ -388,9 +407,13 @@ __global__ void __launch_bounds__(MSM_THREADS, MINW) msm_accumulate(const G1Affi
     uint32_t *meta = task_meta + (size_t)task * META_PER_TASK;
     if (tid <= FINE) meta[tid] = start[tid];
     if (tid == 0) meta[FINE + 1] = nc;
-    for (uint32_t idx = tid; idx < nc; idx += MSM_THREADS) {
-        uint32_t en = entries[s + idx], f = en & (FINE - 1);
-        sorted[start[f] + atomicAdd(&cursor[f], 1u)] = en;
+    for (uint32_t base = tid; base < nc; base += SORT_UNROLL * MSM_THREADS) {
+        uint32_t e[SORT_UNROLL];
+#pragma unroll
+        for (uint32_t k = 0; k < SORT_UNROLL; k++) { const uint32_t idx = base + k * MSM_THREADS; e[k] = idx < nc ? entries[s + idx] : 0u; }
+#pragma unroll
+        for (uint32_t k = 0; k < SORT_UNROLL; k++)
+            if (base + k * MSM_THREADS < nc) { const uint32_t f = e[k] & (FINE - 1); sorted[start[f] + atomicAdd(&cursor[f], 1u)] = e[k]; }
     }
     __syncthreads();
     if (nc == 0 || p.debug == 3) return;                      // (debug 3: time the sort alone)
