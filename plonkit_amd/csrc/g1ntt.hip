@@ -137,6 +137,8 @@ int32_t g1_intt_dev(plk_ctx *ctx, const G1Affine *in, uint32_t log_n, G1Affine *
     if (log_n > 26) { set_error("g1_intt: size exceeds 2^26"); return PLK_ERR_SIZE; }
     PLK_TRY(ntt_init_tables(ctx));
     const uint32_t n = 1u << log_n;
+    // the transform borrows the scratch of the first commitment slot: nothing may be in flight there
+    if (ctx->msm_enq != ctx->msm_fin) { set_error("g1_intt: a commitment enqueued with plk_msm_g1_enqueue_dev is still in flight (call plk_msm_g1_finish first)"); return PLK_ERR_ARG; }
     PLK_TRY(ctx->slot[0].c.reserve((size_t)n * sizeof(XyzzW)));
     XyzzW *pts = ctx->slot[0].c.as<XyzzW>();
     Fr n_inv = to_canonical(ctx->n_inv[log_n]);
