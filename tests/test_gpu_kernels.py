@@ -235,6 +235,10 @@ def test_commitments_in_flight(ctx, srs16):
         assert np.array_equal(got, want)
     with pytest.raises(pa.PlkError):
         ctx.msm_finish()                                          # nothing in flight
+    ctx.msm_enqueue_dev(vecs[0], n)                               # g1_intt borrows a slot's scratch: refused while one is in flight
+    with pytest.raises(pa.PlkError):
+        ctx.g1_intt(srs16[:8], 3)
+    assert np.array_equal(fin(), single[0])
     for depth in (1, 2, 3):
         got = list(ShardedMsm(ctx, None, dev).commit_stream(iter(vecs), n, depth=depth))
         assert len(got) == 7 and all(np.array_equal(g, s) for g, s in zip(got, single)), depth
