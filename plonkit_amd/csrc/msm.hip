@@ -383,16 +383,15 @@ __global__ void __launch_bounds__(MSM_THREADS, MINW) msm_accumulate(const G1Affi
 
     if (tid < FINE) { cnt[tid] = 0; cursor[tid] = 0; }
     __syncthreads();
-    // (both passes over the entries load eight per lane before touching LDS: one dependent global load per iteration left the
-    //  wave waiting on memory 64 times per pass, and at the start of a launch every workgroup of the chip is in this phase)
-    constexpr uint32_t SORT_UNROLL = 8;
-    for (uint32_t base = tid; base < nc; base += SORT_UNROLL * MSM_THREADS) {
-        uint32_t e[SORT_UNROLL];
+    // Both passes of the sort work from registers: a lane's <= 64 entries are loaded up front with all loads in flight (one
+    // dependent global load per loop iteration left the wave waiting on memory 64 times per pass, and at the start of a launch
+    // every workgroup of the chip is in this phase); the registers are free here, the accumulator state is not live yet.
+    constexpr uint32_t PER_LANE = CHUNK / MSM_THREADS;                    // 64
+    uint32_t ent[PER_LANE];
 #pragma unroll
-        for (uint32_t k = 0; k < SORT_UNROLL; k++) { const uint32_t idx = base + k * MSM_THREADS; e[k] = idx < nc ? entries[s + idx] : 0u; }
+    for (uint32_t k = 0; k < PER_LANE; k++) { const uint32_t idx = tid + k * MSM_THREADS; ent[k] = idx < nc ? entries[s + idx] : 0u; }
 #pragma unroll
-        for (uint32_t k = 0; k < SORT_UNROLL; k++) if (base + k * MSM_THREADS < nc) atomicAdd(&cnt[e[k] & (FINE - 1)], 1u);
-    }
+    for (uint32_t k = 0; k < PER_LANE; k++) if (tid + k * MSM_THREADS < nc) atomicAdd(&cnt[ent[k] & (FINE - 1)], 1u);
     __syncthreads();
     if (tid < 64) {                                           // exclusive scan of the FINE counts by one wave
         constexpr uint32_t PER = FINE / 64;                   // 1 or 2 buckets per lane
@@ -410,14 +409,9 @@ __global__ void __launch_bounds__(MSM_THREADS, MINW) msm_accumulate(const G1Affi
     uint32_t *meta = task_meta + (size_t)task * META_PER_TASK;
     if (tid <= FINE) meta[tid] = start[tid];
     if (tid == 0) meta[FINE + 1] = nc;
-    for (uint32_t base = tid; base < nc; base += SORT_UNROLL * MSM_THREADS) {
-        uint32_t e[SORT_UNROLL];
 #pragma unroll
-        for (uint32_t k = 0; k < SORT_UNROLL; k++) { const uint32_t idx = base + k * MSM_THREADS; e[k] = idx < nc ? entries[s + idx] : 0u; }
-#pragma unroll
-        for (uint32_t k = 0; k < SORT_UNROLL; k++)
-            if (base + k * MSM_THREADS < nc) { const uint32_t f = e[k] & (FINE - 1); sorted[start[f] + atomicAdd(&cursor[f], 1u)] = e[k]; }
-    }
+    for (uint32_t k = 0; k < PER_LANE; k++)
+        if (tid + k * MSM_THREADS < nc) { const uint32_t f = ent[k] & (FINE - 1); sorted[start[f] + atomicAdd(&cursor[f], 1u)] = ent[k]; }
     __syncthreads();
     if (nc == 0 || p.debug == 3) return;                      // (debug 3: time the sort alone)
     const uint32_t mu = (nc + MSM_THREADS - 1) / MSM_THREADS;
