@@ -331,7 +331,7 @@ static int32_t ensure_base_table(plk_ctx *ctx, uint32_t copies, hipStream_t stre
         hipError_t e = hipStreamSynchronize(stream);
         xyzz.release(); prefix.release(); aff[0].release(); aff[1].release();
         PLK_HIP(e);
-    }
+    } else PLK_HIP(hipStreamSynchronize(stream));             // the table is read by commitments on OTHER slot streams too: complete before any is enqueued
     PLK_HIP(hipGetLastError());
     ctx->srs_w_valid = true;
     ctx->srs_w_copies = copies;

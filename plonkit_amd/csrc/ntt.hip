@@ -359,6 +359,9 @@ int32_t ntt_init_tables(plk_ctx *ctx) {
     for (uint32_t i = 0; i <= MAX_LOG_N; i++) ctx->n_inv_w[i] = mul(ctx->n_inv[i], from_u64<FrParams>(32));   // x*2^256 -> x*2^261
     ctx->coset_allocs.push_back(a);
     ctx->coset_allocs.push_back(b);
+    // the tables are filled on the context's stream but read by transforms on ANY stream (plk_ntt_dev takes the caller's):
+    // they must be complete before the first of those is enqueued.  Once per context.
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
     return PLK_OK;
 }
 
@@ -372,6 +375,7 @@ int32_t ntt_coset_table(plk_ctx *ctx, const Fr &g, PowTable *out) {
     PLK_TRY(make_pow_table(ctx, g, &ext, out, &a));
     ctx->coset_allocs.push_back(a);
     ctx->coset_tabs[key] = *out;
+    PLK_HIP(hipStreamSynchronize(ctx->stream));               // filled on the context's stream, used on any (see ntt_init_tables); once per shift
     return PLK_OK;
 }
 
