@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the knob / build variant this script exercises was an experiment of round 2 that was measured and NOT kept (profiles/r02_msm_three_in_flight_ab.txt); the script is the record of how it was run.
 # challenge-free LDEs on a second stream of the prover: parity, then A/B (PLK_NO_AUX_STREAM=1 = one stream as before)
 cd "$(dirname "$0")/.."
 O=gpurun_out/r2aux; mkdir -p $O

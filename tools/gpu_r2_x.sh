@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the knob / build variant this script exercises was an experiment of round 2 that was measured and NOT kept (profiles/r02_msm_three_in_flight_ab.txt); the script is the record of how it was run.
 # accumulations in sequence only while the FIFO fills (PLK_MSM_FILL_EDGE): the driver's region (warm-up 5, 20 steps, default settle)
 cd "$(dirname "$0")/.."
 O=gpurun_out/r2x; mkdir -p $O
