@@ -942,18 +942,38 @@ int32_t plk_msm_g1_finish_sharded(plk_ctx *ctx, plk_g1_affine *out) {
 
 int32_t plk_msm_g1_partial_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, plk_g1_jacobian *out, void *stream) {
     constexpr uint64_t PIECE = 1ull << 24;                    // one pass of the kernels takes at most 2^24 terms
-    if (n <= PIECE) {
+    // From 2^23 terms on, ONE commitment is run as 2^20-term pieces over successive SRS ranges, three pieces in flight: the digit /
+    // partition kernels and the bucket reduction of a piece then overlap the accumulation of its neighbours, which a single pass
+    // cannot do with itself (2^24 terms: 22.1 ms against 24.0 in one pass; at 2^22 the pieces do not pay: 6.5 against 6.15 ms,
+    // profiles/r02_msm_three_in_flight_ab.txt).  The FIFO must be empty for that (it is, unless the caller keeps commitments in flight).
+    constexpr uint64_t PIPE_FROM = 1ull << 23, PIPE_PIECE = 1ull << 20;
+    const bool pipelined = n >= PIPE_FROM && ctx && ctx->msm_enq == ctx->msm_fin;
+    if (n <= PIECE && !pipelined) {
         PLK_TRY(plk_msm_g1_enqueue_dev(ctx, scalars_dev, n, base_offset, stream));
         return plk_msm_g1_finish(ctx, out);
     }
     if (!ctx || !scalars_dev || !out) { set_error("plk_msm_g1: bad argument"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
     host::HJac acc = host::HJac::inf();
-    for (uint64_t off = 0; off < n; off += PIECE) {           // longer commitments: successive SRS ranges, summed on the host
+    const uint64_t piece = pipelined ? PIPE_PIECE : PIECE;
+    const uint32_t depth = pipelined ? plk_ctx::MSM_SLOTS : 1;
+    uint64_t off = 0;
+    uint32_t inflight = 0;
+    int32_t rc = PLK_OK;
+    while (off < n || inflight) {                             // successive SRS ranges, summed on the host
+        while (rc == PLK_OK && off < n && inflight < depth) {
+            rc = msm_enqueue(ctx, (const Fr *)scalars_dev + off, n - off < piece ? n - off : piece, base_offset + off, stream ? (hipStream_t)stream : ctx->stream);
+            if (rc == PLK_OK) { off += piece; inflight++; }
+        }
+        if (rc != PLK_OK) off = n;                            // stop enqueuing, drain what is in flight
+        if (!inflight) break;
         host::HJac j;
-        PLK_TRY(msm_enqueue(ctx, (const Fr *)scalars_dev + off, n - off < PIECE ? n - off : PIECE, base_offset + off, stream ? (hipStream_t)stream : ctx->stream));
-        PLK_TRY(msm_finish(ctx, nullptr, &j));
-        acc = host::jac_add(acc, j);
+        const int32_t rf = msm_finish(ctx, nullptr, &j);
+        inflight--;
+        if (rf != PLK_OK && rc == PLK_OK) rc = rf;
+        if (rc == PLK_OK) acc = host::jac_add(acc, j);
     }
+    if (rc != PLK_OK) return rc;
     memcpy(out->x, acc.x.l, 32); memcpy(out->y, acc.y.l, 32); memcpy(out->z, acc.z.l, 32);
     return PLK_OK;
 }
