@@ -875,6 +875,15 @@ int32_t msm_finish(plk_ctx *ctx, hipStream_t stream, host::HJac *out) {
     return msm_finish_batch(ctx, stream, out);
 }
 
+// From 2^23 terms on, ONE commitment is better run as 2^20-term pieces over successive SRS ranges, three pieces in flight: the
+// digit / partition kernels and the bucket reduction of a piece then overlap the accumulation of its neighbours, which a single
+// pass cannot do with itself (2^24 terms: 21.8 ms against 24.0 in one pass; at 2^22 the pieces do not pay: 6.5 against 6.15 ms,
+// profiles/r02_msm_three_in_flight_ab.txt).  Only with the table of shifted copies: an SRS of more than 2^25 points has none
+// (it would exceed 32 GiB), a 2^20-term piece then runs 19 windows instead of 15 and a 2^26-gate proof got 40 % SLOWER that way.
+uint64_t msm_pipelined_piece(const plk_ctx *ctx, uint64_t terms) {
+    return (terms >= (1ull << 23) && table_copies_for(ctx->srs_n) > 1) ? (1ull << 20) : 0;
+}
+
 }  // namespace plk
 
 using namespace plk;
@@ -942,12 +951,10 @@ int32_t plk_msm_g1_finish_sharded(plk_ctx *ctx, plk_g1_affine *out) {
 
 int32_t plk_msm_g1_partial_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n, uint64_t base_offset, plk_g1_jacobian *out, void *stream) {
     constexpr uint64_t PIECE = 1ull << 24;                    // one pass of the kernels takes at most 2^24 terms
-    // From 2^23 terms on, ONE commitment is run as 2^20-term pieces over successive SRS ranges, three pieces in flight: the digit /
-    // partition kernels and the bucket reduction of a piece then overlap the accumulation of its neighbours, which a single pass
-    // cannot do with itself (2^24 terms: 22.1 ms against 24.0 in one pass; at 2^22 the pieces do not pay: 6.5 against 6.15 ms,
-    // profiles/r02_msm_three_in_flight_ab.txt).  The FIFO must be empty for that (it is, unless the caller keeps commitments in flight).
-    constexpr uint64_t PIPE_FROM = 1ull << 23, PIPE_PIECE = 1ull << 20;
-    const bool pipelined = n >= PIPE_FROM && ctx && ctx->msm_enq == ctx->msm_fin;
+    // long commitments as short pieces, several in flight (msm_pipelined_piece); the FIFO must be empty for that (it is, unless
+    // the caller keeps commitments in flight)
+    const uint64_t pipe_piece = ctx ? msm_pipelined_piece(ctx, n) : 0;
+    const bool pipelined = pipe_piece != 0 && ctx->msm_enq == ctx->msm_fin;
     if (n <= PIECE && !pipelined) {
         PLK_TRY(plk_msm_g1_enqueue_dev(ctx, scalars_dev, n, base_offset, stream));
         return plk_msm_g1_finish(ctx, out);
@@ -955,7 +962,7 @@ int32_t plk_msm_g1_partial_dev(plk_ctx *ctx, const void *scalars_dev, uint64_t n
     if (!ctx || !scalars_dev || !out) { set_error("plk_msm_g1: bad argument"); return PLK_ERR_ARG; }
     PLK_HIP(hipSetDevice(ctx->device));
     host::HJac acc = host::HJac::inf();
-    const uint64_t piece = pipelined ? PIPE_PIECE : PIECE;
+    const uint64_t piece = pipelined ? pipe_piece : PIECE;
     const uint32_t depth = pipelined ? plk_ctx::MSM_SLOTS : 1;
     uint64_t off = 0;
     uint32_t inflight = 0;
