@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the prover-side variant this script exercised (batches as pipelined 2^20-term pieces) was measured and NOT kept (profiles/r02_msm_three_in_flight_ab.txt); the plk_msm_g1 side was.
 # prover commitments of >= 2^23 terms as pipelined 2^20-term pieces: parity at every tier, then the large domains
 cd "$(dirname "$0")/.."
 O=gpurun_out/r2pp; mkdir -p $O
