@@ -2,16 +2,18 @@
 """bench.py — headline benchmark of the PLONK prove hot path on MI355X (BASELINE.json metric:
 "PLONK prove wall-clock (s) + G1 MSM throughput (Mscalar·mul/s) at 2^20 domain, 1/2/4/8 GPU").
 
-  python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W          (N > 1: spawns its own N ranks under torch.distributed.run)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
 A step = one KZG commitment (G1 MSM) of 2^20 uniform scalars per GPU against that GPU's resident
 shard of a tau = 42 monomial SRS (BASELINE.json configs[1]; with N GPUs the job is one commitment
 of N*2^20 terms with the bases split across ranks, partial sums exchanged over RCCL — "weak").
 `value` = total scalar·muls per second over all ranks, inputs resident in HBM.  Up to three commitments are in flight
-(the library's FIFO).  Before the W warm-up steps the same loop runs `--settle-steps` (50) untimed commitments: at
-1.4 ms a step, W = 5 is 7 ms of load, and the GPU reaches its sustained rate only after ~70 ms of it; the timed region is
-still exactly K steps between barrier + synchronize brackets and `config.settle_steps` says what was run.
+(the library's FIFO).  The headline region is exactly what the contract says: W untimed warm-up steps, then K timed steps
+between barrier + synchronize brackets, nothing else before it (`--settle-steps` defaults to 0).  Because a step is
+~1.3 ms, W = 5 is only ~7 ms of load and the GPU reaches its sustained rate after ~70 ms of it; the line therefore also
+carries `sustained` = the same K-step region timed once more after 50 further commitments (value_sustained), so both
+protocols can be read from one run.
 
 The one JSON line also carries
   roofline      dominant kernel msm_accumulate.  `kernel_ms` is its HIP-event duration with ONE commitment in flight
@@ -53,6 +55,8 @@ ALGO_BYTES_PER_TERM = 96         # 64 B base + 32 B scalar
 # not wide coalesced streams, so the guide's x2 correction for 16 B/lane streaming reads does not apply) + 51,073 KB written
 # (lane partial sums).  Only for --log-n 20.
 PMC_TRAFFIC_BYTES_2POW20 = (1012700 + 51073) * 1024
+PMC_TRAFFIC_SOURCE = ("not measured in this run: FETCH_SIZE + WRITE_SIZE of msm_accumulate from separate rocprofv3 --pmc passes, "
+                      "profiles/r02_pmc_traffic_final.txt")
 MSM_WINDOWS = 15                 # 17-bit signed windows over the 254-bit scalars: mixed additions per term
 # VALU yardsticks.  Hardware: v_mad_u64_u32 issues at 576.1 G wave-instructions/s chip-wide
 # (profiles/r01_ubench_int.txt, k_mad64: 4.27 cycles per wave-instruction per SIMD at 2.4 GHz) = 36.87 T lane-mads/s;
@@ -313,8 +317,15 @@ def sharded_prove(ctx, dist, device, log_n, rank, world):
         t = torch.tensor([dt], dtype=torch.float64, device=red_device(device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         best = float(t.item()) if best is None else min(best, float(t.item()))
+    # every rank must hold the same bytes, and the host verifier (real pairing) must accept them against the sharded key
+    import hashlib
+    digests = [None] * world
+    dist.all_gather_object(digests, hashlib.sha256(proof).hexdigest())
+    vk = setup.verification_key_bytes(pa.crs42_g2_bytes())        # 11 sharded commitments: every rank takes part
+    verified = bool(pa.verify(vk, proof)) if rank == 0 else None
     setup.close(); circ.close()
     return {"wall_s": round(best, 4), "domain": n, "n_gpus": world, "srs_points_per_gpu": local, "proof_bytes": len(proof),
+            "same_proof_on_every_rank": len(set(digests)) == 1, "verified": verified,
             "what": "SetupForProver::prove with every commitment computed as the sum over ranks of MSM(slice of the scalars, "
                     "slice of the SRS): ncclAllGather of the Jacobian partial sums inside the library (plk_comm_init) + host EC sum; "
                     "NTTs and point-wise work replicated"}
@@ -390,6 +401,25 @@ def time_commitments(ctx, msm, scalars, n, steps, stream, depth):
     return time.perf_counter() - t0, kernel_ms, out
 
 
+def spawn_ranks(n_gpus):
+    """re-run this command line as N ranks: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>; returns the launcher's exit status"""
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+        sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.pop("MASTER_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -402,20 +432,26 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=3, choices=(1, 2, 3),
                     help="commitments in flight in the timed region (3 = the library's three-slot FIFO; 1 = one at a time: "
                          "the region roofline.kernel_ms is taken from)")
-    ap.add_argument("--settle-steps", type=int, default=50,
-                    help="untimed commitments run before the W warm-up steps: a step is 1.4 ms, so the W = 5 the driver passes is 7 ms "
-                         "of load, and the GPU needs ~70 ms of it before the loop reaches its sustained rate (DESIGN.md §5, "
-                         "profiles/r02_msm_three_in_flight_ab.txt: 1.48-1.51 ms per step without, 1.41-1.43 with, same box); 0 = off")
+    ap.add_argument("--settle-steps", type=int, default=0,
+                    help="extra untimed commitments BEFORE the W warm-up steps of the headline region (default 0: the headline is "
+                         "W warm-up + K timed steps and nothing else; round 2 defaulted to 50)")
+    ap.add_argument("--sustained-settle-steps", type=int, default=50,
+                    help="untimed commitments between the headline region and the `sustained` region (the same K steps timed again "
+                         "once the GPU has been under load for >= 70 ms: DESIGN.md §5); 0 = no sustained region")
     ap.add_argument("--msm-only", action="store_true", help="only the timed commitments (no cpu_baseline / prove / kernels legs): "
                                                             "the command the rocprofv3 summary under profiles/ is taken from")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: spawn the N ranks ourselves, exactly as the driver's documented command does
+        # (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1); their rank 0 prints the JSON line
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N ranks for --gpus N, or run it plainly and let it spawn them)"
+                         % (args.gpus, world))
     # PLK_BENCH_SHARE_DEVICE=1 (test tier with ONE GPU): every rank uses device 0, torch.distributed runs over gloo and the
     # partial sums travel over the library's TCP transport, because RCCL refuses two ranks on one device.  It exercises the
     # N > 1 control flow (slicing, strong-scaling leg, sharded prove); its timings mean nothing.
@@ -477,6 +513,24 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_device(device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the same K steps once more after sustained load (`sustained`: what round 2's default --settle-steps 50 measured)
+    sustained = None
+    if args.sustained_settle_steps:
+        time_commitments(ctx, msm, scalars, n, args.sustained_settle_steps, stream, args.pipeline_depth)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        time_commitments(ctx, msm, scalars, n, args.steps, stream, args.pipeline_depth)
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        sustained = time.perf_counter() - t_s
+        if dist:
+            t = torch.tensor([sustained], dtype=torch.float64, device=red_device(device))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sustained = float(t.item())
     # the dominant kernel alone: one commitment in flight, so nothing shares the GPU with msm_accumulate
     solo_elapsed, solo_kernel_ms, _ = time_commitments(ctx, msm, scalars, n, max(5, args.steps // 2), stream, 1)
     if dist:
@@ -504,6 +558,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": PMC_TRAFFIC_BYTES_2POW20 if (args.log_n == 20) else None,
+                         "traffic_source": PMC_TRAFFIC_SOURCE if (args.log_n == 20) else None,
                          "kernel_ms": round(k_ms, 4), "kernel_ms_pipelined": round(k_pipe, 4),
                          "ms_per_step_one_in_flight": round(solo_elapsed * 1e3 / len(solo_kernel_ms), 4),
                          "algorithmic_bytes": ALGO_BYTES_PER_TERM * n,
@@ -523,6 +578,15 @@ def main():
                                  "64-byte point per (term, window): 15 windows, each from its own shifted copy of the SRS "
                                  "(0.94 GiB fixed-base table in HBM)"},
         }
+        if sustained is not None:
+            line["sustained"] = {"value": round(world * n / (sustained / args.steps) / 1e6, 3), "ms_per_step": round(sustained * 1e3 / args.steps, 4),
+                                 "steps": args.steps, "untimed_steps_before": args.settle_steps + args.warmup + args.steps + args.sustained_settle_steps,
+                                 "what": "the headline region repeated after %d further untimed commitments (GPU under load for >= 70 ms)" % args.sustained_settle_steps}
+        if world > 1 and not args.no_cpu_baseline and not args.msm_only:
+            # the N > 1 line is self-contained: the same dense_multiexp port on this box's host cores (rank 0's GPU shard supplies the bases)
+            cb, ref, s_host = cpu_msm_baseline(ctx, min(args.cpu_log_n, args.log_n), 1234)
+            cb["note"] = "MSM leg only at N > 1; the N = 1 line carries the NTT / prove / G1-iNTT rows"
+            line["cpu_baseline"] = cb
         if world == 1 and not args.no_cpu_baseline and not args.msm_only:
             cb, ref, s_host = cpu_msm_baseline(ctx, min(args.cpu_log_n, args.log_n), 1234)
             got = ctx.msm(s_host)                         # same sample through the HIP path
@@ -554,6 +618,11 @@ def main():
         if rank == 0:
             line["strong"] = strong
             line["prove"] = sharded
+            # the figure north_star's ">= 6x MSM scaling 1 -> 8 GPUs" reads, where a reader will look for it: `value` above is
+            # WEAK scaling (2^log_n terms per GPU), these two are STRONG scaling of one fixed 2^strong_log_n-term commitment
+            line["strong_value"] = strong.get("Mscalar_mul_s")
+            line["strong_unit"] = "Mscalar·mul/s (one 2^%d-term commitment, SRS split over %d GPUs)" % (args.strong_log_n, world)
+            line["strong_scaling_vs_1gpu"] = strong.get("scaling_vs_1gpu")
     if rank == 0:
         print(json.dumps(line, ensure_ascii=False), flush=True)
     if dist:

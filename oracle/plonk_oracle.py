@@ -689,7 +689,9 @@ def verify(vk, P, tau=42):
     N = vk.n + 1
     log_n = N.bit_length() - 1
     om = ol.omega(log_n)
-    if len(P.inputs) != vk.num_inputs or vk.num_inputs < 1:
+    # template.sol:697 also requires num_inputs >= 1; that is the Solidity verifier's restriction — the Rust verifier
+    # `plonkit verify` calls has none [recollection, unpinned], and circom circuits without public signals are legal
+    if len(P.inputs) != vk.num_inputs:
         return False
     tr = Transcript()
     for x in P.inputs:
@@ -706,7 +708,7 @@ def verify(vk, P, tau=42):
     if zN == 1:
         return False
     lag = [pow(om, i, R_MOD) * (zN - 1) % R_MOD * pow(N * (z - pow(om, i, R_MOD)) % R_MOD, -1, R_MOD) % R_MOD
-           for i in range(vk.num_inputs)]
+           for i in range(max(vk.num_inputs, 1))]
     wz, sz = P.wire_values_at_z, P.permutation_polynomials_at_z
     lhs = (zN - 1) * P.quotient_polynomial_at_z % R_MOD
     rhs = P.linearization_polynomial_at_z

@@ -5,7 +5,9 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 
@@ -42,20 +44,34 @@ struct Rd {
     uint64_t u64() { if (!need(8)) return 0; uint64_t v; memcpy(&v, p + off, 8); off += 8; return v; }
 };
 
+// Nothing may unwind out of a worker thread (std::terminate would abort the host process under the extern "C" boundary):
+// every worker catches, the first exception is kept, all threads are always joined, and it is rethrown on the calling
+// thread where guarded() maps it to a status code.  If a thread cannot be created the remaining ranges run on the caller.
 void parallel_for(size_t n, size_t min_per_thread, const std::function<void(size_t, size_t)> &fn, unsigned max_threads) {
     unsigned nt = std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
     if (nt > max_threads) nt = max_threads;
     if (min_per_thread && n / min_per_thread < nt) nt = (unsigned)(n / min_per_thread);
     if (nt <= 1) { if (n) fn(0, n); return; }
+    std::exception_ptr first;
+    std::mutex mu;
+    auto run = [&](size_t lo, size_t hi) noexcept {
+        try { fn(lo, hi); }
+        catch (...) { std::lock_guard<std::mutex> g(mu); if (!first) first = std::current_exception(); }
+    };
     std::vector<std::thread> th;
+    try { th.reserve(nt); } catch (...) { fn(0, n); return; }
     const size_t per = (n + nt - 1) / nt;
+    size_t serial_from = n;                                   // ranges [serial_from, n) run here if thread creation fails
     for (unsigned t = 0; t < nt; t++) {
         const size_t lo = t * per, hi = lo + per < n ? lo + per : n;
         if (lo >= hi) break;
-        th.emplace_back(fn, lo, hi);
+        try { th.emplace_back(run, lo, hi); }
+        catch (...) { serial_from = lo; break; }              // std::system_error: out of threads — never leave joinable threads behind
     }
+    if (serial_from < n) run(serial_from, n);
     for (auto &x : th) x.join();
+    if (first) std::rethrow_exception(first);
 }
 
 // ------------------------------------------------------------------------- .r1cs (binary)

@@ -6,7 +6,7 @@
 //
 // Multi-GPU (an extension; the reference is one process): start one `plonkit prove` / `export-verification-key` per GPU
 // with PLONKIT_WORLD=<ranks> PLONKIT_RANK=<r> and PLONKIT_COMM=rccl:<id file> (rank 0 writes the RCCL unique id there, the
-// others wait for it) or PLONKIT_COMM=tcp:<port> (ranks sharing one device).  Rank r uses device PLONKIT_DEVICE or
+// others wait for it; set PLONKIT_RUN_ID=<nonce> on all ranks when several runs may share the path) or PLONKIT_COMM=tcp:<port> (ranks sharing one device).  Rank r uses device PLONKIT_DEVICE or
 // r mod #devices, keeps only its 1/world slice of the key resident and computes its share of every commitment
 // (plk_comm_init, include/plonkit_amd.h); every rank derives the same bytes and rank 0 writes the files.
 #include "../../include/plonkit_amd.h"
@@ -19,14 +19,27 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <ctime>
 #include <sys/stat.h>
 #include <unistd.h>
 
+// A fatal error ends the process with the Rust panic exit code — but only ever from the MAIN thread: exit() on a helper
+// thread would run static destructors and atexit handlers (HIP, RCCL, libstdc++) under the feet of the main thread.  On the
+// start-up GPU thread fatal() throws instead; the thread records it and main reports it after join() (worker_guard below).
+struct Fatal { int code; std::string msg; };
+static thread_local bool t_in_worker = false;
+static std::thread *g_helper = nullptr;                       // the start-up GPU thread while it may be running
+[[noreturn]] static void fatal(int code, const std::string &msg) {
+    if (t_in_worker) throw Fatal{code, msg};
+    fprintf(stderr, "%s\n", msg.c_str());
+    if (g_helper && g_helper->joinable()) g_helper->join();  // (exit() does not unwind: wait for the helper to leave HIP first)
+    exit(code);
+}
 static bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 static bool ends_with(const std::string &s, const char *suf) { size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
 static std::vector<uint8_t> slurp(const std::string &p, const char *what) {           // one read() of the whole file
     FILE *f = fopen(p.c_str(), "rb");
-    if (!f) { fprintf(stderr, "%s: cannot open %s\n", what, p.c_str()); exit(101); }
+    if (!f) fatal(101, std::string(what) + ": cannot open " + p);
     std::vector<uint8_t> data;
     struct stat st;
     if (fstat(fileno(f), &st) == 0 && st.st_size > 0) {
@@ -41,7 +54,17 @@ static std::vector<uint8_t> slurp(const std::string &p, const char *what) {     
     return data;
 }
 static void spit(const std::string &p, const uint8_t *d, size_t n) { std::ofstream f(p, std::ios::binary); f.write((const char *)d, (std::streamsize)n); }
-static void die(const char *what, int32_t rc) { fprintf(stderr, "%s: %s (status %d)\n", what, plk_last_error(), rc); exit(101); }   // Rust panic exit code
+static void die(const char *what, int32_t rc) { fatal(101, std::string(what) + ": " + plk_last_error() + " (status " + std::to_string(rc) + ")"); }   // Rust panic exit code
+// runs `body` on a helper thread's behalf: a Fatal raised inside is parked in *err (anything else too) instead of ending the process there
+template <class F> static void worker_guard(Fatal *err, F &&body) {
+    t_in_worker = true;
+    try { body(); }
+    catch (const Fatal &f) { *err = f; }
+    catch (const std::exception &e) { *err = Fatal{101, std::string("start-up thread: ") + e.what()}; }
+    catch (...) { *err = Fatal{101, "start-up thread: unknown failure"}; }
+    t_in_worker = false;
+}
+static void rethrow_on_main(const Fatal &err) { if (err.code) fatal(err.code, err.msg); }
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static double g_t0 = 0;
 // PLK_CLI_TIMING=1: phase times on stderr (whole-CLI measurement of DESIGN.md §4)
@@ -176,19 +199,42 @@ static void join_ranks(plk_ctx *ctx, const Ranks &rk, uint64_t N) {
     if (N % (uint64_t)rk.world) { fprintf(stderr, "PLONKIT_WORLD must divide the domain size\n"); exit(101); }
     const uint64_t first = (uint64_t)rk.rank * (N / rk.world);
     if (rk.comm.rfind("tcp:", 0) == 0) { CK("plk_comm_init_tcp", plk_comm_init_tcp(ctx, rk.rank, rk.world, (uint16_t)atoi(rk.comm.c_str() + 4), first)); return; }
+    // The id file is 128 bytes of ncclUniqueId followed by the run id (PLONKIT_RUN_ID, may be empty).  A file left behind
+    // by an earlier run must never be taken for this run's: rank 0 unlinks the path before it does anything else and
+    // removes the file again once the communicator exists (every rank has read it by then: ncclCommInitRank is
+    // collective); the other ranks accept only a file that carries THEIR run id and — when no run id is given — one
+    // that is not older than the two-minute window they are prepared to wait (a crashed run's leftover is older).
     const std::string path = rk.comm.substr(5);
+    const char *rid_env = getenv("PLONKIT_RUN_ID");
+    const std::string run_id = rid_env ? rid_env : "";
+    const time_t started = time(nullptr);
     plk_comm_id id;
     if (rk.rank == 0) {
+        (void)unlink(path.c_str());
         CK("plk_comm_unique_id", plk_comm_unique_id(&id));
-        spit(path + ".tmp", reinterpret_cast<const uint8_t *>(id.bytes), sizeof id.bytes);
-        if (rename((path + ".tmp").c_str(), path.c_str()) != 0) { fprintf(stderr, "cannot write %s\n", path.c_str()); exit(101); }
+        std::vector<uint8_t> blob(id.bytes, id.bytes + sizeof id.bytes);
+        blob.insert(blob.end(), run_id.begin(), run_id.end());
+        spit(path + ".tmp", blob.data(), blob.size());
+        if (rename((path + ".tmp").c_str(), path.c_str()) != 0) fatal(101, "cannot write " + path);
     } else {
-        for (int i = 0; i < 1200 && !exists(path); i++) usleep(100000);           // up to two minutes for rank 0
-        std::vector<uint8_t> raw = slurp(path, "RCCL unique id");
-        if (raw.size() != sizeof id.bytes) { fprintf(stderr, "bad RCCL id file %s\n", path.c_str()); exit(101); }
-        memcpy(id.bytes, raw.data(), sizeof id.bytes);
+        bool got = false;
+        for (int i = 0; i < 1200 && !got; i++) {                                    // up to two minutes for rank 0
+            struct stat st;
+            if (stat(path.c_str(), &st) == 0 && (size_t)st.st_size == sizeof id.bytes + run_id.size() &&
+                (!run_id.empty() || st.st_mtime + 120 >= started)) {
+                std::vector<uint8_t> raw = slurp(path, "RCCL unique id");
+                if (raw.size() == sizeof id.bytes + run_id.size() && memcmp(raw.data() + sizeof id.bytes, run_id.data(), run_id.size()) == 0) {
+                    memcpy(id.bytes, raw.data(), sizeof id.bytes);
+                    got = true;
+                    break;
+                }
+            }
+            usleep(100000);
+        }
+        if (!got) fatal(101, "no RCCL id file of this run at " + path + " (rank 0 writes it; PLONKIT_RUN_ID must agree on all ranks)");
     }
     CK("plk_comm_init", plk_comm_init(ctx, rk.rank, rk.world, &id, first));
+    if (rk.rank == 0) (void)unlink(path.c_str());
 }
 // uploads the key; with several ranks only this rank's slice [rank * N/world, (rank + 1) * N/world) of its first N points
 static void load_key(plk_ctx *ctx, const std::string &path, uint8_t g2[256], bool lagrange = false, const Ranks &rk = Ranks(), uint64_t N = 0) {
@@ -200,7 +246,7 @@ static void load_key(plk_ctx *ctx, const std::string &path, uint8_t g2[256], boo
     CK(what, plk_key_parse(raw.data(), raw.size(), pts.data(), n, &n, g2));
     const plk_g1_affine *first = pts.data();
     if (rk.world > 1) {
-        if (n < N) { fprintf(stderr, "%s: key has %llu points, the domain needs %llu\n", what, (unsigned long long)n, (unsigned long long)N); exit(101); }
+        if (n < N) fatal(101, std::string(what) + ": key has " + std::to_string(n) + " points, the domain needs " + std::to_string(N));
         first += (uint64_t)rk.rank * (N / rk.world);
         n = N / rk.world;
     }
@@ -267,14 +313,23 @@ static int run(int argc, char **argv) {
         plk_setup *s = nullptr;
         plk_circuit *c = nullptr;
         if (rk.world == 1 && rk.comm.empty()) {                      // as in `prove`: the GPU comes up while the circuit is parsed and transpiled
-            std::thread gpu([&] {
-                ctx = open_ctx(rk);
-                load_key(ctx, a.get("srs_monomial_form"), g2);
-                CK("srs precompute", plk_srs_precompute(ctx));
+            const std::string key_path = a.get("srs_monomial_form");   // (a missing option exits here, on the main thread)
+            Fatal gpu_err{0, ""};
+            plk_ctx *gpu_ctx = nullptr;
+            std::thread gpu([&gpu_err, &gpu_ctx, &g2, rk, key_path] {
+                worker_guard(&gpu_err, [&] {
+                    gpu_ctx = open_ctx(rk);
+                    load_key(gpu_ctx, key_path, g2);
+                    CK("srs precompute", plk_srs_precompute(gpu_ctx));
+                });
             });
+            g_helper = &gpu;                                            // fatal() on this thread waits for it before exit()
             c = load_circuit(resolve_circuit(a), nullptr);
             CK("prepare err", plk_setup_prepare_host(c, &s));
             gpu.join();
+            g_helper = nullptr;
+            rethrow_on_main(gpu_err);
+            ctx = gpu_ctx;
             CK("prepare err", plk_setup_upload(ctx, s));
         } else {
             c = load_circuit(resolve_circuit(a), nullptr);
@@ -309,23 +364,32 @@ static int run(int argc, char **argv) {
         if (single) {
             // the GPU side of the start-up (HIP initialisation, key parse + upload, fixed-base table of the MSM) runs on a
             // second thread while this one parses the circuit and the witness: neither needs the other until the setup
-            std::thread gpu([&] {
-                const bool tm = getenv("PLK_CLI_TIMING") != nullptr;
-                double t0 = now_s(), t1;
-                auto lap = [&](const char *what) { if (tm) { t1 = now_s(); fprintf(stderr, "[timing]   gpu thread: %-24s +%.3f s\n", what, t1 - t0); t0 = t1; } };
-                ctx = open_ctx(rk);
-                lap("plk_create (HIP init)");
-                load_key(ctx, a.get("srs_monomial_form"), g2);
-                if (!lag.empty()) { uint8_t g2l[256]; load_key(ctx, lag, g2l, true); }
-                lap("key read + parse + upload");
-                CK("srs precompute", plk_srs_precompute(ctx));
-                lap("MSM table");
+            const std::string key_path = a.get("srs_monomial_form");   // (a missing option exits here, on the main thread)
+            Fatal gpu_err{0, ""};
+            plk_ctx *gpu_ctx = nullptr;
+            std::thread gpu([&gpu_err, &gpu_ctx, &g2, rk, key_path, lag] {
+                worker_guard(&gpu_err, [&] {
+                    const bool tm = getenv("PLK_CLI_TIMING") != nullptr;
+                    double t0 = now_s(), t1;
+                    auto lap = [&](const char *what) { if (tm) { t1 = now_s(); fprintf(stderr, "[timing]   gpu thread: %-24s +%.3f s\n", what, t1 - t0); t0 = t1; } };
+                    gpu_ctx = open_ctx(rk);
+                    lap("plk_create (HIP init)");
+                    load_key(gpu_ctx, key_path, g2);
+                    if (!lag.empty()) { uint8_t g2l[256]; load_key(gpu_ctx, lag, g2l, true); }
+                    lap("key read + parse + upload");
+                    CK("srs precompute", plk_srs_precompute(gpu_ctx));
+                    lap("MSM table");
+                });
             });
+            g_helper = &gpu;                                            // a bad circuit file: fatal() on this thread waits for the helper before exit()
             c = load_circuit(resolve_circuit(a), &wf);
             phase("load circuit + witness");
             CK("prepare err", plk_setup_prepare_host(c, &s));             // pure CPU: does not wait for the GPU either
             phase("setup: host phase");
             gpu.join();
+            g_helper = nullptr;
+            rethrow_on_main(gpu_err);
+            ctx = gpu_ctx;
             phase("HIP init + key + table (other thread)");
             CK("prepare err", plk_setup_upload(ctx, s));
             phase("setup: device phase");

@@ -20,6 +20,7 @@
 #include <sys/socket.h>
 #include <poll.h>
 #include <unistd.h>
+#include <cstdlib>
 #include <cstring>
 #include <chrono>
 #include <thread>
@@ -36,6 +37,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                       // optional: the watchdog's way out
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr; // optional
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -54,6 +57,8 @@ Rccl *rccl() {
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.so, "ncclAllGather"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.so, "ncclCommDestroy"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.so, "ncclGetErrorString"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.so, "ncclCommAbort"));
+    r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(r.so, "ncclCommGetAsyncError"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { dlclose(r.so); r.so = nullptr; return nullptr; }
     return &r;
 }
@@ -64,8 +69,15 @@ int32_t rccl_fail(ncclResult_t e, const char *what) {
     return PLK_ERR_HIP;
 }
 
-// a rank that died must not leave the others blocked for ever: every socket operation gives up after COMM_TIMEOUT_S
+// a rank that died must not leave the others blocked for ever: every socket operation gives up after COMM_TIMEOUT_S, and
+// the RCCL exchange is watched by a deadline of its own (PLK_COMM_TIMEOUT_MS, default COMM_TIMEOUT_S) — the reference
+// panics and exits when a worker fails (src/bin/main.rs:335,371,399); here the call returns PLK_ERR_HIP
 constexpr int COMM_TIMEOUT_S = 180;
+long comm_timeout_ms() {
+    const char *e = getenv("PLK_COMM_TIMEOUT_MS");
+    if (e && *e) { char *end = nullptr; long v = strtol(e, &end, 10); if (end != e && v >= 0) return v; }
+    return COMM_TIMEOUT_S * 1000L;
+}
 void set_timeouts(int fd) {
     timeval tv{COMM_TIMEOUT_S, 0};
     ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
@@ -98,7 +110,42 @@ struct Comm {
     std::vector<plk_g1_jacobian> host_all;
     plk_ctx *ctx = nullptr;
     uint64_t gathers = 0;                    // number of exchanges performed (tracing / tests)
+    bool dead = false;                       // the watchdog aborted the communicator: every later exchange fails at once
 };
+
+// Waits for the exchange stream with a deadline instead of hipStreamSynchronize: if a peer died, ncclAllGather never
+// completes and a plain synchronise would hang this rank (and with it the node) for ever.  Spins for the common case
+// (the exchange takes tens of microseconds), then yields, then sleeps.  On expiry or an asynchronous RCCL error the
+// communicator is aborted (ncclCommAbort tears the collective's kernel down so that the stream drains) and marked dead.
+static int32_t watch_exchange(Comm *C, hipStream_t st) {
+    using clk = std::chrono::steady_clock;
+    Rccl *R = rccl();
+    const auto t0 = clk::now();
+    const auto deadline = t0 + std::chrono::milliseconds(comm_timeout_ms());
+    for (unsigned it = 0;; it++) {
+        hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return PLK_OK;
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); C->dead = true; set_error(std::string("RCCL exchange: ") + hipGetErrorString(q)); return PLK_ERR_HIP; }
+        (void)hipGetLastError();
+        const auto now = clk::now();
+        bool failed = now >= deadline;
+        const char *why = "no answer from a peer before the deadline (PLK_COMM_TIMEOUT_MS)";
+        if (!failed && (it & 1023) == 1023 && R->CommGetAsyncError) {
+            ncclResult_t ae = ncclSuccess;
+            if (R->CommGetAsyncError(C->nccl, &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress) { failed = true; why = "asynchronous RCCL error (a peer went away)"; }
+        }
+        if (failed) {
+            C->dead = true;
+            if (R->CommAbort && C->nccl) { (void)R->CommAbort(C->nccl); C->nccl = nullptr; }
+            set_error(std::string("RCCL exchange aborted: ") + why);
+            return PLK_ERR_HIP;
+        }
+        const auto waited = now - t0;
+        if (waited > std::chrono::milliseconds(20)) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        else if (waited > std::chrono::microseconds(300)) std::this_thread::yield();
+    }
+}
+
 
 // all ranks' `count` partial sums -> all[r * count + k]
 static int32_t gather(Comm *C, const plk_g1_jacobian *mine, uint32_t count, plk_g1_jacobian *all) {
@@ -117,6 +164,7 @@ static int32_t gather(Comm *C, const plk_g1_jacobian *mine, uint32_t count, plk_
         return PLK_OK;
     }
     Rccl *R = rccl();
+    if (C->dead || !C->nccl) { set_error("RCCL exchange: the communicator was aborted earlier (plk_comm_destroy + plk_comm_init to start over)"); return PLK_ERR_HIP; }
     PLK_HIP(hipSetDevice(C->ctx->device));
     hipStream_t st = C->stream;
     PLK_TRY(C->d_send.reserve(8 * sizeof(plk_g1_jacobian)));
@@ -125,8 +173,7 @@ static int32_t gather(Comm *C, const plk_g1_jacobian *mine, uint32_t count, plk_
     ncclResult_t e = R->AllGather(C->d_send.p, C->d_recv.p, bytes, ncclUint8, C->nccl, st);
     if (e != ncclSuccess) return rccl_fail(e, "ncclAllGather");
     PLK_HIP(hipMemcpyAsync(all, C->d_recv.p, bytes * C->world, hipMemcpyDeviceToHost, st));
-    PLK_HIP(hipStreamSynchronize(st));
-    return PLK_OK;
+    return watch_exchange(C, st);
 }
 
 // the built-in plk_combine_fn: sums[k] <- sum over ranks of sums[k]; every rank ends with the same group elements

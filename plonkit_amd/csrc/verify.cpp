@@ -105,7 +105,11 @@ bool verify_keccak(const Vk &vk, const ProofData &P) {
     const uint64_t N = vk.n + 1;
     if (N < 2 || (N & (N - 1)) || N > (1ull << 28)) return false;
     uint32_t log_n = 0; while ((1ull << log_n) < N) log_n++;
-    if (P.n != vk.n || P.inputs.size() != vk.num_inputs || vk.num_inputs < 1) return false;
+    // contrib/template.sol:697 additionally requires num_inputs >= 1 — a restriction of the SOLIDITY verifier only.  `plonkit
+    // verify` calls bellman's Rust verifier::verify (src/plonk.rs:196), which walks proof.input_values with no such
+    // requirement [recollection; unpinned: no fixture has zero inputs], and a circom circuit without public signals is
+    // legal (num_inputs = 1 = wire ONE only, src/reader.rs:197, src/circom_circuit.rs:78): zero inputs are accepted here.
+    if (P.n != vk.n || P.inputs.size() != vk.num_inputs) return false;
     const HFr om = omega_of(log_n), one = HFr::one();
     RollingKeccak tr;
     for (const HFr &x : P.inputs) tr.absorb_fr(x);
@@ -118,9 +122,9 @@ bool verify_keccak(const Vk &vk, const ProofData &P) {
     HFr zN = z; for (uint32_t i = 0; i < log_n; i++) zN = zN.sqr();
     if (zN == one) return false;
     // L_i(z) = w^i (z^N - 1) / (N (z - w^i)) for the public-input rows
-    std::vector<HFr> lag(vk.num_inputs);
+    std::vector<HFr> lag(vk.num_inputs ? vk.num_inputs : 1);          // L_0(z) is needed whatever the number of inputs
     { HFr wi = one; const HFr nf = HFr::from_u64(N);
-      for (uint64_t i = 0; i < vk.num_inputs; i++) { lag[i] = wi * (zN - one) * (nf * (z - wi)).inv(); wi = wi * om; } }
+      for (uint64_t i = 0; i < lag.size(); i++) { lag[i] = wi * (zN - one) * (nf * (z - wi)).inv(); wi = wi * om; } }
     const std::vector<HFr> &wz = P.wire_z, &sz = P.sigma_z;
     // verify_at_z: t(z) (z^N - 1) == r(z) + PI(z) - alpha z(zw) prod_j(..) (gamma + d) - alpha^2 L_0(z)
     {

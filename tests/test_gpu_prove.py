@@ -295,6 +295,52 @@ def test_several_public_inputs(ctx, n_pub, golden_crs):
     assert len(po.read_proof(proof).inputs) == n_pub
 
 
+def _zero_input_circuit(n_cons):
+    """no public input and no output at all: circom's nPubInputs = nOutputs = 0, so num_inputs = 1 (wire ONE only,
+    src/reader.rs:197) and the PLONK circuit has NO input gate (src/circom_circuit.rs:78-113 allocates inputs 1..num_inputs).
+    t_1 = u*v, t_{j+1} = t_j*v — single-variable constraints, inside the pinned transpilation subset."""
+    u, v = 3, 5
+    wit = [1, u, v, u * v % R_MOD]
+    cons = [({"1": "1"}, {"2": "1"}, {"3": "1"})]
+    for _ in range(n_cons - 1):
+        wit.append(wit[-1] * v % R_MOD)
+        cons.append(({str(len(wit) - 2): "1"}, {"2": "1"}, {str(len(wit) - 1): "1"}))
+    r1cs = {"n8": 32, "prime": str(R_MOD), "nVars": len(wit), "nOutputs": 0, "nPubInputs": 0, "nPrvInputs": 2,
+            "nLabels": len(wit), "nConstraints": len(cons), "constraints": [list(c) for c in cons]}
+    return json.dumps(r1cs).encode(), json.dumps([str(x) for x in wit]).encode()
+
+
+@pytest.mark.parametrize("n_cons,domain", [(5, 8), (3000, 1 << 12)])
+def test_zero_public_inputs(ctx, n_cons, domain, golden_crs):
+    """a circuit without public inputs is legal circom (num_inputs = 1: src/reader.rs:197, src/circom_circuit.rs:78);
+    the proof then carries an empty input list (1112 bytes), PI(x) = 0 and the first gate row is a constraint row.
+    Bytes = the oracle's, the real-pairing verifier accepts, a tampered proof is rejected."""
+    import plonkit_amd as pa
+    r1cs_b, wit_b = _zero_input_circuit(n_cons)
+    circ = pa.Circuit(r1cs_b, True, wit_b, True)
+    r1cs, wit = po.load_r1cs_json(json.loads(r1cs_b)), [int(x) for x in json.loads(wit_b)]
+    if domain <= 1 << 10:
+        ctx.srs_upload(golden_crs.g1)
+        crs = golden_crs
+    else:
+        ctx.srs_generate(domain, 0, 42)
+        crs = po.Crs(ctx.srs_download(0, domain), pa.crs42_g2_bytes())
+    ctx.srs_lagrange_clear()
+    setup = pa.SetupForProver(ctx, circ)
+    assert setup.domain_size == domain
+    S = po.setup(r1cs)
+    proof = setup.prove(circ)
+    assert proof == po.write_proof(po.prove(r1cs, wit, crs, S))
+    P = po.read_proof(proof)
+    assert len(P.inputs) == 0 and len(proof) == 1144 - 32
+    vk = setup.verification_key_bytes(crs.g2_raw)
+    assert vk == po.write_vk(po.make_verification_key(S, crs))
+    assert pa.verify(vk, proof) and po.verify(po.read_vk(vk), P, tau=42)
+    P.quotient_polynomial_at_z = (P.quotient_polynomial_at_z + 1) % R_MOD
+    assert not pa.verify(vk, po.write_proof(P)) and not po.verify(po.read_vk(vk), P, tau=42)
+    setup.close(); circ.close()
+
+
 def test_long_linear_combinations_take_the_host_witness_path(ctx, golden_crs):
     """constraints whose linear combinations need chains of temporaries (a temporary defined from another one):
     the prover then evaluates the temporaries on the host in allocation order instead of in the device kernel.

@@ -152,15 +152,16 @@ def _native_worker(rank, world, port, n_per_rank, q):
         L.plk_comm_close(comm)
 
 
-def test_native_combiner_world2_and_world3():
-    for world in (2, 3):
+def test_native_combiner_world2_world3_and_world8():
+    """world 8 = the node size of BASELINE.json configs[2]: eight processes, one hub, every rank ends with the same sums"""
+    for world in (2, 3, 8):
         port = _free_port()
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
-        procs = [ctx.Process(target=_native_worker, args=(r, world, port, 200, q)) for r in range(world)]
+        procs = [ctx.Process(target=_native_worker, args=(r, world, port, 200 if world < 8 else 64, q)) for r in range(world)]
         for p in procs:
             p.start()
-        res = sorted(q.get(timeout=120) for _ in range(world))
+        res = sorted(q.get(timeout=240) for _ in range(world))
         for p in procs:
             p.join(timeout=60)
         assert [r[:2] for r in res] == [(r, True) for r in range(world)]
