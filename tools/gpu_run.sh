@@ -33,7 +33,7 @@ for st in "$@"; do
   kind=${st%%:*}; arg=""; [[ "$st" == *:* ]] && arg=${st#*:}
   echo "=== $st"
   case $kind in
-    tests) ( time timeout 1500 python -m pytest ${arg:-tests} -m gpu -x -q --durations=8 ) > "$O/pytest.log" 2>&1; tail -16 "$O/pytest.log" ;;
+    tests) ( time eval "timeout 1500 python -m pytest ${arg:-tests} -m gpu -x -q --durations=8" ) > "$O/pytest.log" 2>&1; tail -16 "$O/pytest.log" ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ;;
     bench) ( time timeout 900 python bench.py ${arg:---gpus 1 --steps 20 --warmup 5} ) > "$O/bench.log" 2> "$O/bench.err"; python -c "$show" < "$O/bench.log"; tail -3 "$O/bench.err" ;;
     prof-solo) prof solo python bench.py --msm-only --pipeline-depth 1 --steps 20 --warmup 5 ;;
