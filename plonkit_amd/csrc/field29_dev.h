@@ -143,66 +143,117 @@ template <class WP> PLK_HD W9<WP> neg2(const W9<WP> &a) {
 }
 template <class WP> PLK_HD W9<WP> addn(const W9<WP> &a, const W9<WP> &b) { return normw(addw(a, b)); }
 
-// Montgomery product, radix 2^29, R' = 2^261.  Limbs: b < 2^29 (normalised); a may be an un-normalised sum or padded
-// difference: a global column receives at most 9 products a_j*b_i, 9 products m_i*p_j (both factors < 2^29) and one
-// carry (< 2^35), so  9*A*(2^29-1) + 9*(2^29-1)^2 + 2^35 < 2^64  allows a-limbs up to A = 3.28e9 (MULW_A_LIMB_MAX).
-// The sums the kernels feed in: x + y (< 2^30), x + PAD2 - y (< 2^29 + 2.66e9 = 3.19e9).  Checked on the host at the
-// bound (tests/host/field29_check.hip).
+// Montgomery product, radix 2^29, R' = 2^261 — PRODUCT SCANNING: the 18 columns of a*b + m*p are summed one after the
+// other in ONE 64-bit accumulator; the carry of column k (acc >> 29) is the addend of the first multiply-add of column k+1,
+// so no 64-bit addition is ever issued (operand scanning paid one v_lshl_add_u64 per row plus eight in the final
+// normalisation: 58 non-mad instructions per product against 42 here).  CHAIN() pins that association: left alone, the
+// compiler sums a column apart from the carry and joins the two with the very addition this form exists to avoid.
+// Limbs: b < 2^29 (normalised); a may be an un-normalised sum or padded difference: a column receives at most 9 products
+// a_j*b_i, 9 products m_i*p_j (both factors < 2^29) and one carry (< 2^35), so 9*A*(2^29-1) + 9*(2^29-1)^2 + 2^35 < 2^64
+// allows a-limbs up to A = 3.28e9 (MULW_A_LIMB_MAX).  The sums the kernels feed in: x + y (< 2^30), x + PAD2 - y
+// (< 2^29 + 2.66e9 = 3.19e9).  Checked on the host at the bound (tests/host/field29_check.hip).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PLK_CHAIN(acc) asm("" : "+v"(acc))
+#else
+#define PLK_CHAIN(acc) do { } while (0)
+#endif
+// the reduction half of a column: m_k for k < 9 (and its product with p_0), then the carry; or the output limb for k >= 9
+#define PLK_MONT_LOW(k)  { _Pragma("unroll") for (int i = 0; i < (k); i++) { acc += (uint64_t)m[i] * WP::P29[(k) - i]; PLK_CHAIN(acc); } \
+                           m[k] = ((uint32_t)acc * WP::INV29) & M29; acc += (uint64_t)m[k] * WP::P29[0]; acc >>= 29; }
+#define PLK_MONT_HIGH(k) { _Pragma("unroll") for (int i = (k) - 8; i <= 8; i++) { acc += (uint64_t)m[i] * WP::P29[(k) - i]; PLK_CHAIN(acc); } \
+                           r.l[(k) - 9] = (uint32_t)acc & M29; acc >>= 29; }
 template <class WP>
 PLK_HD W9<WP> mulw(const W9<WP> &a, const W9<WP> &b) {
-    uint64_t t[10];
-#pragma unroll
-    for (int j = 0; j < 10; j++) t[j] = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] += (uint64_t)a.l[j] * b.l[i];
-        const uint32_t m = ((uint32_t)t[0] * WP::INV29) & M29;
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * WP::P29[j];
-        const uint64_t c = t[0] >> 29;                               // t[0] is now a multiple of 2^29
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] = t[j + 1];
-        t[0] += c;
-        t[9] = 0;
-    }
+    uint32_t m[9];
     W9<WP> r;
-    uint64_t c = 0;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) { uint64_t s = t[j] + c; r.l[j] = (uint32_t)s & M29; c = s >> 29; }
-    r.l[8] = (uint32_t)(t[8] + c);
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) { acc += (uint64_t)a.l[k - i] * b.l[i]; PLK_CHAIN(acc); }
+        PLK_MONT_LOW(k)
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) { acc += (uint64_t)a.l[k - i] * b.l[i]; PLK_CHAIN(acc); }
+        PLK_MONT_HIGH(k)
+    }
+    r.l[8] = (uint32_t)acc;
     return r;
 }
-// a^2: the cross products a_i*a_j (i < j) are taken once against the doubled operand, 45 + 81 mads instead
-// of 162.  Row i adds a_i^2 to column 2i and 2*a_j*a_i (j > i) to column i+j; every product that belongs to
-// global column g is in place before step g reduces it (the smaller index is <= g/2).
+// Two independent products in lockstep: the multiply-adds of the two accumulator chains alternate, so that no
+// v_mad_u64_u32 reads the result of the one issued just before it (on gfx950 that costs a wait state: the compiler
+// puts an s_nop between every pair of a single chain).
+#define PLK_MONT_LOW2(k)  { _Pragma("unroll") for (int i = 0; i < (k); i++) { acc0 += (uint64_t)m0[i] * WP::P29[(k) - i]; PLK_CHAIN(acc0); acc1 += (uint64_t)m1[i] * WP::P29[(k) - i]; PLK_CHAIN(acc1); } \
+                            m0[k] = ((uint32_t)acc0 * WP::INV29) & M29; m1[k] = ((uint32_t)acc1 * WP::INV29) & M29; \
+                            acc0 += (uint64_t)m0[k] * WP::P29[0]; acc1 += (uint64_t)m1[k] * WP::P29[0]; acc0 >>= 29; acc1 >>= 29; }
+#define PLK_MONT_HIGH2(k) { _Pragma("unroll") for (int i = (k) - 8; i <= 8; i++) { acc0 += (uint64_t)m0[i] * WP::P29[(k) - i]; PLK_CHAIN(acc0); acc1 += (uint64_t)m1[i] * WP::P29[(k) - i]; PLK_CHAIN(acc1); } \
+                            r0.l[(k) - 9] = (uint32_t)acc0 & M29; r1.l[(k) - 9] = (uint32_t)acc1 & M29; acc0 >>= 29; acc1 >>= 29; }
+template <class WP>
+PLK_HD void mulw2(const W9<WP> &a0, const W9<WP> &b0, const W9<WP> &a1, const W9<WP> &b1, W9<WP> &r0, W9<WP> &r1) {
+    uint32_t m0[9], m1[9];
+    uint64_t acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) { acc0 += (uint64_t)a0.l[k - i] * b0.l[i]; PLK_CHAIN(acc0); acc1 += (uint64_t)a1.l[k - i] * b1.l[i]; PLK_CHAIN(acc1); }
+        PLK_MONT_LOW2(k)
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) { acc0 += (uint64_t)a0.l[k - i] * b0.l[i]; PLK_CHAIN(acc0); acc1 += (uint64_t)a1.l[k - i] * b1.l[i]; PLK_CHAIN(acc1); }
+        PLK_MONT_HIGH2(k)
+    }
+    r0.l[8] = (uint32_t)acc0; r1.l[8] = (uint32_t)acc1;
+}
+// two independent squarings in lockstep (see mulw2)
+template <class WP>
+PLK_HD void sqrw2(const W9<WP> &x0, const W9<WP> &x1, W9<WP> &r0, W9<WP> &r1) {
+    uint32_t m0[9], m1[9], d0[9], d1[9];
+    uint64_t acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) { d0[j] = x0.l[j] << 1; d1[j] = x1.l[j] << 1; }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) { acc0 += (uint64_t)d0[k - i] * x0.l[i]; PLK_CHAIN(acc0); acc1 += (uint64_t)d1[k - i] * x1.l[i]; PLK_CHAIN(acc1); }
+        if (k % 2 == 0) { acc0 += (uint64_t)x0.l[k / 2] * x0.l[k / 2]; PLK_CHAIN(acc0); acc1 += (uint64_t)x1.l[k / 2] * x1.l[k / 2]; PLK_CHAIN(acc1); }
+        PLK_MONT_LOW2(k)
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; 2 * i < k; i++) { acc0 += (uint64_t)d0[k - i] * x0.l[i]; PLK_CHAIN(acc0); acc1 += (uint64_t)d1[k - i] * x1.l[i]; PLK_CHAIN(acc1); }
+        if (k % 2 == 0) { acc0 += (uint64_t)x0.l[k / 2] * x0.l[k / 2]; PLK_CHAIN(acc0); acc1 += (uint64_t)x1.l[k / 2] * x1.l[k / 2]; PLK_CHAIN(acc1); }
+        PLK_MONT_HIGH2(k)
+    }
+    r0.l[8] = (uint32_t)acc0; r1.l[8] = (uint32_t)acc1;
+}
+// a^2: the cross products a_i*a_j (i < j) are taken once against the doubled operand: 45 + 81 mads instead of 162
 template <class WP>
 PLK_HD W9<WP> sqrw(const W9<WP> &a) {
-    uint64_t t[10];
-    uint32_t a2[9];
-#pragma unroll
-    for (int j = 0; j < 10; j++) t[j] = 0;
+    uint32_t m[9], a2[9];
+    W9<WP> r;
+    uint64_t acc = 0;
 #pragma unroll
     for (int j = 0; j < 9; j++) a2[j] = a.l[j] << 1;
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-        t[i] += (uint64_t)a.l[i] * a.l[i];                           // global column 2i = local column i
+    for (int k = 0; k < 9; k++) {
 #pragma unroll
-        for (int j = i + 1; j < 9; j++) t[j] += (uint64_t)a2[j] * a.l[i];   // global column i+j = local column j
-        const uint32_t m = ((uint32_t)t[0] * WP::INV29) & M29;
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * WP::P29[j];
-        const uint64_t c = t[0] >> 29;
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] = t[j + 1];
-        t[0] += c;
-        t[9] = 0;
+        for (int i = 0; 2 * i < k; i++) { acc += (uint64_t)a2[k - i] * a.l[i]; PLK_CHAIN(acc); }
+        if (k % 2 == 0) { acc += (uint64_t)a.l[k / 2] * a.l[k / 2]; PLK_CHAIN(acc); }
+        PLK_MONT_LOW(k)
     }
-    W9<WP> r;
-    uint64_t c = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) { uint64_t s = t[j] + c; r.l[j] = (uint32_t)s & M29; c = s >> 29; }
-    r.l[8] = (uint32_t)(t[8] + c);
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; 2 * i < k; i++) { acc += (uint64_t)a2[k - i] * a.l[i]; PLK_CHAIN(acc); }
+        if (k % 2 == 0) { acc += (uint64_t)a.l[k / 2] * a.l[k / 2]; PLK_CHAIN(acc); }
+        PLK_MONT_HIGH(k)
+    }
+    r.l[8] = (uint32_t)acc;
     return r;
 }
 
@@ -210,29 +261,22 @@ PLK_HD W9<WP> sqrw(const W9<WP> &a) {
 // d = k*p - e.  Limbs: a, c < 2^30; b, d < 2^29.  Columns hold at most 9 * (2*2^59 + 2^58) < 2^63.4.
 template <class WP>
 PLK_HD W9<WP> mul2addw(const W9<WP> &a, const W9<WP> &b, const W9<WP> &c, const W9<WP> &d) {
-    uint64_t t[10];
-#pragma unroll
-    for (int j = 0; j < 10; j++) t[j] = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] += (uint64_t)a.l[j] * b.l[i];
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] += (uint64_t)c.l[j] * d.l[i];
-        const uint32_t m = ((uint32_t)t[0] * WP::INV29) & M29;
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * WP::P29[j];
-        const uint64_t cy = t[0] >> 29;
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] = t[j + 1];
-        t[0] += cy;
-        t[9] = 0;
-    }
+    uint32_t m[9];
     W9<WP> r;
-    uint64_t cy = 0;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) { uint64_t s = t[j] + cy; r.l[j] = (uint32_t)s & M29; cy = s >> 29; }
-    r.l[8] = (uint32_t)(t[8] + cy);
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) { acc += (uint64_t)a.l[k - i] * b.l[i]; PLK_CHAIN(acc); acc += (uint64_t)c.l[k - i] * d.l[i]; PLK_CHAIN(acc); }
+        PLK_MONT_LOW(k)
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) { acc += (uint64_t)a.l[k - i] * b.l[i]; PLK_CHAIN(acc); acc += (uint64_t)c.l[k - i] * d.l[i]; PLK_CHAIN(acc); }
+        PLK_MONT_HIGH(k)
+    }
+    r.l[8] = (uint32_t)acc;
     return r;
 }
 
@@ -291,31 +335,28 @@ PLK_HD bool maybe_zero_mod_p(const W9<WP> &a) { return ((a.l[0] * WP::PINV0) & M
 // holds more than 9 * (3 + 1) * 2^58 < 2^64.
 template <class WP>
 PLK_HD W9<WP> mulsum3w(const W9<WP> &a0, const W9<WP> &b0, const W9<WP> &a1, const W9<WP> &b1, const W9<WP> &a2, const W9<WP> &b2) {
-    uint64_t t[10];
-#pragma unroll
-    for (int j = 0; j < 10; j++) t[j] = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] += (uint64_t)a0.l[j] * b0.l[i];
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] += (uint64_t)a1.l[j] * b1.l[i];
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] += (uint64_t)a2.l[j] * b2.l[i];
-        const uint32_t m = ((uint32_t)t[0] * WP::INV29) & M29;
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] += (uint64_t)m * WP::P29[j];
-        const uint64_t cy = t[0] >> 29;
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] = t[j + 1];
-        t[0] += cy;
-        t[9] = 0;
-    }
+    uint32_t m[9];
     W9<WP> r;
-    uint64_t cy = 0;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) { uint64_t s = t[j] + cy; r.l[j] = (uint32_t)s & M29; cy = s >> 29; }
-    r.l[8] = (uint32_t)(t[8] + cy);
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (uint64_t)a0.l[k - i] * b0.l[i]; PLK_CHAIN(acc); acc += (uint64_t)a1.l[k - i] * b1.l[i]; PLK_CHAIN(acc);
+            acc += (uint64_t)a2.l[k - i] * b2.l[i]; PLK_CHAIN(acc);
+        }
+        PLK_MONT_LOW(k)
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) {
+            acc += (uint64_t)a0.l[k - i] * b0.l[i]; PLK_CHAIN(acc); acc += (uint64_t)a1.l[k - i] * b1.l[i]; PLK_CHAIN(acc);
+            acc += (uint64_t)a2.l[k - i] * b2.l[i]; PLK_CHAIN(acc);
+        }
+        PLK_MONT_HIGH(k)
+    }
+    r.l[8] = (uint32_t)acc;
     return r;
 }
 
