@@ -65,7 +65,9 @@ struct plk_ctx {
     std::map<std::vector<uint32_t>, plk::Fr> inv_cache;
     plk::Fr n_inv[plk::MAX_LOG_N + 1];      // 2^-k
     plk::Fr n_inv_w[plk::MAX_LOG_N + 1];    // 2^-k in the 2^261 domain
-    plk::DevBuf ntt_scratch;                 // ping-pong buffer for the transposing final pass
+    plk::DevBuf ntt_scratch[2];              // ping-pong buffers of the NTT passes: [0] main stream, [1] the prover's background stream
+    hipStream_t bg_stream = nullptr;         // low-priority stream of the prover: extensions that no challenge waits for
+    hipEvent_t bg_go = nullptr, bg_done = nullptr;
     // SRS
     const void *srs = nullptr;               // device, Montgomery affine, 64 B per point
     uint64_t srs_n = 0;
@@ -90,6 +92,7 @@ struct plk_ctx {
         uint32_t windows = 0, c_bits = 0, pending_parts = 0, batch = 1, roles = 2, fine_bits = 7;
         hipStream_t stream = nullptr;        // the kernels of this commitment; ordered after the caller's stream by `ready`
         hipEvent_t ready = nullptr;
+        hipEvent_t acc_done = nullptr;       // recorded behind msm_accumulate: from here on the commitment only runs its latency-bound reduction
         hipEvent_t ev[2] = {nullptr, nullptr};   // optional bracket around msm_accumulate (bench roofline)
         bool busy = false;
     } slot[MSM_SLOTS];

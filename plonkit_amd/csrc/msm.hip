@@ -102,6 +102,24 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_digits(ScalarSet set, MsmPara
     }
 }
 
+// Copy-out of a workgroup's LDS-sorted entries: bin b's run staged[lstart[b] .. lstart[b+1]) goes to entries[gbase[b] ..],
+// one run per wave iteration so that the stores are contiguous bursts.  A wave takes 64 consecutive bins: every lane reads
+// the three words describing ITS bin once, and the iterations get them by readlane — the first version read them from LDS
+// inside the loop, three dependent LDS round trips per 16-entry run (64 iterations per wave: ~9 us of a ~50 us workgroup).
+template <int THREADS>
+__device__ __forceinline__ void copy_out_runs(const uint32_t *lstart, const uint32_t *gbase, const uint32_t *staged, uint32_t *entries, uint32_t nbins) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t b0 = wave * 64; b0 < nbins; b0 += (THREADS / 64) * 64) {
+        const uint32_t mine = b0 + lane;
+        const uint32_t my_s = mine < nbins ? lstart[mine] : 0, my_e = mine < nbins ? lstart[mine + 1] : 0, my_g = mine < nbins ? gbase[mine] : 0;
+        const uint32_t live = nbins - b0 < 64 ? nbins - b0 : 64;
+        for (uint32_t j = 0; j < live; j++) {
+            const uint32_t s0 = __shfl(my_s, (int)j), len = __shfl(my_e, (int)j) - s0, g0 = __shfl(my_g, (int)j);
+            for (uint32_t k = lane; k < len; k += 64) entries[g0 + k] = staged[s0 + k];
+        }
+    }
+}
+
 // Steps 2 and 4: one workgroup per (chunk of DIGIT_CHUNK scalars, global window).  COUNT: coarse-bin
 // histogram in LDS -> global.  SCATTER: the chunk's entries are counting-sorted by coarse bin inside LDS,
 // one global reservation per (block, bin), then every bin's run is copied out contiguously — full
@@ -168,11 +186,7 @@ __global__ void __launch_bounds__(PART_THREADS) msm_partition(const int32_t *dig
         }
     }
     __syncthreads();
-    const uint32_t wave = tid >> 6, lane = tid & 63;
-    for (uint32_t b = wave; b < p.nbins; b += PART_THREADS / 64) {
-        const uint32_t s0 = lstart[b], len = lstart[b + 1] - s0, g0 = gbase[b];
-        for (uint32_t k = lane; k < len; k += 64) entries[g0 + k] = staged[s0 + k];
-    }
+    copy_out_runs<PART_THREADS>(lstart, gbase, staged, entries, p.nbins);
 }
 
 // exclusive scan of the (W * nbins) histogram -> bin_start[total+1], and of the per-bin task counts
@@ -202,6 +216,108 @@ __global__ void __launch_bounds__(1024) msm_scan_bins(uint32_t *hist, uint32_t *
         hist[i] = 0;
     }
     if (tid == 1023) { bin_start[total_bins] = sums[1023]; task_start[total_bins] = tsums[1023]; }
+}
+
+// ------------------------------------------------------------------ fused recoding (one bucket set per commitment)
+// With the table of shifted copies every window of a commitment drops into ONE bucket set (groups == 1: up to 2^20 terms,
+// c = 17, 15 windows) — then a scalar's 15 entries can be produced where the scalar is read, and the int32 digit array
+// (60 B per term written by msm_digits, read twice by msm_partition) disappears: both passes read the 32-byte scalar,
+// leave Montgomery form (one product) and recode in registers.  Per term the pre-phase moves 64 B + the 60 B of entries
+// instead of 212 B, in two launches instead of three (0.22 -> ~0.1 ms in front of a 2^20-term commitment: it is on the
+// critical path of every round of a proof, and in a stream of commitments its workgroups displace accumulate workgroups).
+// The workgroup of the scatter pass takes RC_SCALARS scalars x 15 windows = 15360 entries, the same LDS staging volume
+// and the same ~15-entry runs per (workgroup, coarse bin) as the per-window partition it replaces.
+constexpr int RC_THREADS = 1024, RC_SCALARS = 1024, RC_WINDOWS = 15;
+static_assert(RC_WINDOWS == 254 / 17 + 1, "the fused path is the c = 17 shape");
+
+// the signed digits of msm_digits for c = 17, 15 windows, in registers
+__device__ __forceinline__ void recode17(const Fr &k, int32_t (&d)[RC_WINDOWS]) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < RC_WINDOWS; w++) {
+        const uint32_t v = extract_bits(k.l, w * 17, 17) + carry;
+        if (v >= (1u << 16) && w + 1 < RC_WINDOWS) { d[w] = (int32_t)v - (1 << 17); carry = 1; } else { d[w] = (int32_t)v; carry = 0; }
+    }
+}
+
+// pass 1: coarse-bin histogram of the commitment's bucket set; RC_COUNT_PER scalars per thread keep the global atomics at
+// one per (workgroup, bin) for 4096 scalars
+constexpr int RC_COUNT_PER = 4;
+__global__ void __launch_bounds__(RC_THREADS) msm_recode_count(ScalarSet set, MsmParams p, uint32_t *hist) {
+    __shared__ uint32_t lcnt[1024];
+    const uint32_t tid = threadIdx.x, m = blockIdx.y;
+    lcnt[tid] = 0;
+    __syncthreads();
+    Fr k[RC_COUNT_PER];
+    bool live[RC_COUNT_PER];
+#pragma unroll
+    for (int r = 0; r < RC_COUNT_PER; r++) {                      // all loads in flight together
+        const uint32_t i = (blockIdx.x * RC_COUNT_PER + r) * RC_THREADS + tid;
+        live[r] = i < p.n;
+        if (live[r]) k[r] = load_fp(set.v[m] + i);
+    }
+#pragma unroll
+    for (int r = 0; r < RC_COUNT_PER; r++) {
+        if (!live[r]) continue;
+        int32_t d[RC_WINDOWS];
+        recode17(to_canonical(k[r]), d);
+#pragma unroll
+        for (uint32_t w = 0; w < RC_WINDOWS; w++)
+            if (d[w]) { const uint32_t mg = (uint32_t)(d[w] < 0 ? -d[w] : d[w]) - 1; atomicAdd(&lcnt[mg >> p.fine_bits], 1u); }
+    }
+    __syncthreads();
+    if (tid < p.nbins && lcnt[tid]) atomicAdd(&hist[m * p.nbins + tid], lcnt[tid]);
+}
+
+// pass 2: the workgroup's 15 x 1024 entries are counting-sorted by coarse bin inside LDS, one global reservation per
+// (workgroup, bin), contiguous copy-out (same scheme as msm_partition<true>)
+__global__ void __launch_bounds__(RC_THREADS) msm_recode_scatter(ScalarSet set, MsmParams p, uint32_t *cursor, const uint32_t *bin_start, uint32_t *entries) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *lcnt = reinterpret_cast<uint32_t *>(smem);               // [nbins]
+    uint32_t *lstart = lcnt + p.nbins;                                 // [nbins + 1]
+    uint32_t *gbase = lstart + p.nbins + 1;                            // [nbins]
+    uint32_t *staged = gbase + p.nbins;                                // [RC_SCALARS * RC_WINDOWS]
+    const uint32_t tid = threadIdx.x, m = blockIdx.y;
+    const uint32_t i = blockIdx.x * RC_SCALARS + tid;
+    cursor += m * p.nbins; bin_start += m * p.nbins;
+    int32_t d[RC_WINDOWS];
+    if (i < p.n) recode17(to_canonical(load_fp(set.v[m] + i)), d);
+    else {
+#pragma unroll
+        for (uint32_t w = 0; w < RC_WINDOWS; w++) d[w] = 0;
+    }
+    for (uint32_t b = tid; b < p.nbins; b += RC_THREADS) lcnt[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t w = 0; w < RC_WINDOWS; w++)
+        if (d[w]) { const uint32_t mg = (uint32_t)(d[w] < 0 ? -d[w] : d[w]) - 1; atomicAdd(&lcnt[mg >> p.fine_bits], 1u); }
+    __syncthreads();
+    if (tid < 64) {                                                    // exclusive scan of <= 1024 counts by one wave
+        uint32_t per = (p.nbins + 63) / 64, lo = tid * per, hi = lo + per < p.nbins ? lo + per : p.nbins, sum = 0;
+        for (uint32_t b = lo; b < hi; b++) sum += lcnt[b];
+        uint32_t v = sum;
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off); if ((int)tid >= off) v += t; }
+        uint32_t run = v - sum;
+        for (uint32_t b = lo; b < hi; b++) { lstart[b] = run; run += lcnt[b]; }
+        if (tid == 63) lstart[p.nbins] = v;
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < p.nbins; b += RC_THREADS) {
+        const uint32_t cnt = lcnt[b];
+        gbase[b] = cnt ? bin_start[b] + atomicAdd(&cursor[b], cnt) : 0;
+        lcnt[b] = 0;                                                   // reused as the in-bin cursor
+    }
+    __syncthreads();
+    const uint32_t fmask = (1u << p.fine_bits) - 1;
+#pragma unroll
+    for (uint32_t w = 0; w < RC_WINDOWS; w++) {
+        if (!d[w]) continue;
+        const uint32_t mg = (uint32_t)(d[w] < 0 ? -d[w] : d[w]) - 1, bin = mg >> p.fine_bits;
+        // window w takes its point from copy w of the table (groups == 1): copy_tag = w << nbits
+        staged[lstart[bin] + atomicAdd(&lcnt[bin], 1u)] = ((((uint32_t)w << p.nbits) | i) << 8) | (d[w] < 0 ? 0x80u : 0u) | (mg & fmask);
+    }
+    __syncthreads();
+    copy_out_runs<RC_THREADS>(lstart, gbase, staged, entries, p.nbins);
 }
 
 // --------------------------------------------------------------------- bucket accumulation
@@ -701,6 +817,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     if (!S.stream) {
         PLK_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
         PLK_HIP(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
+        PLK_HIP(hipEventCreateWithFlags(&S.acc_done, hipEventDisableTiming));
     }
     if (ctx->ev_on && !S.ev[0]) { PLK_HIP(hipEventCreate(&S.ev[0])); PLK_HIP(hipEventCreate(&S.ev[1])); }
     PLK_HIP(hipEventRecord(S.ready, caller));
@@ -726,13 +843,14 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     S.pending_parts = 0;
     S.windows = 0;
     S.batch = batch;
-    if (n == 0) { in_flight(); return PLK_OK; }
+    if (n == 0) { (void)hipEventRecord(S.acc_done, stream); in_flight(); return PLK_OK; }
     if (n < 4096) {
         uint32_t blocks = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
         PLK_TRY(S.d.reserve((size_t)batch * blocks * sizeof(G1Xyzz)));
         for (uint32_t m = 0; m < batch; m++)
             hipLaunchKernelGGL(msm_naive, dim3(blocks), dim3(MSM_THREADS), 0, stream, bases, scalars_dev[m], (uint32_t)n, S.d.as<G1Xyzz>() + (size_t)m * blocks);
         PLK_HIP(hipGetLastError());
+        (void)hipEventRecord(S.acc_done, stream);
         S.pending_parts = blocks;
         S.c_bits = 0;
         PLK_TRY(slot_pinned(S, (size_t)batch * blocks * sizeof(G1Xyzz)));
@@ -771,23 +889,36 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     G1Xyzz *window_out = S.d.as<G1Xyzz>();
 
     PLK_HIP(hipMemsetAsync(hist, 0, total_bins * sizeof(uint32_t), stream));
-    PLK_TRY(S.f.reserve((size_t)total_windows * n * sizeof(int32_t)));
-    int32_t *digits = S.f.as<int32_t>();
-    hipLaunchKernelGGL(msm_digits, dim3((uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS), batch), dim3(MSM_THREADS), 0, stream, set, p, digits);
-    const uint32_t pblocks = (uint32_t)((n + DIGIT_CHUNK - 1) / DIGIT_CHUNK);
-    const size_t plds_count = (size_t)p.nbins * sizeof(uint32_t);
-    const size_t plds_scatter = (size_t)(3 * p.nbins + 1 + DIGIT_CHUNK) * sizeof(uint32_t);
     static bool attr_set = false;
     if (!attr_set) {
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_partition<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_recode_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<6>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<7>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<6, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(msm_partition<false>, dim3(pblocks, total_windows), dim3(PART_THREADS), plds_count, stream, (const int32_t *)digits, p, hist, (const uint32_t *)nullptr, (uint32_t *)nullptr);
-    hipLaunchKernelGGL(msm_scan_bins, dim3(1), dim3(1024), 0, stream, hist, bin_start, task_start, total_bins);
-    hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks, total_windows), dim3(PART_THREADS), plds_scatter, stream, (const int32_t *)digits, p, hist, (const uint32_t *)bin_start, entries);
+    // PLK_MSM_FUSED_RECODE=0 (A/B knob): the three-launch pre-phase through the digit array, as for several bucket sets
+    static const bool fused_ok = [] { const char *e = getenv("PLK_MSM_FUSED_RECODE"); return !(e && e[0] == '0'); }();
+    if (fused_ok && p.groups == 1 && p.c == 17 && p.windows == RC_WINDOWS && p.nbins <= 1024) {
+        // one bucket set per commitment (the 2^20 shape): digits never leave the registers (msm_recode_count / _scatter)
+        const uint32_t cblocks = (uint32_t)((n + (uint64_t)RC_THREADS * RC_COUNT_PER - 1) / ((uint64_t)RC_THREADS * RC_COUNT_PER));
+        const uint32_t sblocks = (uint32_t)((n + RC_SCALARS - 1) / RC_SCALARS);
+        const size_t lds = (size_t)(3 * p.nbins + 1 + RC_SCALARS * RC_WINDOWS) * sizeof(uint32_t);
+        hipLaunchKernelGGL(msm_recode_count, dim3(cblocks, batch), dim3(RC_THREADS), 0, stream, set, p, hist);
+        hipLaunchKernelGGL(msm_scan_bins, dim3(1), dim3(1024), 0, stream, hist, bin_start, task_start, total_bins);
+        hipLaunchKernelGGL(msm_recode_scatter, dim3(sblocks, batch), dim3(RC_THREADS), lds, stream, set, p, hist, (const uint32_t *)bin_start, entries);
+    } else {
+        PLK_TRY(S.f.reserve((size_t)total_windows * n * sizeof(int32_t)));
+        int32_t *digits = S.f.as<int32_t>();
+        hipLaunchKernelGGL(msm_digits, dim3((uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS), batch), dim3(MSM_THREADS), 0, stream, set, p, digits);
+        const uint32_t pblocks = (uint32_t)((n + DIGIT_CHUNK - 1) / DIGIT_CHUNK);
+        const size_t plds_count = (size_t)p.nbins * sizeof(uint32_t);
+        const size_t plds_scatter = (size_t)(3 * p.nbins + 1 + DIGIT_CHUNK) * sizeof(uint32_t);
+        hipLaunchKernelGGL(msm_partition<false>, dim3(pblocks, total_windows), dim3(PART_THREADS), plds_count, stream, (const int32_t *)digits, p, hist, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+        hipLaunchKernelGGL(msm_scan_bins, dim3(1), dim3(1024), 0, stream, hist, bin_start, task_start, total_bins);
+        hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks, total_windows), dim3(PART_THREADS), plds_scatter, stream, (const int32_t *)digits, p, hist, (const uint32_t *)bin_start, entries);
+    }
     if (ctx->ev_on) PLK_HIP(hipEventRecord(S.ev[0], stream));
     const uint32_t rblocks = (max_tasks * RL + MSM_THREADS - 1) / MSM_THREADS;
     auto launch_shape = [&](auto fb_tag) {
@@ -801,6 +932,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
         hipLaunchKernelGGL(msm_accumulate<FB>, dim3(max_tasks), dim3(MSM_THREADS), CHUNK * sizeof(uint32_t), stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
                            (const uint32_t *)task_start, partials, task_meta, p);
         if (ctx->ev_on) (void)hipEventRecord(S.ev[1], stream);
+        (void)hipEventRecord(S.acc_done, stream);
         hipLaunchKernelGGL(msm_fold_hot<FB>, dim3(rblocks), dim3(MSM_THREADS), 0, stream, partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
         hipLaunchKernelGGL(msm_task_reduce<FB>, dim3(rblocks), dim3(MSM_THREADS), 0, stream,
                            (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);

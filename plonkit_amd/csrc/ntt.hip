@@ -37,9 +37,10 @@ namespace plk {
 constexpr int NTT_THREADS = 512;               // 8 waves per workgroup, 2 workgroups per CU (LDS): 4 waves per SIMD
 constexpr int LOG_TILE = 11;                   // 2048 elements per workgroup
 
+constexpr uint32_t NTT_MAX_BATCH = 8;          // transforms of equal shape sharing one launch per pass (blockIdx.y)
 struct NttPassArgs {
-    const Fr *in;
-    Fr *out;
+    const Fr *in_b[NTT_MAX_BATCH];             // per transform of the batch: where this pass reads ...
+    Fr *out_b[NTT_MAX_BATCH];                  // ... and writes
     uint32_t log_n, log_r, log_c;
     uint32_t log_inner;                        // type-A: row stride = 2^log_inner
     uint32_t log_r1, log_m1, log_m2;           // final pass: digit widths of k1 and the middle digits
@@ -188,6 +189,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
     const uint32_t T = 1u << (log_r + log_c);
     LdsTile L{reinterpret_cast<u32x4 *>(smem), reinterpret_cast<u32x4 *>(smem) + T, reinterpret_cast<uint32_t *>(reinterpret_cast<u32x4 *>(smem) + 2 * T)};
     const uint32_t tid = threadIdx.x, t = blockIdx.x;
+    const Fr *const in = a.in_b[blockIdx.y];
+    Fr *const out = a.out_b[blockIdx.y];
     const uint32_t tiles_log = a.log_inner - log_c;
     const uint32_t o = t >> tiles_log, c0 = (t & ((1u << tiles_log) - 1)) << log_c;
     const size_t base = ((size_t)o << (log_r + a.log_inner)) + c0;
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
         size_t g = base + ((size_t)brev(p, log_r) << a.log_inner) + c;     // rows fetched in bit-reversed order
         FrW9 v = w_zero<FrW>();
         if (!a.nonzero || g < a.nonzero) {
-            v = ldw(a.in + g);
+            v = ldw(in + g);
             if (a.pre.lo) v = mulw(v, pow2l_w(a.pre, (uint32_t)g));
         }
         L.put(idx, v);
@@ -213,7 +216,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
         const FrW9 t = a.tw_direct ? ldw(a.tw_direct + ((size_t)k << a.log_inner) + c0 + c)
                      : eshift >= POW_SPLIT ? ldw(a.tw.hi + (e >> POW_SPLIT)) : pow2l_w(a.tw, e);
         FrW9 v = mulw(L.get(idx), t);                                         // < 1.1p: fits 256 bits, stays lazy
-        store_fp(a.out + base + ((size_t)k << a.log_inner) + c, pack<FrParams>(v));
+        store_fp(out + base + ((size_t)k << a.log_inner) + c, pack<FrParams>(v));
     }
 }
 
@@ -224,6 +227,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
     const uint32_t T = 1u << (log_r + log_c);
     LdsTile L{reinterpret_cast<u32x4 *>(smem), reinterpret_cast<u32x4 *>(smem) + T, reinterpret_cast<uint32_t *>(reinterpret_cast<u32x4 *>(smem) + 2 * T)};
     const uint32_t tid = threadIdx.x, t = blockIdx.x;
+    const Fr *const in = a.in_b[blockIdx.y];
+    Fr *const out = a.out_b[blockIdx.y];
     const uint32_t kb_log = a.log_r1 - log_c, log_m = a.log_m1 + a.log_m2;
     const uint32_t k1_0 = (t & ((1u << kb_log) - 1)) << log_c, mu = t >> kb_log;
 
@@ -233,7 +238,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
         size_t g = (rho << log_r) + n;
         FrW9 v = w_zero<FrW>();
         if (!a.nonzero || g < a.nonzero) {
-            v = ldw(a.in + g);
+            v = ldw(in + g);
             if (a.pre.lo) v = mulw(v, pow2l_w(a.pre, (uint32_t)g));
         }
         L.put(brev(n, log_r) * C + c, v);                                    // bit reversal as an LDS scatter
@@ -249,7 +254,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
         FrW9 v = L.get(k * C + c);
         if (a.post.lo) v = mulw(v, pow2l_w(a.post, (uint32_t)o));
         v = a.has_scale ? csub_p(mulw(v, last)) : reduce_small(v);          // canonical output (values here are < 24p)
-        store_fp(a.out + o, pack<FrParams>(v));
+        store_fp(out + o, pack<FrParams>(v));
     }
 }
 
@@ -429,15 +434,35 @@ static int32_t ntt_direct_table(plk_ctx *ctx, bool inverse, uint32_t log_r, uint
 // ------------------------------------------------------------------------------- driver
 static bool g_attr_set = false;
 
-// src: where the first pass reads (data itself for an in-place transform); nonzero: see NttPassArgs
-static int32_t ntt_run(plk_ctx *ctx, const Fr *src, uint64_t nonzero, Fr *data, uint32_t log_n, bool inverse, const Fr *coset, hipStream_t stream);
+// src: where the first pass reads (data itself for an in-place transform); nonzero: see NttPassArgs.
+// `count` transforms of the same shape share every launch (grid.y): a 2^20-point pass is ONE round of 512 tiles on the
+// chip's 512 workgroup slots, i.e. its time is the latency of a tile's load -> LDS stages -> store chain; four vectors
+// per launch run at the throughput rate instead (the four wire polynomials of round 1, their four extensions).
+// `lane` selects the ping-pong scratch: transforms enqueued on different streams at the same time must not share it
+// (lane 1 = the prover's background stream).
+static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr *const *data, uint32_t count, uint32_t log_n, bool inverse,
+                       const Fr *coset, hipStream_t stream, uint32_t lane);
 
 int32_t ntt_dev(plk_ctx *ctx, Fr *data, uint32_t log_n, bool inverse, const Fr *coset, hipStream_t stream) {
-    return ntt_run(ctx, data, 0, data, log_n, inverse, coset, stream);
+    const Fr *src = data;
+    return ntt_run(ctx, &src, 0, &data, 1, log_n, inverse, coset, stream, 0);
 }
 
-static int32_t ntt_run(plk_ctx *ctx, const Fr *src, uint64_t nonzero, Fr *data, uint32_t log_n, bool inverse, const Fr *coset, hipStream_t stream) {
-    if (!data || !src) { set_error("ntt: null data"); return PLK_ERR_ARG; }
+int32_t ntt_batch_dev(plk_ctx *ctx, Fr *const *data, uint32_t count, uint32_t log_n, bool inverse, const Fr *coset, hipStream_t stream, uint32_t lane) {
+    for (uint32_t done = 0; done < count;) {
+        const uint32_t b = count - done > NTT_MAX_BATCH ? NTT_MAX_BATCH : count - done;
+        const Fr *src[NTT_MAX_BATCH];
+        for (uint32_t k = 0; k < b; k++) src[k] = data[done + k];
+        PLK_TRY(ntt_run(ctx, src, 0, data + done, b, log_n, inverse, coset, stream, lane));
+        done += b;
+    }
+    return PLK_OK;
+}
+
+static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr *const *data, uint32_t count, uint32_t log_n, bool inverse,
+                       const Fr *coset, hipStream_t stream, uint32_t lane) {
+    if (!data || !src || count == 0 || count > NTT_MAX_BATCH || lane >= 2) { set_error("ntt: bad argument"); return PLK_ERR_ARG; }
+    for (uint32_t b = 0; b < count; b++) if (!data[b] || !src[b]) { set_error("ntt: null data"); return PLK_ERR_ARG; }
     if (log_n > MAX_LOG_N) { set_error("ntt: log_n exceeds the 2-adicity of Fr (28)"); return PLK_ERR_SIZE; }
     if (log_n == 0) return PLK_OK;
     PLK_TRY(ntt_init_tables(ctx));
@@ -462,9 +487,8 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *src, uint64_t nonzero, Fr *data, 
         }
     }
     const size_t n = (size_t)1 << log_n;
-    Fr *scratch = nullptr;
-    PLK_TRY(ctx->ntt_scratch.reserve(n * sizeof(Fr)));
-    scratch = ctx->ntt_scratch.as<Fr>();
+    PLK_TRY(ctx->ntt_scratch[lane].reserve((size_t)count * n * sizeof(Fr)));
+    Fr *const scratch = ctx->ntt_scratch[lane].as<Fr>();
 
     NttPassArgs a{};
     a.log_n = log_n;
@@ -474,7 +498,7 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *src, uint64_t nonzero, Fr *data, 
     bool scale_folded = false;
     for (uint32_t i = 0; i + 1 < p; i++) {
         rem -= d[i];
-        a.in = (i == 0) ? src : scratch; a.out = scratch;
+        for (uint32_t b = 0; b < count; b++) { a.in_b[b] = (i == 0) ? src[b] : scratch + (size_t)b * n; a.out_b[b] = scratch + (size_t)b * n; }
         a.nonzero = (i == 0) ? (uint32_t)nonzero : 0;
         a.log_r = d[i]; a.log_inner = rem;
         a.log_c = (LOG_TILE - d[i]) < rem ? (LOG_TILE - d[i]) : rem;
@@ -485,10 +509,10 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *src, uint64_t nonzero, Fr *data, 
         a.quarter = (i == 0 && nonzero && nonzero == (n >> 2) && !(d[0] & 1) && d[0] >= 2) ? 1 : 0;
         uint32_t tiles = (uint32_t)(n >> (a.log_r + a.log_c));
         size_t lds = (size_t)36 << (a.log_r + a.log_c);
-        hipLaunchKernelGGL(ntt_pass_cols, dim3(tiles), dim3(NTT_THREADS), lds, stream, a);
+        hipLaunchKernelGGL(ntt_pass_cols, dim3(tiles, count), dim3(NTT_THREADS), lds, stream, a);
     }
     {
-        a.in = (p == 1) ? src : scratch; a.out = (p == 1) ? scratch : data;
+        for (uint32_t b = 0; b < count; b++) { a.in_b[b] = (p == 1) ? src[b] : scratch + (size_t)b * n; a.out_b[b] = (p == 1) ? scratch + (size_t)b * n : data[b]; }
         a.nonzero = (p == 1) ? (uint32_t)nonzero : 0;
         a.log_r = d[p - 1];
         if (p == 1) { a.log_r1 = 0; a.log_m1 = a.log_m2 = 0; a.log_c = 0; }
@@ -505,21 +529,32 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *src, uint64_t nonzero, Fr *data, 
         if (a.has_scale) a.scale = ctx->n_inv_w[log_n];
         uint32_t tiles = (uint32_t)(n >> (a.log_r + a.log_c));
         size_t lds = (size_t)36 << (a.log_r + a.log_c);
-        hipLaunchKernelGGL(ntt_pass_rows, dim3(tiles), dim3(NTT_THREADS), lds, stream, a);
+        hipLaunchKernelGGL(ntt_pass_rows, dim3(tiles, count), dim3(NTT_THREADS), lds, stream, a);
     }
     PLK_HIP(hipGetLastError());
-    if (p == 1) PLK_HIP(hipMemcpyAsync(data, scratch, n * sizeof(Fr), hipMemcpyDeviceToDevice, stream));
+    if (p == 1) for (uint32_t b = 0; b < count; b++) PLK_HIP(hipMemcpyAsync(data[b], scratch + (size_t)b * n, n * sizeof(Fr), hipMemcpyDeviceToDevice, stream));
     return PLK_OK;
 }
 
-int32_t lde4_dev(plk_ctx *ctx, const Fr *coeffs, uint32_t log_n, Fr *out_4n, hipStream_t stream) {
+int32_t lde4_batch_dev(plk_ctx *ctx, const Fr *const *coeffs, uint32_t count, uint32_t log_n, Fr *const *out_4n, hipStream_t stream, uint32_t lane) {
     if (log_n + 2 > MAX_LOG_N) { set_error("lde4: 4n exceeds 2^28"); return PLK_ERR_SIZE; }
     const size_t n = (size_t)1 << log_n;
     // the zero-padded 4n-point coset transform without materialising the padding: the first pass reads the n
     // coefficients where they are and treats every index >= n as zero (no copy, no memset, no scaling of zeros)
-    if (coeffs == out_4n) { set_error("lde4: input and output must not alias"); return PLK_ERR_ARG; }
+    for (uint32_t k = 0; k < count; k++) if (coeffs[k] == out_4n[k]) { set_error("lde4: input and output must not alias"); return PLK_ERR_ARG; }
     Fr g = from_u64<FrParams>(7);
-    return ntt_run(ctx, coeffs, n, out_4n, log_n + 2, false, &g, stream);
+    // one launch per pass for the whole batch while its ping-pong scratch stays below 2 GiB (count x 4n x 32 B)
+    const uint32_t per = log_n + 2 <= 22 ? NTT_MAX_BATCH : (log_n + 2 <= 24 ? 4 : 1);
+    for (uint32_t done = 0; done < count;) {
+        const uint32_t b = count - done > per ? per : count - done;
+        PLK_TRY(ntt_run(ctx, coeffs + done, n, out_4n + done, b, log_n + 2, false, &g, stream, lane));
+        done += b;
+    }
+    return PLK_OK;
+}
+
+int32_t lde4_dev(plk_ctx *ctx, const Fr *coeffs, uint32_t log_n, Fr *out_4n, hipStream_t stream) {
+    return lde4_batch_dev(ctx, &coeffs, 1, log_n, &out_4n, stream, 0);
 }
 
 }  // namespace plk

@@ -470,19 +470,56 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
         PLK_HIP(hipEventRecord(ctx->flag_ready, st));
     }
 
-    // ---- round 1: wire polynomials, 4 x iNTT(N), 4 x MSM(N)
+    // The extensions that no challenge waits for (wires, z, public inputs: round-3 inputs) run on a low-priority stream of
+    // their own with their own NTT scratch: they fill the SIMDs that the latency-bound ends of a commitment leave idle
+    // without standing between two rounds — on the main stream round 2 queued up behind the four wire extensions, which
+    // in turn were starved by the accumulation they shared the GPU with (round 1: 6.4-7.0 ms).  Up to the 2^24 domain (a
+    // second 4N scratch above that is memory better spent elsewhere); PLK_PROVE_BG=0 restores the single stream.
+    static const bool bg_env = [] { const char *e = getenv("PLK_PROVE_BG"); return !(e && e[0] == '0'); }();
+    const bool use_bg = bg_env && log_n <= 24;
+    if (use_bg && !ctx->bg_stream) {
+        int lo_prio = 0, hi_prio = 0;
+        PLK_HIP(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+        PLK_HIP(hipStreamCreateWithPriority(&ctx->bg_stream, hipStreamNonBlocking, lo_prio));
+        PLK_HIP(hipEventCreateWithFlags(&ctx->bg_go, hipEventDisableTiming));
+        PLK_HIP(hipEventCreateWithFlags(&ctx->bg_done, hipEventDisableTiming));
+    }
+    hipStream_t bg = use_bg ? ctx->bg_stream : st;
+    const uint32_t bg_lane = use_bg ? 1 : 0;
+    struct BgGuard {                                          // an early return must not leave background work writing into the arena
+        hipStream_t s; bool armed;
+        ~BgGuard() { if (armed && s) (void)hipStreamSynchronize(s); }
+    } bg_guard{use_bg ? ctx->bg_stream : nullptr, use_bg};
+    // What follows on bg starts after everything enqueued on st so far AND after the accumulation of the commitment enqueued
+    // last: stream priorities do not keep a 8192-workgroup NTT pass from taking the CUs first (measured: the pre-phase of the
+    // wire commitments took 2.1 ms instead of 0.35 behind it), so the start is placed by hand where the GPU has room — the
+    // bucket reduction of that commitment, the point-wise kernels of the next round and the pre-phase of its commitment.
+    auto bg_after_main = [&]() -> int32_t {
+        if (!use_bg) return PLK_OK;
+        PLK_HIP(hipEventRecord(ctx->bg_go, st));
+        PLK_HIP(hipStreamWaitEvent(bg, ctx->bg_go, 0));
+        if (ctx->msm_enq != ctx->msm_fin) {
+            plk_ctx::MsmSlot &L = ctx->slot[ctx->fifo[(ctx->msm_enq - 1) % plk_ctx::MSM_SLOTS]];
+            if (L.acc_done) PLK_HIP(hipStreamWaitEvent(bg, L.acc_done, 0));
+        }
+        return PLK_OK;
+    };
+
+    // ---- round 1: wire polynomials, 4 x iNTT(N) in one launch per pass, 4 x MSM(N)
     for (int j = 0; j < 4; j++) {
         PLK_TRY(gather(w_vals[j], d_values, S->gate_vars[j], (uint32_t)N, st));
         PLK_HIP(hipMemcpyAsync(w_coef[j], w_vals[j], N * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-        PLK_TRY(ntt_dev(ctx, w_coef[j], log_n, true, nullptr, st));
     }
+    if (log_n <= 22) PLK_TRY(ntt_batch_dev(ctx, w_coef, 4, log_n, true, nullptr, st, 0));
+    else for (int j = 0; j < 4; j++) PLK_TRY(ntt_dev(ctx, w_coef[j], log_n, true, nullptr, st));
     // with a Lagrange-form key of the domain's size resident (`prove -l`, src/plonk.rs:138-146) the witness and
     // grand-product polynomials are committed from their evaluations, as bellman's prove() does; same proof bytes
     const bool use_lagrange = ctx->lag.pts != nullptr;
     if (use_lagrange && (ctx->combine ? ctx->lag.n != ctx->srs_n : ctx->lag.n != N)) { set_error("Lagrange-form key has a different size than the circuit's domain"); return PLK_ERR_SRS; }
     HAffine wire_c[4];
     PLK_TRY(commit_begin(ctx, use_lagrange ? w_vals : w_coef, 4, N, use_lagrange));
-    for (int j = 0; j < 4; j++) PLK_TRY(lde4_dev(ctx, w_coef[j], log_n, ext[j], st));      // round-3 work that needs no challenge
+    PLK_TRY(bg_after_main());
+    PLK_TRY(lde4_batch_dev(ctx, w_coef, 4, log_n, ext, bg, bg_lane));                       // round-3 work that needs no challenge
     PLK_HIP(hipEventSynchronize(ctx->flag_ready));
     if (*reinterpret_cast<volatile uint32_t *>(ctx->pinned)) { set_error("must satisfy: witness does not satisfy the circuit"); return PLK_ERR_UNSAT; }
     PLK_TRY(commit_end(ctx, 4, wire_c));
@@ -517,13 +554,19 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     HAffine z_c;
     { const Fr *zp = use_lagrange ? t1 : z_coef; PLK_TRY(commit_begin(ctx, &zp, 1, N, use_lagrange)); }
     // while z is being committed: its extension, the public-input polynomial, and (first proof only) the constant vectors
-    PLK_TRY(lde4_dev(ctx, z_coef, log_n, ext[4], st));
-    if (!direct_pi) {
-        PLK_HIP(hipMemsetAsync(pi_coef, 0, N * sizeof(Fr), st));
-        PLK_HIP(hipMemcpyAsync(pi_coef, inputs.data(), inputs.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
-        PLK_TRY(ntt_dev(ctx, pi_coef, log_n, true, nullptr, st));
-        PLK_TRY(lde4_dev(ctx, pi_coef, log_n, ext[16], st));
+    PLK_TRY(bg_after_main());
+    {
+        const Fr *zc = z_coef;
+        PLK_TRY(lde4_batch_dev(ctx, &zc, 1, log_n, &ext[4], bg, bg_lane));
     }
+    if (!direct_pi) {
+        PLK_HIP(hipMemsetAsync(pi_coef, 0, N * sizeof(Fr), bg));
+        PLK_HIP(hipMemcpyAsync(pi_coef, inputs.data(), inputs.size() * sizeof(Fr), hipMemcpyHostToDevice, bg));
+        PLK_TRY(ntt_batch_dev(ctx, &pi_coef, 1, log_n, true, nullptr, bg, bg_lane));
+        const Fr *pc = pi_coef;
+        PLK_TRY(lde4_batch_dev(ctx, &pc, 1, log_n, &ext[16], bg, bg_lane));
+    }
+    if (use_bg) PLK_HIP(hipEventRecord(ctx->bg_done, bg));
     PLK_TRY(commit_end(ctx, 1, &z_c));
     tr.absorb_g1(z_c);
     const HFr alpha = tr.challenge();
@@ -580,6 +623,7 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
         }
         for (int k = 0; k < 4; k++) qa.zh_inv_w[k] = to_dev(S->zh_inv[k] * two5);
         qa.m = (uint32_t)M; qa.log_m = log_m;
+        if (use_bg) PLK_HIP(hipStreamWaitEvent(st, ctx->bg_done, 0));      // the five extensions (+ PI) of the background stream
         PLK_TRY(quotient(qa, st));
         Fr g = to_dev(coset);
         PLK_TRY(ntt_dev(ctx, t_ext, log_m, true, &g, st));
@@ -589,6 +633,7 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
         const Fr *parts[4] = {t_ext, t_ext + N, t_ext + 2 * N, t_ext + 3 * N};
         PLK_TRY(commit_many(ctx, parts, 4, N, t_c));
     }
+    bg_guard.armed = false;                                   // the quotient consumed everything the background stream produced
     for (int k = 0; k < 4; k++) tr.absorb_g1(t_c[k]);
     const HFr z = tr.challenge();
     lap();                                                                    // [3] round 3

@@ -110,20 +110,25 @@ void plk_destroy(plk_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
     for (auto &S : ctx->slot) if (S.stream) (void)hipStreamSynchronize(S.stream);     // commitments still in flight
+    if (ctx->bg_stream) (void)hipStreamSynchronize(ctx->bg_stream);
     comm_release(ctx);
     for (void *p : ctx->coset_allocs) (void)hipFree(p);
-    ctx->tables.release(); ctx->ntt_scratch.release(); ctx->srs_own.release(); ctx->srs_w.release(); ctx->lag.own.release(); ctx->lag.w.release();
+    ctx->tables.release(); ctx->ntt_scratch[0].release(); ctx->ntt_scratch[1].release(); ctx->srs_own.release(); ctx->srs_w.release(); ctx->lag.own.release(); ctx->lag.w.release();
     for (auto &S : ctx->slot) {
         S.a.release(); S.b.release(); S.c.release(); S.d.release(); S.e.release(); S.f.release();
         if (S.pinned) (void)hipHostFree(S.pinned);
         if (S.stream) (void)hipStreamDestroy(S.stream);
         if (S.ready) (void)hipEventDestroy(S.ready);
+        if (S.acc_done) (void)hipEventDestroy(S.acc_done);
         if (S.ev[0]) { (void)hipEventDestroy(S.ev[0]); (void)hipEventDestroy(S.ev[1]); }
     }
     ctx->stage.release(); ctx->poly_tmp.release(); ctx->poly_tmp2.release(); ctx->prove_ws.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned2) (void)hipHostFree(ctx->pinned2);
     if (ctx->flag_ready) (void)hipEventDestroy(ctx->flag_ready);
+    if (ctx->bg_go) (void)hipEventDestroy(ctx->bg_go);
+    if (ctx->bg_done) (void)hipEventDestroy(ctx->bg_done);
+    if (ctx->bg_stream) (void)hipStreamDestroy(ctx->bg_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
