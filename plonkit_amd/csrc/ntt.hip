@@ -37,7 +37,7 @@ namespace plk {
 constexpr int NTT_THREADS = 512;               // 8 waves per workgroup, 2 workgroups per CU (LDS): 4 waves per SIMD
 constexpr int LOG_TILE = 11;                   // 2048 elements per workgroup
 
-constexpr uint32_t NTT_MAX_BATCH = 8;          // transforms of equal shape sharing one launch per pass (blockIdx.y)
+constexpr uint32_t NTT_MAX_BATCH = 16;         // transforms of equal shape sharing one launch per pass (blockIdx.y)
 struct NttPassArgs {
     const Fr *in_b[NTT_MAX_BATCH];             // per transform of the batch: where this pass reads ...
     Fr *out_b[NTT_MAX_BATCH];                  // ... and writes
@@ -45,7 +45,7 @@ struct NttPassArgs {
     uint32_t log_inner;                        // type-A: row stride = 2^log_inner
     uint32_t log_r1, log_m1, log_m2;           // final pass: digit widths of k1 and the middle digits
     PowTable tw;                               // omega_{2^28}^(+-e)
-    PowTable pre;                              // optional: multiply input i by pre^i (first pass)
+    PowTable pre_b[NTT_MAX_BATCH];             // optional, per transform: multiply input i by pre^i (first pass)
     PowTable post;                             // optional: multiply output k by post^k (last pass)
     Fr scale;                                  // optional 1/n on the last pass
     uint32_t has_scale;
@@ -191,6 +191,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
     const uint32_t tid = threadIdx.x, t = blockIdx.x;
     const Fr *const in = a.in_b[blockIdx.y];
     Fr *const out = a.out_b[blockIdx.y];
+    const PowTable pre = a.pre_b[blockIdx.y];
     const uint32_t tiles_log = a.log_inner - log_c;
     const uint32_t o = t >> tiles_log, c0 = (t & ((1u << tiles_log) - 1)) << log_c;
     const size_t base = ((size_t)o << (log_r + a.log_inner)) + c0;
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
         FrW9 v = w_zero<FrW>();
         if (!a.nonzero || g < a.nonzero) {
             v = ldw(in + g);
-            if (a.pre.lo) v = mulw(v, pow2l_w(a.pre, (uint32_t)g));
+            if (pre.lo) v = mulw(v, pow2l_w(pre, (uint32_t)g));
         }
         L.put(idx, v);
     }
@@ -229,6 +230,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
     const uint32_t tid = threadIdx.x, t = blockIdx.x;
     const Fr *const in = a.in_b[blockIdx.y];
     Fr *const out = a.out_b[blockIdx.y];
+    const PowTable pre = a.pre_b[blockIdx.y];
     const uint32_t kb_log = a.log_r1 - log_c, log_m = a.log_m1 + a.log_m2;
     const uint32_t k1_0 = (t & ((1u << kb_log) - 1)) << log_c, mu = t >> kb_log;
 
@@ -239,7 +241,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
         FrW9 v = w_zero<FrW>();
         if (!a.nonzero || g < a.nonzero) {
             v = ldw(in + g);
-            if (a.pre.lo) v = mulw(v, pow2l_w(a.pre, (uint32_t)g));
+            if (pre.lo) v = mulw(v, pow2l_w(pre, (uint32_t)g));
         }
         L.put(brev(n, log_r) * C + c, v);                                    // bit reversal as an LDS scatter
     }
@@ -441,7 +443,7 @@ static bool g_attr_set = false;
 // `lane` selects the ping-pong scratch: transforms enqueued on different streams at the same time must not share it
 // (lane 1 = the prover's background stream).
 static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr *const *data, uint32_t count, uint32_t log_n, bool inverse,
-                       const Fr *coset, hipStream_t stream, uint32_t lane);
+                       const Fr *coset, hipStream_t stream, uint32_t lane, const PowTable *pre_each = nullptr);
 
 int32_t ntt_dev(plk_ctx *ctx, Fr *data, uint32_t log_n, bool inverse, const Fr *coset, hipStream_t stream) {
     const Fr *src = data;
@@ -459,8 +461,9 @@ int32_t ntt_batch_dev(plk_ctx *ctx, Fr *const *data, uint32_t count, uint32_t lo
     return PLK_OK;
 }
 
+// pre_each: one input-scaling table per transform of the batch (the four cosets of lde4cm_batch_dev) instead of `coset`
 static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr *const *data, uint32_t count, uint32_t log_n, bool inverse,
-                       const Fr *coset, hipStream_t stream, uint32_t lane) {
+                       const Fr *coset, hipStream_t stream, uint32_t lane, const PowTable *pre_each) {
     if (!data || !src || count == 0 || count > NTT_MAX_BATCH || lane >= 2) { set_error("ntt: bad argument"); return PLK_ERR_ARG; }
     for (uint32_t b = 0; b < count; b++) if (!data[b] || !src[b]) { set_error("ntt: null data"); return PLK_ERR_ARG; }
     if (log_n > MAX_LOG_N) { set_error("ntt: log_n exceeds the 2-adicity of Fr (28)"); return PLK_ERR_SIZE; }
@@ -502,7 +505,7 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
         a.nonzero = (i == 0) ? (uint32_t)nonzero : 0;
         a.log_r = d[i]; a.log_inner = rem;
         a.log_c = (LOG_TILE - d[i]) < rem ? (LOG_TILE - d[i]) : rem;
-        a.pre = (i == 0) ? pre : PowTable{};
+        for (uint32_t b = 0; b < count; b++) a.pre_b[b] = (i == 0) ? (pre_each ? pre_each[b] : pre) : PowTable{};
         a.post = PowTable{}; a.has_scale = 0;
         PLK_TRY(ntt_direct_table(ctx, inverse, d[i], rem, inverse && i == 0, log_n, stream, &a.tw_direct));
         if (a.tw_direct && inverse && i == 0) scale_folded = true;
@@ -522,7 +525,7 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
             a.log_m2 = p >= 4 ? d[2] : 0;
             a.log_c = (LOG_TILE - a.log_r) < d[0] ? (LOG_TILE - a.log_r) : d[0];
         }
-        a.pre = (p == 1) ? pre : PowTable{};
+        for (uint32_t b = 0; b < count; b++) a.pre_b[b] = (p == 1) ? (pre_each ? pre_each[b] : pre) : PowTable{};
         a.post = post;
         a.tw_direct = nullptr; a.quarter = 0;
         a.has_scale = (inverse && !scale_folded) ? 1 : 0;
@@ -555,6 +558,38 @@ int32_t lde4_batch_dev(plk_ctx *ctx, const Fr *const *coeffs, uint32_t count, ui
 
 int32_t lde4_dev(plk_ctx *ctx, const Fr *coeffs, uint32_t log_n, Fr *out_4n, hipStream_t stream) {
     return lde4_batch_dev(ctx, &coeffs, 1, log_n, &out_4n, stream, 0);
+}
+
+// The same 4n evaluations in COSET-MAJOR order: out[k * n + r] = f(7 * omega_4n^(4 r + k)), k = 0..3 — the layout the
+// prover's round 3 works in.  The coset 7 * <omega_4n> is the union of the four cosets g_k * <omega_n>, g_k = 7 * omega_4n^k,
+// so the extension is four n-point coset transforms of the SAME coefficients (input scaled by g_k^i on load): 4 n log n
+// butterflies instead of 4 n (log n + 2), and — what counts on this chip — two passes over n elements per coset (8 n
+// element-passes at 2^20) instead of three passes over 4 n (12 n), with all cosets of up to four polynomials in one launch
+// per pass.  Natural order (lde4_dev) needs the interleaving k + 4 r, i.e. 32-byte stores at a 128-byte stride; the
+// quotient kernel is point-wise and does not care, so it reads this layout and interleaves only its one output vector.
+int32_t lde4cm_batch_dev(plk_ctx *ctx, const Fr *const *coeffs, uint32_t count, uint32_t log_n, Fr *const *out_4n, hipStream_t stream, uint32_t lane) {
+    if (log_n + 2 > MAX_LOG_N) { set_error("lde4: 4n exceeds 2^28"); return PLK_ERR_SIZE; }
+    const size_t n = (size_t)1 << log_n;
+    for (uint32_t k = 0; k < count; k++) if (coeffs[k] == out_4n[k]) { set_error("lde4: input and output must not alias"); return PLK_ERR_ARG; }
+    PLK_TRY(ntt_init_tables(ctx));
+    PowTable pre[4];
+    {
+        Fr g = from_u64<FrParams>(7);
+        const Fr w = ntt_omega(log_n + 2);
+        for (int k = 0; k < 4; k++) { PLK_TRY(ntt_coset_table(ctx, g, &pre[k])); g = mul(g, w); }
+    }
+    // polynomials per launch: 4 transforms each, at most NTT_MAX_BATCH per launch and 2 GiB of ping-pong scratch
+    uint32_t per = NTT_MAX_BATCH / 4;
+    while (per > 1 && (size_t)per * 4 * n * sizeof(Fr) > ((size_t)2 << 30)) per--;
+    for (uint32_t done = 0; done < count;) {
+        const uint32_t b = count - done > per ? per : count - done;
+        const Fr *src[NTT_MAX_BATCH]; Fr *dst[NTT_MAX_BATCH]; PowTable pe[NTT_MAX_BATCH];
+        for (uint32_t q = 0; q < b; q++)
+            for (uint32_t k = 0; k < 4; k++) { src[4 * q + k] = coeffs[done + q]; dst[4 * q + k] = out_4n[done + q] + k * n; pe[4 * q + k] = pre[k]; }
+        PLK_TRY(ntt_run(ctx, src, 0, dst, 4 * b, log_n, false, nullptr, stream, lane, pe));
+        done += b;
+    }
+    return PLK_OK;
 }
 
 }  // namespace plk

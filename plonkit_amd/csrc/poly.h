@@ -39,7 +39,7 @@ struct QuotientArgs {
     Fr coset_w;
 };
 int32_t scale_const(Fr *out, const Fr *in, const Fr &c_s, uint32_t n, hipStream_t s);            // out_i = in_i * c (one W-layer product), canonical
-int32_t coset_points_w(Fr *out, const PowTable &tw_w, uint32_t log_m, const Fr &c_s, uint32_t m, hipStream_t s);   // out_i = c * omega_m^i
+int32_t coset_points_w(Fr *out, const PowTable &tw_w, uint32_t log_m, const Fr &c_s, uint32_t m, hipStream_t s);   // out_i = c * omega_m^(4 r + k) at the coset-major position i = k * m/4 + r
 
 constexpr uint32_t LINCOMB_MAX = 14;
 struct LinCombArgs {

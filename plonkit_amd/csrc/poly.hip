@@ -198,21 +198,31 @@ __global__ void __launch_bounds__(PT) k_scale_const(Fr *out, const Fr *in, Fr c,
     uint32_t i = blockIdx.x * PT + threadIdx.x;
     if (i < n) store_fp(out + i, pack<FrParams>(csub_p(mulw(ldw(in + i), cw(c)))));
 }
-// out_i = c * omega_m^i  (tw_w: the power table of omega_{2^28} in the 2^261 domain)
-__global__ void __launch_bounds__(PT) k_coset_points_w(Fr *out, PowTable tw_w, uint32_t shift, Fr c, uint32_t m) {
+// out_i = c * omega_m^j, j = the natural index of coset-major position i (k = i / n, r = i % n, j = 4 r + k)
+// (tw_w: the power table of omega_{2^28} in the 2^261 domain)
+__global__ void __launch_bounds__(PT) k_coset_points_w(Fr *out, PowTable tw_w, uint32_t shift, Fr c, uint32_t m, uint32_t log_n) {
     uint32_t i = blockIdx.x * PT + threadIdx.x;
     if (i >= m) return;
-    const uint32_t e = i << shift;
+    const uint32_t j = ((i & ((1u << log_n) - 1)) << 2) | (i >> log_n);
+    const uint32_t e = j << shift;
     const FrW9 w = mulw(ldw(tw_w.lo + (e & (POW_TAB - 1))), ldw(tw_w.hi + (e >> POW_SPLIT)));
     store_fp(out + i, pack<FrParams>(csub_p(mulw(w, cw(c)))));
 }
 
-// t(x_i) = [gate + PI + alpha*(perm) + alpha^2*L0*(z-1)] / Z_H(x_i) on the coset 7*<omega_4N>.
-// 27 products per point on the 29-bit layer, the seven gate products in two fused sums (one reduction per three).
+// t(x) = [gate + PI + alpha*(perm) + alpha^2*L0*(z-1)] / Z_H(x) on the coset 7*<omega_4N>.
+// 24 products per point on the 29-bit layer, the seven gate products in two fused sums (one reduction per three).
+// Every input vector is in the COSET-MAJOR layout of lde4cm_batch_dev: position i = k * N + r holds the value at
+// x_j = 7 * omega_4N^j, j = 4 r + k.  f(omega * x) is then the next row of the same coset, 1 / Z_H depends on k only.  The
+// quotient itself is written at its natural index j (the coset iNTT that follows takes natural order): a workgroup takes
+// 256 rows of one coset and its three neighbours in the grid the same rows of the other cosets, so that the four 32-byte
+// quarters of a 128-byte line are written at about the same time.
 __global__ void __launch_bounds__(PT) k_quotient(QuotientArgs a) {
-    uint32_t i = blockIdx.x * PT + threadIdx.x;
-    if (i >= a.m) return;
-    const uint32_t nxt = (i + 4) & (a.m - 1);                    // f(omega*x) on the 4N domain
+    const uint32_t log_n = a.log_m - 2, nmask = (1u << log_n) - 1;
+    uint32_t i, kc, r;
+    if (a.m >= 4 * PT) { kc = blockIdx.x & 3; r = (blockIdx.x >> 2) * PT + threadIdx.x; i = (kc << log_n) | r; }
+    else { i = blockIdx.x * PT + threadIdx.x; if (i >= a.m) return; kc = i >> log_n; r = i & nmask; }      // tiny domains
+    const uint32_t jnat = (r << 2) | kc;
+    const uint32_t nxt = (kc << log_n) | ((r + 1) & nmask);      // f(omega*x): the next row of this coset
     FrW9 w[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) w[j] = ldw(a.w[j] + i);
@@ -221,11 +231,11 @@ __global__ void __launch_bounds__(PT) k_quotient(QuotientArgs a) {
     const FrW9 f2 = mulsum3w(ldw(a.q[3] + i), w[3], ldw(a.q[4] + i), w01, ldw(a.q[6] + i), ldw(a.w[3] + nxt));
     FrW9 g = addn(addn(f1, f2), ldw(a.q[5] + i));
     if (a.pi) g = addn(g, ldw(a.pi + i));
-    else for (uint32_t k = 0; k < a.num_pi; k++) g = addn(g, mulw(ldw(a.l0 + ((i - 4 * k) & (a.m - 1))), cw(a.pi_in[k])));
+    else for (uint32_t k = 0; k < a.num_pi; k++) g = addn(g, mulw(ldw(a.l0 + ((kc << log_n) | ((r - k) & nmask))), cw(a.pi_in[k])));
     FrW9 x;
     if (a.x) x = ldw(a.x + i);
     else {                                                        // no cached coset points (largest domains): 7 * omega_4N^i from the table
-        const uint32_t e = i << (MAX_LOG_N - a.log_m);
+        const uint32_t e = jnat << (MAX_LOG_N - a.log_m);
         x = mulw(mulw(ldw(a.tw_w.lo + (e & (POW_TAB - 1))), ldw(a.tw_w.hi + (e >> POW_SPLIT))), cw(a.coset_w));
     }
     const FrW9 z = ldw(a.z + i), gamma = cw(a.gamma), beta = cw(a.beta);
@@ -253,7 +263,7 @@ __global__ void __launch_bounds__(PT) k_quotient(QuotientArgs a) {
     }
     FrW9 t = addn(g, mulw(cw(a.alpha_pp), sub2(pa, pb)));
     t = addn(t, mulw(cw(a.alpha2_w), mulw(ldw(a.l0 + i), sub2(z, cw(Fr::one())))));
-    store_fp(a.out + i, pack<FrParams>(csub_p(mulw(t, cw(a.zh_inv_w[i & 3])))));
+    store_fp(a.out + jnat, pack<FrParams>(csub_p(mulw(t, cw(a.zh_inv_w[kc])))));
 }
 
 // ------------------------------------------------------------------- linear combinations
@@ -388,7 +398,7 @@ int32_t scale_const(Fr *out, const Fr *in, const Fr &c_s, uint32_t n, hipStream_
     return PLK_OK;
 }
 int32_t coset_points_w(Fr *out, const PowTable &tw_w, uint32_t log_m, const Fr &c_s, uint32_t m, hipStream_t s) {
-    hipLaunchKernelGGL(k_coset_points_w, grid1(m), dim3(PT), 0, s, out, tw_w, MAX_LOG_N - log_m, c_s, m);
+    hipLaunchKernelGGL(k_coset_points_w, grid1(m), dim3(PT), 0, s, out, tw_w, MAX_LOG_N - log_m, c_s, m, log_m - 2);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
 }

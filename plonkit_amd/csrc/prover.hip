@@ -494,11 +494,12 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     // last: stream priorities do not keep a 8192-workgroup NTT pass from taking the CUs first (measured: the pre-phase of the
     // wire commitments took 2.1 ms instead of 0.35 behind it), so the start is placed by hand where the GPU has room — the
     // bucket reduction of that commitment, the point-wise kernels of the next round and the pre-phase of its commitment.
-    auto bg_after_main = [&]() -> int32_t {
+    static const int bg_gate_z = [] { const char *e = getenv("PLK_PROVE_BG_GATE_Z"); return e ? atoi(e) : 0; }();   // A/B knob
+    auto bg_after_main = [&](bool behind_accumulation) -> int32_t {
         if (!use_bg) return PLK_OK;
         PLK_HIP(hipEventRecord(ctx->bg_go, st));
         PLK_HIP(hipStreamWaitEvent(bg, ctx->bg_go, 0));
-        if (ctx->msm_enq != ctx->msm_fin) {
+        if (behind_accumulation && ctx->msm_enq != ctx->msm_fin) {
             plk_ctx::MsmSlot &L = ctx->slot[ctx->fifo[(ctx->msm_enq - 1) % plk_ctx::MSM_SLOTS]];
             if (L.acc_done) PLK_HIP(hipStreamWaitEvent(bg, L.acc_done, 0));
         }
@@ -518,8 +519,8 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     if (use_lagrange && (ctx->combine ? ctx->lag.n != ctx->srs_n : ctx->lag.n != N)) { set_error("Lagrange-form key has a different size than the circuit's domain"); return PLK_ERR_SRS; }
     HAffine wire_c[4];
     PLK_TRY(commit_begin(ctx, use_lagrange ? w_vals : w_coef, 4, N, use_lagrange));
-    PLK_TRY(bg_after_main());
-    PLK_TRY(lde4_batch_dev(ctx, w_coef, 4, log_n, ext, bg, bg_lane));                       // round-3 work that needs no challenge
+    PLK_TRY(bg_after_main(true));
+    PLK_TRY(lde4cm_batch_dev(ctx, w_coef, 4, log_n, ext, bg, bg_lane));                       // round-3 work that needs no challenge
     PLK_HIP(hipEventSynchronize(ctx->flag_ready));
     if (*reinterpret_cast<volatile uint32_t *>(ctx->pinned)) { set_error("must satisfy: witness does not satisfy the circuit"); return PLK_ERR_UNSAT; }
     PLK_TRY(commit_end(ctx, 4, wire_c));
@@ -554,17 +555,19 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     HAffine z_c;
     { const Fr *zp = use_lagrange ? t1 : z_coef; PLK_TRY(commit_begin(ctx, &zp, 1, N, use_lagrange)); }
     // while z is being committed: its extension, the public-input polynomial, and (first proof only) the constant vectors
-    PLK_TRY(bg_after_main());
+    // (z's extension is the last thing the quotient waits for: it starts as soon as z's coefficients exist and shares the GPU
+    //  with the accumulation of z's commitment — behind that accumulation it ended 0.4 ms after the commitment itself)
+    PLK_TRY(bg_after_main(bg_gate_z != 0));
     {
         const Fr *zc = z_coef;
-        PLK_TRY(lde4_batch_dev(ctx, &zc, 1, log_n, &ext[4], bg, bg_lane));
+        PLK_TRY(lde4cm_batch_dev(ctx, &zc, 1, log_n, &ext[4], bg, bg_lane));
     }
     if (!direct_pi) {
         PLK_HIP(hipMemsetAsync(pi_coef, 0, N * sizeof(Fr), bg));
         PLK_HIP(hipMemcpyAsync(pi_coef, inputs.data(), inputs.size() * sizeof(Fr), hipMemcpyHostToDevice, bg));
         PLK_TRY(ntt_batch_dev(ctx, &pi_coef, 1, log_n, true, nullptr, bg, bg_lane));
         const Fr *pc = pi_coef;
-        PLK_TRY(lde4_batch_dev(ctx, &pc, 1, log_n, &ext[16], bg, bg_lane));
+        PLK_TRY(lde4cm_batch_dev(ctx, &pc, 1, log_n, &ext[16], bg, bg_lane));
     }
     if (use_bg) PLK_HIP(hipEventRecord(ctx->bg_done, bg));
     PLK_TRY(commit_end(ctx, 1, &z_c));
@@ -584,13 +587,17 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
             Arena LA{&S->lde_store};
             for (int k = 0; k < (cache_x ? 13 : 12); k++) S->lde[k] = LA.take<Fr>(M);
             if (!cache_x) S->lde[12] = nullptr;
-            for (int k = 0; k < 7; k++) PLK_TRY(lde4_dev(ctx, S->sel_coef[k], log_n, S->lde[k], st));
-            for (int j = 0; j < 4; j++) PLK_TRY(lde4_dev(ctx, S->sig_coef[j], log_n, S->lde[7 + j], st));
             HFr one = HFr::one();
             PLK_HIP(hipMemsetAsync(l0_coef, 0, N * sizeof(Fr), st));
             PLK_HIP(hipMemcpyAsync(l0_coef, one.l, sizeof(Fr), hipMemcpyHostToDevice, st));
             PLK_TRY(ntt_dev(ctx, l0_coef, log_n, true, nullptr, st));
-            PLK_TRY(lde4_dev(ctx, l0_coef, log_n, S->lde[11], st));
+            {   // 7 selectors, 4 sigmas, L0: twelve extensions in the coset-major layout of the quotient kernel, four polynomials per launch
+                const Fr *src[12]; Fr *dst[12];
+                for (int k = 0; k < 7; k++) { src[k] = S->sel_coef[k]; dst[k] = S->lde[k]; }
+                for (int j = 0; j < 4; j++) { src[7 + j] = S->sig_coef[j]; dst[7 + j] = S->lde[7 + j]; }
+                src[11] = l0_coef; dst[11] = S->lde[11];
+                PLK_TRY(lde4cm_batch_dev(ctx, src, 12, log_n, dst, st, 0));
+            }
             // pre-scaled for the 29-bit layer of the quotient kernel (poly.h, QuotientArgs): 2^5 everywhere,
             // 2^10 on q_m, none on q_const (it is only added); plus the coset points x_i = 7 * omega_4N^i
             const HFr s5 = HFr::from_u64(1u << 10), s10 = HFr::from_u64(1u << 15);      // as factors of a product that removes 2^5

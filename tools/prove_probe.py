@@ -1,6 +1,6 @@
 """one setup + N proves at the 2^log_n domain (for rocprofv3 --kernel-trace --stats): python tools/prove_probe.py [log_n] [proves]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
 import plonkit_amd as pa
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
