@@ -23,6 +23,10 @@ struct alignas(16) XyzzW { FqW9 x, y, zz, zzz; };              // 144 bytes
 #define WM(a, b) mulw<FqW>((a), (b))
 #define WS(a) sqrw<FqW>((a))                               // normalised input; 126 mads instead of 162
 #define WMA(a, b, c, d) mul2addw<FqW>((a), (b), (c), (d))  // a*b + c*d, one reduction
+// the latency-bound chains (full addition, doubling: bucket reduction, table build) take the operand-scanning forms
+#define LM(a, b) mulw_os<FqW>((a), (b))
+#define LS(a) sqrw_os<FqW>((a))
+#define LMA(a, b, c, d) mul2addw_os<FqW>((a), (b), (c), (d))
 
 PLK_HD bool is_inf(const XyzzW &p) { return w_all_zero(p.zz); }
 PLK_HD bool is_inf(const AffW &p) { return w_all_zero(p.x) && w_all_zero(p.y); }
@@ -41,12 +45,12 @@ PLK_HD XyzzW xyzzw_double_affine(const FqW9 &x, const FqW9 &y) {
 
 PLK_HD XyzzW xyzzw_double(const XyzzW &p) {
     if (is_inf(p)) return p;
-    FqW9 u = addn(p.y, p.y), v = WS(u), w = WM(u, v), s = WM(p.x, v);
-    FqW9 xx = WS(p.x), m = normw(addw(addw(xx, xx), xx));
+    FqW9 u = addn(p.y, p.y), v = LS(u), w = LM(u, v), s = LM(p.x, v);
+    FqW9 xx = LS(p.x), m = normw(addw(addw(xx, xx), xx));
     XyzzW r;
-    r.x = sub4(WS(m), addn(s, s));
-    r.y = WMA(m, sub6(s, r.x), p.y, neg2(w));
-    r.zz = WM(v, p.zz); r.zzz = WM(w, p.zzz);
+    r.x = sub4(LS(m), addn(s, s));
+    r.y = LMA(m, sub6(s, r.x), p.y, neg2(w));
+    r.zz = LM(v, p.zz); r.zzz = LM(w, p.zzz);
     return r;
 }
 
@@ -101,25 +105,25 @@ PLK_HD void xyzzw_add_mixed(XyzzW &acc, const AffW &q, bool neg_q) {
 PLK_HD void xyzzw_add(XyzzW &a, const XyzzW &b) {
     if (is_inf(b)) return;
     if (is_inf(a)) { a = b; return; }
-    FqW9 u1 = WM(a.x, b.zz), u2 = WM(b.x, a.zz), s1 = WM(a.y, b.zzz), s2 = WM(b.y, a.zzz);
+    FqW9 u1 = LM(a.x, b.zz), u2 = LM(b.x, a.zz), s1 = LM(a.y, b.zzz), s2 = LM(b.y, a.zzz);
     FqW9 p = sub2(u2, u1), r = sub2(s2, s1);
     if (is_zero_mod_p(p)) {
         if (is_zero_mod_p(r)) a = xyzzw_double(a);
         else a = xyzzw_identity();
         return;
     }
-    FqW9 pp = WS(p), ppp = WM(p, pp), qq = WM(u1, pp);
+    FqW9 pp = LS(p), ppp = LM(p, pp), qq = LM(u1, pp);
     FqW9 x3;
     {
-        FqW9 rr = WS(r);
+        FqW9 rr = LS(r);
 #pragma unroll
         for (int i = 0; i < 9; i++) x3.l[i] = rr.l[i] + FqW::PAD4[i] - ppp.l[i] - 2 * qq.l[i];
         x3 = normw(x3);
     }
-    a.y = WMA(r, sub6(qq, x3), s1, neg2(ppp));
+    a.y = LMA(r, sub6(qq, x3), s1, neg2(ppp));
     a.x = x3;
-    a.zz = WM(WM(a.zz, b.zz), pp);
-    a.zzz = WM(WM(a.zzz, b.zzz), ppp);
+    a.zz = LM(LM(a.zz, b.zz), pp);
+    a.zzz = LM(LM(a.zzz, b.zzz), ppp);
 }
 
 // storage <-> registers

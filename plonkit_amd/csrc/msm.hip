@@ -49,7 +49,7 @@ constexpr int MSM_THREADS = 256;
 //           against 15.7 M mixed additions of 9.3), and it shares the GPU with the next commitment's accumulation.
 //   FB = 7: 128 buckets per task, 512 bins of ~31 K entries = two tasks per bin (131 K task-buckets): the round-1 shape.
 constexpr uint32_t FINE_BITS_MAX = 7;
-constexpr uint32_t CHUNK = 16384;                 // entries per accumulate workgroup (sorted in 64 KB of LDS; two workgroups per CU)
+constexpr uint32_t CHUNK = 16384;                // entries per accumulate workgroup (sorted in 64 KB of LDS; two workgroups per CU)
 constexpr uint32_t DIGIT_CHUNK = 16384;            // scalars per partition workgroup (per window): 64 KB of LDS staging
 constexpr uint32_t TASK_MAX = CHUNK;
                    // per-chunk bucket population handled cooperatively

@@ -9,9 +9,16 @@ ctx.srs_generate(1 << log_n, 0, 42)
 circ = pa.Circuit.synthetic((1 << log_n) - 2)
 setup = pa.SetupForProver(ctx, circ)
 setup.prove(circ)
+tot, rounds = [], {}
 for _ in range(reps):
     t0 = time.perf_counter(); setup.prove(circ); dt = time.perf_counter() - t0
-    print("prove 2^%d: %.2f ms  %s" % (log_n, dt * 1e3, {k: round(v, 2) for k, v in setup.timings_ms().items()}), flush=True)
+    tm = setup.timings_ms()
+    tot.append(dt * 1e3)
+    for k, v in tm.items(): rounds.setdefault(k, []).append(v)
+    if reps <= 8: print("prove 2^%d: %.2f ms  %s" % (log_n, dt * 1e3, {k: round(v, 2) for k, v in tm.items()}), flush=True)
+tot.sort()
+print("prove 2^%d over %d: median %.2f ms  min %.2f  mean %.2f   rounds (mean) %s" % (log_n, reps, tot[len(tot) // 2], tot[0], sum(tot) / len(tot),
+      {k: round(sum(v) / len(v), 2) for k, v in rounds.items()}), flush=True)
 if os.environ.get("PROBE_VERIFY"):
     vk = setup.verification_key_bytes(pa.crs42_g2_bytes())
     t0 = time.perf_counter(); ok = pa.verify(vk, setup.prove(circ)); dt = time.perf_counter() - t0
