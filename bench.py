@@ -486,7 +486,16 @@ def main():
         # the exchange of the partial sums runs inside the library (comm.cpp: ncclAllGather on the communicator's own stream + host
         # EC sum); torch.distributed only carries the 128-byte RCCL id to the other ranks and the timing barriers
         if share:
-            ctx.comm_init_tcp(rank, world, int(os.environ.get("MASTER_PORT", "29500")) + 17, rank * n)
+            # rank 0 picks a free port for the library's TCP hub and tells the others (MASTER_PORT + k may be taken or exceed 65535)
+            box = [None]
+            if rank == 0:
+                import socket
+                sk = socket.socket()
+                sk.bind(("127.0.0.1", 0))
+                box[0] = sk.getsockname()[1]
+                sk.close()
+            dist.broadcast_object_list(box, src=0)
+            ctx.comm_init_tcp(rank, world, int(box[0]), rank * n)
         else:
             box = [pa.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
