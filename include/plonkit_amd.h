@@ -77,6 +77,11 @@ int32_t plk_ntt_dev(plk_ctx *ctx, void *data_dev, uint32_t log_n, int32_t invers
 /* Polynomial::coset_lde(4): n coefficients -> 4n evaluations on 7*<omega_4n> */
 int32_t plk_lde4(plk_ctx *ctx, const plk_fr *coeffs_host, uint32_t log_n, plk_fr *out_4n_host);
 int32_t plk_lde4_dev(plk_ctx *ctx, const void *coeffs_dev, uint32_t log_n, void *out_4n_dev, void *stream);
+/* The same 4n evaluations of `count` (<= 16) polynomials in the COSET-MAJOR order the prover's round 3 works in:
+ * out[p][k * n + r] = f_p(7 * omega_4n^(4 r + k)), k = 0..3 — four n-point coset transforms per polynomial, all of them in
+ * one launch per pass (prove_by_steps' ~18 coset_lde(4) calls, src/plonk.rs:152-159).  A permutation of plk_lde4_dev's output;
+ * exposed so that the layout is testable on its own.                                                                      */
+int32_t plk_lde4_coset_major_dev(plk_ctx *ctx, const void *const *coeffs_dev, uint32_t count, uint32_t log_n, void *const *out_4n_dev, void *stream);
 
 /* ---- kate_commitment::commit_using_monomials -> multiexp::dense_multiexp (src/plonk.rs:122-124 and
  *      the 11 commitments of prove): sum_i scalars[i] * srs[base_offset + i], scalars Montgomery Fr.

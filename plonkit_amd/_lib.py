@@ -226,6 +226,13 @@ class Context:
     def lde4_dev(self, in_ptr, log_n, out_ptr, stream=None):
         _check(lib().plk_lde4_dev(self._h, _devptr(in_ptr), ctypes.c_uint32(log_n), _devptr(out_ptr), _stream(stream)))
 
+    def lde4_coset_major_dev(self, in_ptrs, log_n, out_ptrs, stream=None):
+        """`count` polynomials -> their 4n evaluations in the prover's coset-major order (out[k*n + r] = f(7 w_4n^(4r+k)))"""
+        cnt = len(in_ptrs)
+        ins = (ctypes.c_void_p * cnt)(*[_devptr(p).value for p in in_ptrs])
+        outs = (ctypes.c_void_p * cnt)(*[_devptr(p).value for p in out_ptrs])
+        _check(lib().plk_lde4_coset_major_dev(self._h, ins, ctypes.c_uint32(cnt), ctypes.c_uint32(log_n), outs, _stream(stream)))
+
     # ---- MSM
     def msm(self, scalars, base_offset=0):
         s = np.ascontiguousarray(scalars, dtype=np.uint64)

@@ -223,6 +223,14 @@ int32_t plk_lde4_dev(plk_ctx *ctx, const void *coeffs_dev, uint32_t log_n, void 
     return lde4_dev(ctx, (const Fr *)coeffs_dev, log_n, (Fr *)out_4n_dev, s);
 }
 
+int32_t plk_lde4_coset_major_dev(plk_ctx *ctx, const void *const *coeffs_dev, uint32_t count, uint32_t log_n, void *const *out_4n_dev, void *stream) {
+    if (!ctx || !coeffs_dev || !out_4n_dev || count == 0 || count > 16) { set_error("plk_lde4_coset_major_dev: bad argument"); return PLK_ERR_ARG; }
+    for (uint32_t k = 0; k < count; k++) if (!coeffs_dev[k] || !out_4n_dev[k]) { set_error("plk_lde4_coset_major_dev: null vector"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    return lde4cm_batch_dev(ctx, reinterpret_cast<const Fr *const *>(coeffs_dev), count, log_n, reinterpret_cast<Fr *const *>(out_4n_dev),
+                            stream ? (hipStream_t)stream : ctx->stream, 0);
+}
+
 int32_t plk_lde4(plk_ctx *ctx, const plk_fr *coeffs, uint32_t log_n, plk_fr *out_4n) {
     if (!ctx || !coeffs || !out_4n) { set_error("plk_lde4: bad argument"); return PLK_ERR_ARG; }
     if (log_n + 2 > MAX_LOG_N) { set_error("lde4: 4n exceeds 2^28"); return PLK_ERR_SIZE; }

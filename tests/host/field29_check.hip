@@ -48,6 +48,21 @@ int main() {
         FqW9 r1 = reduce_small(big), r2 = reduce_full(big);                           // same residue (x * one / R)
         for (int k = 0; k < 9; k++) if (r1.l[k] != r2.l[k]) { bad++; if (bad < 5) printf("reduce_small mismatch %d\n", it); break; }
     }
+    // the operand-scanning forms (latency-bound EC chains) and the two-chain lockstep forms are the SAME functions, bit for bit
+    for (int it = 0; it < 20000; it++) {
+        Fq a = rnd_fp<FqParams>(), b = rnd_fp<FqParams>(), c = rnd_fp<FqParams>(), d = rnd_fp<FqParams>();
+        FqW9 aw = w_from_s(unpack<FqW>(a)), bw = w_from_s(unpack<FqW>(b)), cw = w_from_s(unpack<FqW>(c)), dw = w_from_s(unpack<FqW>(d));
+        if (it & 1) aw = addw(aw, sub2(cw, dw));                                          // an un-normalised left operand now and then
+        const FqW9 m1 = mulw(aw, bw), m2 = mulw_os(aw, bw), s1 = sqrw(bw), s2 = sqrw_os(bw);
+        const FqW9 f1 = mul2addw(normw(aw), bw, cw, dw), f2 = mul2addw_os(normw(aw), bw, cw, dw);
+        FqW9 p0, p1, q0, q1;
+        mulw2(aw, bw, cw, dw, p0, p1);
+        sqrw2(bw, dw, q0, q1);
+        const FqW9 p1s = mulw(cw, dw), q1s = sqrw(dw);
+        for (int k = 0; k < 9; k++)
+            if (m1.l[k] != m2.l[k] || s1.l[k] != s2.l[k] || f1.l[k] != f2.l[k] || p0.l[k] != m1.l[k] || p1.l[k] != p1s.l[k] || q0.l[k] != s1.l[k] || q1.l[k] != q1s.l[k]) {
+                bad++; if (bad < 5) printf("product forms disagree %d\n", it); break; }
+    }
     // mulw with an un-normalised left operand (ntt.hip r4_finish): limbs at MULW_A_LIMB_MAX against a right operand with
     // every limb at 2^29 - 1, raw padded differences against their normalised forms, and one lazy radix-4 butterfly
     // against the strictly normalised formulas

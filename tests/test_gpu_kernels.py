@@ -72,6 +72,35 @@ def test_lde4(ctx, log_n):
     assert np.array_equal(ctx.lde4(a, log_n), ol.ntt(ext, log_n + 2, coset=7))
 
 
+@pytest.mark.parametrize("log_n,count", [(1, 1), (3, 2), (10, 4), (11, 1), (12, 5), (16, 4), (20, 4)])
+def test_lde4_coset_major(ctx, log_n, count):
+    """the layout of the prover's round 3 (lde4cm_batch_dev: four n-point coset transforms per polynomial, up to four
+    polynomials per launch): out[k*n + r] must be the natural-order extension's element 4r + k — against the oracle's
+    coset NTT of the zero-padded vector up to 2^16 (bit-exact), against plk_lde4_dev at 2^20"""
+    import torch
+    n = 1 << log_n
+    polys = [_rand_fr(n, 100 * log_n + p) for p in range(count)]
+    d_in = [torch.from_numpy(a.view(np.int64)).to("cuda:0") for a in polys]
+    d_out = [torch.zeros((4 * n, 4), dtype=torch.int64, device="cuda:0") for _ in range(count)]
+    torch.cuda.synchronize()
+    ctx.lde4_coset_major_dev(d_in, log_n, d_out)
+    ctx.synchronize()
+    for p in range(count):
+        got = d_out[p].cpu().numpy().view(np.uint64).reshape(4, n, 4)
+        if log_n <= 16:
+            ext = np.zeros((4 * n, 4), dtype=np.uint64)
+            ext[:n] = polys[p]
+            nat = ol.ntt(ext, log_n + 2, coset=7)
+        else:
+            d_nat = torch.zeros((4 * n, 4), dtype=torch.int64, device="cuda:0")
+            ctx.lde4_dev(d_in[p], log_n, d_nat)
+            ctx.synchronize()
+            nat = d_nat.cpu().numpy().view(np.uint64)
+        nat = nat.reshape(n, 4, 4)                                   # [r][k][limb]
+        for k in range(4):
+            assert np.array_equal(got[k], nat[:, k, :]), (p, k)
+
+
 def test_ntt_errors(ctx):
     import plonkit_amd as pa
     with pytest.raises(pa.PlkError) as e:
