@@ -9,7 +9,8 @@
 // RCCL is bound at run time (dlopen of librccl.so.1) so that the library — and the `plonkit` binary for single-GPU use —
 // load on machines without it, and so that a host program that already carries RCCL (PyTorch) shares its copy.
 // A second transport, a TCP hub on 127.0.0.1, exists for the one case RCCL refuses: several ranks on the SAME device
-// (the single-GPU test tier).  It moves the same bytes through the same combiner.
+// (the single-GPU test tier).  It moves the same bytes through the same combiner.  TEST TIER ONLY, not for production:
+// the hub accepts any local process that connects and names a free rank (no authentication, no encryption, loopback only).
 #include "ctx.h"
 #include "comm.h"
 #include <rccl/rccl.h>

@@ -62,6 +62,7 @@ struct plk_ctx {
     std::map<std::vector<uint32_t>, plk::PowTable> coset_tabs;   // keyed by the 8 limbs of the shift
     std::vector<void *> coset_allocs;
     std::map<uint32_t, void *> ntt_direct;                       // ntt.hip: inter-pass twiddle tables by (direction, digit plan)
+    size_t ntt_direct_bytes = 0;                                 // what they hold together (capped: ntt.hip, NTT_DIRECT_CAP_BYTES)
     std::map<std::vector<uint32_t>, plk::Fr> inv_cache;
     plk::Fr n_inv[plk::MAX_LOG_N + 1];      // 2^-k
     plk::Fr n_inv_w[plk::MAX_LOG_N + 1];    // 2^-k in the 2^261 domain

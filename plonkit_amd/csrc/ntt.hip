@@ -420,15 +420,26 @@ static int32_t ntt_direct_table(plk_ctx *ctx, bool inverse, uint32_t log_r, uint
     const uint32_t key = (inverse ? 1u << 31 : 0) | (scaled ? log_n << 16 : 0) | log_r << 8 | log_inner;
     auto it = ctx->ntt_direct.find(key);
     if (it != ctx->ntt_direct.end()) { *out = static_cast<const Fr *>(it->second); return PLK_OK; }
+    // A long-lived context that proves many domain sizes would otherwise collect tables for ever (up to 1 GiB each): when
+    // the next one would take the total past the cap, every table is dropped first — after the device has drained, since
+    // passes in flight on any stream may still be reading them — and the sizes in use come back on demand.
+    static const size_t cap = [] { const char *e = getenv("PLK_NTT_DIRECT_CAP_MB"); size_t mb = e ? strtoull(e, nullptr, 10) : 0; return (mb ? mb : 6144) << 20; }();
+    const size_t want = sizeof(Fr) << bits;
+    if (ctx->ntt_direct_bytes + want > cap && !ctx->ntt_direct.empty()) {
+        PLK_HIP(hipDeviceSynchronize());
+        for (auto &kv : ctx->ntt_direct) (void)hipFree(kv.second);
+        ctx->ntt_direct.clear();
+        ctx->ntt_direct_bytes = 0;
+    }
     Fr *buf = nullptr;
-    if (hipMalloc(&buf, sizeof(Fr) << bits) != hipSuccess) { (void)hipGetLastError(); return PLK_OK; }   // no room: compose
+    if (hipMalloc(&buf, want) != hipSuccess) { (void)hipGetLastError(); return PLK_OK; }   // no room: compose
     const PowTable &tw = inverse ? ctx->tw_inv_w : ctx->tw_fwd_w;
     hipLaunchKernelGGL(ntt_fill_direct, dim3((uint32_t)((((size_t)1 << bits) + 255) / 256)), dim3(256), 0, stream, buf, tw, log_r, log_inner,
                        scaled ? ctx->n_inv_w[log_n] : Fr::zero(), scaled ? 1u : 0u);
     PLK_HIP(hipGetLastError());
     PLK_HIP(hipStreamSynchronize(stream));                 // other streams may use the table right after this call
     ctx->ntt_direct[key] = buf;
-    ctx->coset_allocs.push_back(buf);
+    ctx->ntt_direct_bytes += want;
     *out = buf;
     return PLK_OK;
 }

@@ -113,6 +113,7 @@ void plk_destroy(plk_ctx *ctx) {
     if (ctx->bg_stream) (void)hipStreamSynchronize(ctx->bg_stream);
     comm_release(ctx);
     for (void *p : ctx->coset_allocs) (void)hipFree(p);
+    for (auto &kv : ctx->ntt_direct) (void)hipFree(kv.second);
     ctx->tables.release(); ctx->ntt_scratch[0].release(); ctx->ntt_scratch[1].release(); ctx->srs_own.release(); ctx->srs_w.release(); ctx->lag.own.release(); ctx->lag.w.release();
     for (auto &S : ctx->slot) {
         S.a.release(); S.b.release(); S.c.release(); S.d.release(); S.e.release(); S.f.release();

@@ -146,3 +146,17 @@ def test_long_lc_chain_proves(golden_crs):
     S = po.setup(r1cs)
     P = po.prove(r1cs, wit, golden_crs, S)
     assert po.verify(po.make_verification_key(S, golden_crs), P)
+
+
+def test_crosscheck_manifest_simple_case_is_the_reference_golden(golden_dir):
+    """tools/make_crosscheck_bundle.py (run on an MI355X; its MANIFEST.json is committed as tools/crosscheck_MANIFEST.json) writes
+    five circuits' artefacts for a future comparison with a real `plonkit`.  Four of them are PARITY UNPINNED; the fifth, the
+    reference's own `simple` circuit taken through circom's BINARY formats this time, must hash to the reference's committed
+    files (src/tests.rs:31-73): key, verification key and proof."""
+    import hashlib
+    import json
+    root = os.path.dirname(golden_dir.rstrip("/"))
+    m = json.load(open(os.path.join(os.path.dirname(root), "tools", "crosscheck_MANIFEST.json")))
+    sha = lambda name: hashlib.sha256(open(os.path.join(golden_dir, name), "rb").read()).hexdigest()
+    assert m["simple"]["vk.bin"] == sha("vk.bin") and m["simple"]["proof.bin"] == sha("proof.bin") and m["simple"]["setup.key"] == sha("setup_2pow10.key")
+    assert set(m) == {"simple", "poseidon_12", "poseidon_14", "poseidon_16", "long_lc"}
