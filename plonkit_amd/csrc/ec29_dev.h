@@ -73,9 +73,9 @@ PLK_HD void xyzzw_add_mixed_special(XyzzW &acc, const AffW &q, bool neg_q, const
 PLK_HD void xyzzw_add_mixed(XyzzW &acc, const AffW &q, bool neg_q) {
     if (is_inf(q)) return;
     if (is_inf(acc)) { acc.x = q.x; acc.y = neg_q ? neg2(q.y) : q.y; acc.zz = w_one<FqW>(); acc.zzz = w_one<FqW>(); return; }
-    FqW9 u2 = WM(q.x, acc.zz), s2 = WM(q.y, acc.zzz);
+    FqW9 u2, s2;
+    mulw2<FqW>(q.x, acc.zz, q.y, acc.zzz, u2, s2);
     FqW9 p = sub6(u2, acc.x);
-    // r = 8p - y +- s2  (sign folded in limb-wise: no separate negation of q.y)
     FqW9 r;
     {
         const uint32_t m = neg_q ? 0xffffffffu : 0u;
@@ -87,18 +87,21 @@ PLK_HD void xyzzw_add_mixed(XyzzW &acc, const AffW &q, bool neg_q) {
         xyzzw_add_mixed_special(acc, q, neg_q, p, r);
         return;
     }
-    FqW9 pp = WS(p), ppp = WM(p, pp), qq = WM(acc.x, pp);
+    FqW9 pp, rr, ppp, qq;
+    sqrw2<FqW>(p, r, pp, rr);
+    mulw2<FqW>(p, pp, acc.x, pp, ppp, qq);
     FqW9 x3;
     {
-        FqW9 rr = WS(r);
 #pragma unroll
         for (int i = 0; i < 9; i++) x3.l[i] = rr.l[i] + FqW::PAD4[i] - ppp.l[i] - 2 * qq.l[i];
         x3 = normw(x3);
     }
+    FqW9 zz3, zzz3;
+    mulw2<FqW>(acc.zz, pp, acc.zzz, ppp, zz3, zzz3);
     acc.y = WMA(r, sub6(qq, x3), acc.y, neg2(ppp));           // R*(Q - X3) - Y*PPP, one reduction
     acc.x = x3;
-    acc.zz = WM(acc.zz, pp);
-    acc.zzz = WM(acc.zzz, ppp);
+    acc.zz = zz3;
+    acc.zzz = zzz3;
 }
 
 // a += b
