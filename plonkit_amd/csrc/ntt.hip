@@ -128,12 +128,14 @@ __device__ __forceinline__ void r4_load(Radix4Group &q, const LdsTile &L, const 
 //     x2 + PAD2 - y3 < 3.22e9 (product operand)      x0 + PAD4 - y1 - b3 < 3.22e9      everything else smaller.
 // Values grow by at most 4p per pair of stages, as before.
 __device__ __forceinline__ void r4_finish(const Radix4Group &q, const LdsTile &L, uint32_t s) {
-    const FrW9 y1 = s ? mulw(q.x1, q.t1) : q.x1, y3 = s ? mulw(q.x3, q.t1) : q.x3;                  // stage 0: twiddle 1
+    // the two products of a stage are independent: issued in lockstep (mulw2, field29_dev.h)
+    FrW9 y1 = q.x1, y3 = q.x3;                                                                      // stage 0: twiddle 1
+    if (s) mulw2(q.x1, q.t1, q.x3, q.t1, y1, y3);
     FrW9 u, v;
 #pragma unroll
     for (int i = 0; i < 9; i++) { u.l[i] = q.x2.l[i] + y3.l[i]; v.l[i] = q.x2.l[i] + FrW::PAD2[i] - y3.l[i]; }
-    const FrW9 b2 = s ? mulw(u, q.t2) : u;                                                          // stage 1 of the first pair: omega_4^0 = 1
-    const FrW9 b3 = mulw(v, q.t3);
+    FrW9 b2 = u, b3;                                                                                // stage 1 of the first pair: omega_4^0 = 1
+    if (s) mulw2(u, q.t2, v, q.t3, b2, b3); else b3 = mulw(v, q.t3);
     FrW9 o0, o1, o2, o3;
 #pragma unroll
     for (int i = 0; i < 9; i++) {

@@ -1,5 +1,5 @@
 import sys, time
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
 import numpy as np, torch
 import plonkit_amd as pa
 from oracle import oracle_lib as ol

@@ -1,7 +1,7 @@
 """differential fuzz of the MSM entry points against the tau = 42 trapdoor: random lengths, offsets, batch sizes and scalar
 distributions, single / batched / two-in-flight.  python tools/msm_fuzz.py [cases] [seed]"""
 import os, random, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
 import numpy as np, torch
 import plonkit_amd as pa
 from oracle import oracle_lib as ol

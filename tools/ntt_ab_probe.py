@@ -1,6 +1,6 @@
 """Timings of the transforms a proof uses: python tools/ntt_ab_probe.py [log_n ...]  (forward, inverse, coset inverse at 4n, LDE x4)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
 import torch
 import plonkit_amd as pa
 ctx = pa.Context(0); dev = torch.device("cuda:0")

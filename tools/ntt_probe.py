@@ -1,6 +1,6 @@
 """NTT timing / profiling probe: python tools/ntt_probe.py <log_n> [reps]"""
 import sys, time
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
 import torch
 import plonkit_amd as pa
 ctx = pa.Context(0); dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
 """determinism soak: the same 2^log_n proof N times (byte-identical every time) — a cheap race detector for the prover"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
 import plonkit_amd as pa
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
