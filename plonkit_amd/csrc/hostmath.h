@@ -141,6 +141,20 @@ inline HAffine jac_to_affine(const HJac &p) {
     a.x = p.x * zi2; a.y = p.y * zi2 * zi;
     return a;
 }
+// n points with ONE inversion (Montgomery's trick on the z coordinates; points at infinity are skipped)
+inline void jac_to_affine_batch(const HJac *p, uint32_t n, HAffine *out) {
+    HFq prefix[16];
+    if (n > 16) { for (uint32_t k = 0; k < n; k++) out[k] = jac_to_affine(p[k]); return; }
+    HFq acc = HFq::one();
+    for (uint32_t k = 0; k < n; k++) { prefix[k] = acc; if (!p[k].is_inf()) acc = acc * p[k].z; }
+    HFq inv = acc.inv();
+    for (uint32_t k = n; k-- > 0;) {
+        if (p[k].is_inf()) { out[k].x = HFq::zero(); out[k].y = HFq::zero(); continue; }
+        const HFq zi = inv * prefix[k], zi2 = zi.sqr();
+        inv = inv * p[k].z;
+        out[k].x = p[k].x * zi2; out[k].y = p[k].y * zi2 * zi;
+    }
+}
 inline HJac jac_neg(const HJac &p) { HJac r = p; r.y = -p.y; return r; }
 // k canonical little-endian limbs
 inline HJac jac_mul(const HJac &p, const uint64_t k[4]) {

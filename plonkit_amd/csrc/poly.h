@@ -48,6 +48,7 @@ struct LinCombArgs {
     Fr s[LINCOMB_MAX];                  // W
     uint32_t unit[LINCOMB_MAX];         // 1: coefficient is one (skip the multiply)
     uint32_t count, n;
+    PowTable times_pow;                 // optional (lo != null): out_i = (sum) * base^i — the first step of the division by (x - z)
 };
 
 constexpr uint32_t EVAL_MAX = 12;
@@ -70,7 +71,8 @@ int32_t eval_witness_ops(Fr *values, const void *ops_dev, const void *terms_dev,
 int32_t perm_terms(const PermArgs &a, hipStream_t s);
 int32_t mul3(Fr *out, const Fr *a, const Fr *b, const Fr &sc, uint32_t n, hipStream_t s);
 // out may alias in.  mult: product scan, else sum; reverse: suffix; exclusive: shifted by one
-int32_t scan(plk_ctx *ctx, Fr *out, const Fr *in, uint32_t n, bool mult, bool reverse, bool exclusive, hipStream_t s);
+// totals: where the block totals live (default: the context's poly_tmp; two scans in flight on two streams need two)
+int32_t scan(plk_ctx *ctx, Fr *out, const Fr *in, uint32_t n, bool mult, bool reverse, bool exclusive, hipStream_t s, DevBuf *totals = nullptr);
 int32_t quotient(const QuotientArgs &a, hipStream_t s);
 int32_t lincomb(const LinCombArgs &a, hipStream_t s);
 int32_t mul_powers(Fr *out, const Fr *in, const PowTable &t, uint32_t shift, uint32_t n, hipStream_t s);

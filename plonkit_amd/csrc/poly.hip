@@ -147,10 +147,11 @@ __global__ void __launch_bounds__(PT) k_scan_apply(Fr *out, const Fr *tot, uint3
     }
 }
 
-int32_t scan(plk_ctx *ctx, Fr *out, const Fr *in, uint32_t n, bool mult, bool reverse, bool exclusive, hipStream_t s) {
+int32_t scan(plk_ctx *ctx, Fr *out, const Fr *in, uint32_t n, bool mult, bool reverse, bool exclusive, hipStream_t s, DevBuf *totals) {
     uint32_t nb = (n + BLOCK_ELEMS - 1) / BLOCK_ELEMS;
-    PLK_TRY(ctx->poly_tmp.reserve((size_t)nb * sizeof(Fr)));
-    Fr *tot = ctx->poly_tmp.as<Fr>();
+    DevBuf &tb = totals ? *totals : ctx->poly_tmp;
+    PLK_TRY(tb.reserve((size_t)nb * sizeof(Fr)));
+    Fr *tot = tb.as<Fr>();
     if (mult) {
         hipLaunchKernelGGL(k_scan_local<true>, dim3(nb), dim3(PT), 0, s, out, in, tot, n, reverse ? 1 : 0, exclusive ? 1 : 0);
         if (nb > 1) {
@@ -283,7 +284,8 @@ __global__ void __launch_bounds__(PT) k_lincomb(LinCombArgs a) {
         else { acc = addn(acc, mul2addw(pv, ps, v, sk)); pending = false; }
     }
     if (pending) acc = addn(acc, mulw(pv, ps));
-    stw(a.out + i, reduce_small(acc));                                                  // < 16 p here
+    if (a.times_pow.lo) stw(a.out + i, csub_p(mulw(normw(acc), pow2l_w_(a.times_pow, i))));   // (k_mul_powers folded in)
+    else stw(a.out + i, reduce_small(acc));                                             // < 16 p here
 }
 
 // out_i = in_i * base^(i + shift)     (base given by its W-domain power table)
