@@ -62,12 +62,12 @@ MSM_WINDOWS = 15                 # 17-bit signed windows over the 254-bit scalar
 # (profiles/r01_ubench_int.txt, k_mad64: 4.27 cycles per wave-instruction per SIMD at 2.4 GHz) = 36.87 T lane-mads/s;
 # one XYZZ mixed addition on the 9 x 29-bit layer is 1467 of them (6 products of 162 + 2 squarings of 126 + one fused
 # double product of 243; counted in the hot block of the code object) -> 25.1 G mixed additions/s if nothing but the
-# multiply-adds were issued.  The loop as compiled (1467 mads + 817 other VALU instructions per addition) reaches
-# 15.6 G/s in isolation (tools/ubench_w, profiles/r01_ubench_w.txt).
+# multiply-adds were issued.  The loop as compiled (round 3: 1467 mads + 625 other VALU instructions per addition, products in
+# lockstep pairs) reaches 16.3 G/s in isolation (tools/ubench_w, profiles/r03_ubench_mulw_forms.txt; 15.6 in round 2).
 MAD_RATE_TLANE_S = 576.11e9 * 64 / 1e12
 MADS_PER_MIXED_ADD = 1467
 VALU_PEAK_GMADD = MAD_RATE_TLANE_S * 1e3 / MADS_PER_MIXED_ADD
-LOOP_ISOLATED_GMADD = 15.6
+LOOP_ISOLATED_GMADD = 16.3
 
 
 def red_device(device):
@@ -577,7 +577,7 @@ def main():
                                   "frac_of_isolated_loop": round(gmadd / LOOP_ISOLATED_GMADD, 3),
                                   "derivation": "peak = measured v_mad_u64_u32 issue rate (576.1 G wave-instr/s x 64 lanes, "
                                                 "profiles/r01_ubench_int.txt) / 1467 mads per XYZZ mixed addition; "
-                                                "loop_isolated = the same loop with its 817 non-mad instructions, alone on the chip"},
+                                                "loop_isolated = the same loop with its 625 non-mad instructions, alone on the chip (profiles/r03_ubench_mulw_forms.txt)"},
                          "note": "kernel_ms = HIP-event duration of msm_accumulate with one commitment in flight (the region timed right "
                                  "after the headline one; rocprofv3 of `bench.py --msm-only --pipeline-depth 1` agrees, profiles/); "
                                  "kernel_ms_pipelined = the same kernel inside the headline region, where up to three commitments are in "
