@@ -109,13 +109,15 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_digits(ScalarSet set, MsmPara
 template <int THREADS>
 __device__ __forceinline__ void copy_out_runs(const uint32_t *lstart, const uint32_t *gbase, const uint32_t *staged, uint32_t *entries, uint32_t nbins) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t quad = lane >> 4, sub = lane & 15;             // four runs per iteration, 16 lanes each (a run is ~15 entries)
     for (uint32_t b0 = wave * 64; b0 < nbins; b0 += (THREADS / 64) * 64) {
         const uint32_t mine = b0 + lane;
         const uint32_t my_s = mine < nbins ? lstart[mine] : 0, my_e = mine < nbins ? lstart[mine + 1] : 0, my_g = mine < nbins ? gbase[mine] : 0;
         const uint32_t live = nbins - b0 < 64 ? nbins - b0 : 64;
-        for (uint32_t j = 0; j < live; j++) {
-            const uint32_t s0 = __shfl(my_s, (int)j), len = __shfl(my_e, (int)j) - s0, g0 = __shfl(my_g, (int)j);
-            for (uint32_t k = lane; k < len; k += 64) entries[g0 + k] = staged[s0 + k];
+        for (uint32_t j = 0; j < live; j += 4) {
+            const int src = (int)(j + quad);                           // (beyond `live`: the lane read zeros, the run is empty)
+            const uint32_t s0 = __shfl(my_s, src), len = __shfl(my_e, src) - s0, g0 = __shfl(my_g, src);
+            for (uint32_t k = sub; k < len; k += 16) entries[g0 + k] = staged[s0 + k];
         }
     }
 }
@@ -292,22 +294,25 @@ __global__ void __launch_bounds__(RC_THREADS) msm_recode_scatter(ScalarSet set, 
     for (uint32_t w = 0; w < RC_WINDOWS; w++)
         if (d[w]) { const uint32_t mg = (uint32_t)(d[w] < 0 ? -d[w] : d[w]) - 1; atomicAdd(&lcnt[mg >> p.fine_bits], 1u); }
     __syncthreads();
-    if (tid < 64) {                                                    // exclusive scan of <= 1024 counts by one wave
-        uint32_t per = (p.nbins + 63) / 64, lo = tid * per, hi = lo + per < p.nbins ? lo + per : p.nbins, sum = 0;
-        for (uint32_t b = lo; b < hi; b++) sum += lcnt[b];
-        uint32_t v = sum;
-        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off); if ((int)tid >= off) v += t; }
-        uint32_t run = v - sum;
-        for (uint32_t b = lo; b < hi; b++) { lstart[b] = run; run += lcnt[b]; }
-        if (tid == 63) lstart[p.nbins] = v;
+    // exclusive scan of the <= 1024 counts by the whole workgroup (one bin per thread: wave scan + the 16 wave totals), and the
+    // global reservation of every bin's run issued right away: its round trip to L2 overlaps the staging pass below, which only
+    // needs the LOCAL offsets
+    {
+        const uint32_t cnt = tid < p.nbins ? lcnt[tid] : 0;
+        uint32_t v = cnt;
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off); if ((int)(tid & 63) >= off) v += t; }
+        uint32_t *wtot = gbase;                                         // (scratch until the reservations land)
+        if ((tid & 63) == 63) wtot[tid >> 6] = v;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < (tid >> 6); w++) before += wtot[w];
+        __syncthreads();
+        const uint32_t reserved = cnt ? bin_start[tid] + atomicAdd(&cursor[tid], cnt) : 0;    // (tid < nbins whenever cnt != 0)
+        if (tid < p.nbins) { lstart[tid] = before + v - cnt; lcnt[tid] = 0; }                 // lcnt: reused as the in-bin cursor
+        if (tid == RC_THREADS - 1) lstart[p.nbins] = before + v;
+        __syncthreads();
+        if (tid < p.nbins) gbase[tid] = reserved;                       // read by the copy-out, after the barrier that follows the staging
     }
-    __syncthreads();
-    for (uint32_t b = tid; b < p.nbins; b += RC_THREADS) {
-        const uint32_t cnt = lcnt[b];
-        gbase[b] = cnt ? bin_start[b] + atomicAdd(&cursor[b], cnt) : 0;
-        lcnt[b] = 0;                                                   // reused as the in-bin cursor
-    }
-    __syncthreads();
     const uint32_t fmask = (1u << p.fine_bits) - 1;
 #pragma unroll
     for (uint32_t w = 0; w < RC_WINDOWS; w++) {
