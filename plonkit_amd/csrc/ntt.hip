@@ -449,6 +449,21 @@ static int32_t ntt_direct_table(plk_ctx *ctx, bool inverse, uint32_t log_r, uint
 // ------------------------------------------------------------------------------- driver
 static bool g_attr_set = false;
 
+// digits of the mixed-radix plan: up to 10 bits per pass
+static void digit_plan(uint32_t log_n, uint32_t d[4], uint32_t *passes) {
+    d[0] = d[1] = d[2] = d[3] = 0;
+    uint32_t p = 1;
+    if (log_n <= LOG_TILE) d[0] = log_n;
+    else {
+        p = (log_n + 9) / 10;                              // up to 10 bits per pass: 2^20 = 10 + 10 (two passes)
+        for (uint32_t i = 0; i < p; i++) d[i] = log_n / p + (i < log_n % p ? 1 : 0);
+        if (p == 3 && log_n <= 23) {                       // leave 14 bits to passes 2 and 3: their inter-pass twiddles
+            d[0] = log_n - 14; d[1] = 7; d[2] = 7;         // then come straight out of the hi table (ntt_pass_cols)
+        }
+    }
+    *passes = p;
+}
+
 // src: where the first pass reads (data itself for an in-place transform); nonzero: see NttPassArgs.
 // `count` transforms of the same shape share every launch (grid.y): a 2^20-point pass is ONE round of 512 tiles on the
 // chip's 512 workgroup slots, i.e. its time is the latency of a tile's load -> LDS stages -> store chain; four vectors
@@ -492,16 +507,8 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
         if (!inverse) PLK_TRY(ntt_coset_table(ctx, *coset, &pre));
         else PLK_TRY(ntt_coset_table(ctx, cached_inverse(ctx, *coset), &post));
     }
-    // digit plan
-    uint32_t d[4] = {0, 0, 0, 0}, p = 1;
-    if (log_n <= LOG_TILE) d[0] = log_n;
-    else {
-        p = (log_n + 9) / 10;                              // up to 10 bits per pass: 2^20 = 10 + 10 (two passes)
-        for (uint32_t i = 0; i < p; i++) d[i] = log_n / p + (i < log_n % p ? 1 : 0);
-        if (p == 3 && log_n <= 23) {                       // leave 14 bits to passes 2 and 3: their inter-pass twiddles
-            d[0] = log_n - 14; d[1] = 7; d[2] = 7;         // then come straight out of the hi table (ntt_pass_cols)
-        }
-    }
+    uint32_t d[4], p;
+    digit_plan(log_n, d, &p);
     const size_t n = (size_t)1 << log_n;
     PLK_TRY(ctx->ntt_scratch[lane].reserve((size_t)count * n * sizeof(Fr)));
     Fr *const scratch = ctx->ntt_scratch[lane].as<Fr>();

@@ -308,8 +308,10 @@ static int32_t setup_upload_impl(plk_ctx *ctx, plk_setup *S) {
         for (int j = 0; j < 4; j++) {
             if ((rc = sigma_from_index(S->sig_vals[j], idx + (size_t)j * N, (uint32_t)N, log_n, ctx->tw_fwd, kk, st)) != PLK_OK) { idx_buf.release(); return fail(rc); }
             if (hipMemcpyAsync(S->sig_coef[j], S->sig_vals[j], N * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) { idx_buf.release(); return fail(hip_fail(hipGetLastError(), "D2D sigma", __FILE__, __LINE__)); }
-            if ((rc = ntt_dev(ctx, S->sig_coef[j], log_n, true, nullptr, st)) != PLK_OK) { idx_buf.release(); return fail(rc); }
+            if (log_n > 22 && (rc = ntt_dev(ctx, S->sig_coef[j], log_n, true, nullptr, st)) != PLK_OK) { idx_buf.release(); return fail(rc); }
         }
+        // (one launch per pass for the four of them where the batch scratch is small)
+        if (log_n <= 22 && (rc = ntt_batch_dev(ctx, S->sig_coef, 4, log_n, true, nullptr, st, 0)) != PLK_OK) { idx_buf.release(); return fail(rc); }
         hipError_t e = hipStreamSynchronize(st);
         idx_buf.release();
         if (e != hipSuccess) return fail(hip_fail(e, "sync", __FILE__, __LINE__));
