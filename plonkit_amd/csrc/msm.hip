@@ -5,19 +5,22 @@
 // (src/plonk.rs:152-159) and the 11 of make_verification_key (src/plonk.rs:122-124).
 // The result is the same group element; the schedule is MI355X-first, not bellman's:
 //   * signed c-bit windows, W = floor(254/c)+1 of them, top window unsigned: c = 17 (15 windows, 2^16 buckets)
-//     from 2^19 terms, 15 / 13 below; scalars leave Montgomery form once and are recoded into int32 digits.
+//     from 2^19 terms, 15 / 13 below; scalars leave Montgomery form once and are recoded into signed digits — in registers
+//     when the commitment has ONE bucket set (msm_recode_count / msm_recode_scatter: the 2^20 shape), through an int32
+//     digit array otherwise (msm_digits + msm_partition).
 //   * the SRS is a FIXED base: a resident table holds 15 shifted copies 2^(17k) * P_i (0.94 GiB at 2^20 points,
 //     built once per SRS).  Window w takes its point from copy w, so that all windows drop into ONE bucket set
 //     (3 or 5 sets above 2^20 terms, where an entry can only address 5 or 3 copies) and the host Horner shrinks
 //     to 17 * (sets - 1) doublings.
 //   * two-level bucket sort without a global sort: (1) a coarse partition by the top bits of the bucket index:
-//     per (window, 16K-scalar chunk) workgroup an LDS counting sort, one global reservation per (block, bin) and
-//     contiguous copy-out of every bin's run; (2) a coarse bin (2^FB consecutive buckets; FB = 6: 1024 bins of ~15 K
+//     per workgroup (1024 scalars x all windows, or a 16K-scalar chunk of one window) an LDS counting sort, one global
+//     reservation per (block, bin) and contiguous copy-out of every bin's run; (2) a coarse bin (2^FB consecutive buckets; FB = 6: 1024 bins of ~15 K
 //     entries at 2^20 terms, i.e. one task per bin) is cut into equal tasks of <= 16384 entries; a workgroup
 //     counting-sorts its task inside LDS and cuts the sorted run into 256 EQUAL pieces, one per lane: one flat loop of
 //     mixed additions with XYZZ accumulators in registers, a bucket boundary inside a piece only flushes the accumulator
 //     (PRIMARY / HEAD / TAIL slots).  Points are gathered as 64-byte affine records.  All field arithmetic is the
-//     carry-free 9x29-bit layer (field29_dev.h / ec29_dev.h).
+//     carry-free 9x29-bit layer (field29_dev.h / ec29_dev.h): product-scanning products in lockstep pairs in the mixed
+//     addition (throughput-bound), operand-scanning products in the full additions of the reduce kernels (latency-bound).
 //   * a bucket spread over many lanes (repeated scalars: all-ones, all -1) is folded by a separate small kernel
 //     (msm_fold_hot), a coarse bin spread over many tasks by another (msm_bin_fold).
 //   * per task T = sum B_f and S = sum (f+1) B_f (running sums + 32-lane shuffle scan), then per bucket set

@@ -25,6 +25,10 @@
 //     zero-padded input (LDE) is read in place: indices beyond the coefficient count are neither loaded nor
 //     scaled, and the first pair of stages of its first pass is a copy.  Outputs are made canonical by a
 //     quotient-estimate reduction, not by a product.
+//   * Up to 16 transforms of one shape share every launch (grid.y, per-transform input tables): the four wire iNTTs of a
+//     proof, and the coset-major extension lde4cm_batch_dev — 4n evaluations as four n-point coset transforms (cosets
+//     7*omega_4n^k * <omega_n>) per polynomial, the layout the quotient kernel reads.  Two scratch lanes, so that transforms on the
+//     prover's background stream do not share the ping-pong buffer with the main stream's.
 //   * No MFMA: this is 256-bit modular integer arithmetic, bound by v_mad_u64_u32 issue.
 #include "ctx.h"
 #include "ntt.h"

@@ -9,6 +9,10 @@
 // Appendix A.3/A.4 and pinned byte-for-byte by test/circuits/simple/{vk,proof}.bin.
 // Everything O(N) runs on the GPU (ntt.hip, msm.hip, poly.hip); the host keeps the transcript,
 // a few dozen scalars per round and the circuit synthesis.
+// Streams of a proof: ctx->stream carries the round-critical kernels; every commitment runs on its MSM slot's stream
+// (msm.hip); ctx->bg_stream (own NTT scratch) carries the work no challenge waits for — the coset-major extensions of the
+// wires, z and the public inputs, and the second opening quotient — started by hand behind the accumulation of the commitment
+// in flight, so that it fills the latency-bound ends of a commitment instead of standing between two rounds.
 #include "ctx.h"
 #include "ntt.h"
 #include "msm.h"
