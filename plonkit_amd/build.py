@@ -54,6 +54,9 @@ def build(verbose=False, force=False):
         for f in os.listdir(OBJDIR):
             os.remove(os.path.join(OBJDIR, f))
     srcs = _sources()
+    for f in os.listdir(OBJDIR):                                   # objects of earlier header generations are dead weight
+        if f.endswith(".o") and ("." + digest + ".o") not in f:
+            os.remove(os.path.join(OBJDIR, f))
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, digest, verbose), srcs))
     newest = max(os.path.getmtime(o) for o in objs)
