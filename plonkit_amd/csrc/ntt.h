@@ -14,5 +14,7 @@ int32_t lde4_dev(plk_ctx *ctx, const Fr *coeffs, uint32_t log_n, Fr *out_4n, hip
 int32_t ntt_batch_dev(plk_ctx *ctx, Fr *const *data, uint32_t count, uint32_t log_n, bool inverse, const Fr *coset, hipStream_t stream, uint32_t lane);
 // the 4n evaluations in coset-major order: out[k * n + r] = f(7 * omega_4n^(4 r + k)) (four n-point coset transforms; prover-internal layout)
 int32_t lde4cm_batch_dev(plk_ctx *ctx, const Fr *const *coeffs, uint32_t count, uint32_t log_n, Fr *const *out_4n, hipStream_t stream, uint32_t lane);
+// coset-major 4n values -> per coset k the n coefficients u_k (in place, u_k at data + k*n); poly.hip icoset_combine finishes the coset iNTT
+int32_t icoset4cm_dev(plk_ctx *ctx, Fr *data_4n, uint32_t log_n, hipStream_t stream, uint32_t lane);
 int32_t lde4_batch_dev(plk_ctx *ctx, const Fr *const *coeffs, uint32_t count, uint32_t log_n, Fr *const *out_4n, hipStream_t stream, uint32_t lane);
 }  // namespace plk

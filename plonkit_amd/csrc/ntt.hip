@@ -50,7 +50,7 @@ struct NttPassArgs {
     uint32_t log_r1, log_m1, log_m2;           // final pass: digit widths of k1 and the middle digits
     PowTable tw;                               // omega_{2^28}^(+-e)
     PowTable pre_b[NTT_MAX_BATCH];             // optional, per transform: multiply input i by pre^i (first pass)
-    PowTable post;                             // optional: multiply output k by post^k (last pass)
+    PowTable post_b[NTT_MAX_BATCH];            // optional, per transform: multiply output k by post^k (last pass)
     Fr scale;                                  // optional 1/n on the last pass
     uint32_t has_scale;
     uint32_t nonzero;                          // first pass: input elements at index >= nonzero are zero and are
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
     const uint32_t tid = threadIdx.x, t = blockIdx.x;
     const Fr *const in = a.in_b[blockIdx.y];
     Fr *const out = a.out_b[blockIdx.y];
-    const PowTable pre = a.pre_b[blockIdx.y];
+    const PowTable pre = a.pre_b[blockIdx.y], post = a.post_b[blockIdx.y];
     const uint32_t kb_log = a.log_r1 - log_c, log_m = a.log_m1 + a.log_m2;
     const uint32_t k1_0 = (t & ((1u << kb_log) - 1)) << log_c, mu = t >> kb_log;
 
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
         uint32_t c = idx & (C - 1), k = idx >> log_c;
         size_t o = (size_t)(k1_0 + c) + (drev << a.log_r1) + ((size_t)k << (a.log_n - log_r));
         FrW9 v = L.get(k * C + c);
-        if (a.post.lo) v = mulw(v, pow2l_w(a.post, (uint32_t)o));
+        if (post.lo) v = mulw(v, pow2l_w(post, (uint32_t)o));
         v = a.has_scale ? csub_p(mulw(v, last)) : reduce_small(v);          // canonical output (values here are < 24p)
         store_fp(out + o, pack<FrParams>(v));
     }
@@ -475,7 +475,7 @@ static void digit_plan(uint32_t log_n, uint32_t d[4], uint32_t *passes) {
 // `lane` selects the ping-pong scratch: transforms enqueued on different streams at the same time must not share it
 // (lane 1 = the prover's background stream).
 static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr *const *data, uint32_t count, uint32_t log_n, bool inverse,
-                       const Fr *coset, hipStream_t stream, uint32_t lane, const PowTable *pre_each = nullptr);
+                       const Fr *coset, hipStream_t stream, uint32_t lane, const PowTable *pre_each = nullptr, const PowTable *post_each = nullptr);
 
 int32_t ntt_dev(plk_ctx *ctx, Fr *data, uint32_t log_n, bool inverse, const Fr *coset, hipStream_t stream) {
     const Fr *src = data;
@@ -493,9 +493,10 @@ int32_t ntt_batch_dev(plk_ctx *ctx, Fr *const *data, uint32_t count, uint32_t lo
     return PLK_OK;
 }
 
-// pre_each: one input-scaling table per transform of the batch (the four cosets of lde4cm_batch_dev) instead of `coset`
+// pre_each / post_each: one input- / output-scaling table per transform of the batch (the four cosets of lde4cm_batch_dev and
+// of icoset4cm_dev) instead of `coset`
 static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr *const *data, uint32_t count, uint32_t log_n, bool inverse,
-                       const Fr *coset, hipStream_t stream, uint32_t lane, const PowTable *pre_each) {
+                       const Fr *coset, hipStream_t stream, uint32_t lane, const PowTable *pre_each, const PowTable *post_each) {
     if (!data || !src || count == 0 || count > NTT_MAX_BATCH || lane >= 2) { set_error("ntt: bad argument"); return PLK_ERR_ARG; }
     for (uint32_t b = 0; b < count; b++) if (!data[b] || !src[b]) { set_error("ntt: null data"); return PLK_ERR_ARG; }
     if (log_n > MAX_LOG_N) { set_error("ntt: log_n exceeds the 2-adicity of Fr (28)"); return PLK_ERR_SIZE; }
@@ -530,7 +531,8 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
         a.log_r = d[i]; a.log_inner = rem;
         a.log_c = (LOG_TILE - d[i]) < rem ? (LOG_TILE - d[i]) : rem;
         for (uint32_t b = 0; b < count; b++) a.pre_b[b] = (i == 0) ? (pre_each ? pre_each[b] : pre) : PowTable{};
-        a.post = PowTable{}; a.has_scale = 0;
+        for (uint32_t b = 0; b < count; b++) a.post_b[b] = PowTable{};
+        a.has_scale = 0;
         PLK_TRY(ntt_direct_table(ctx, inverse, d[i], rem, inverse && i == 0, log_n, stream, &a.tw_direct));
         if (a.tw_direct && inverse && i == 0) scale_folded = true;
         a.quarter = (i == 0 && nonzero && nonzero == (n >> 2) && !(d[0] & 1) && d[0] >= 2) ? 1 : 0;
@@ -550,7 +552,7 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
             a.log_c = (LOG_TILE - a.log_r) < d[0] ? (LOG_TILE - a.log_r) : d[0];
         }
         for (uint32_t b = 0; b < count; b++) a.pre_b[b] = (p == 1) ? (pre_each ? pre_each[b] : pre) : PowTable{};
-        a.post = post;
+        for (uint32_t b = 0; b < count; b++) a.post_b[b] = post_each ? post_each[b] : post;
         a.tw_direct = nullptr; a.quarter = 0;
         a.has_scale = (inverse && !scale_folded) ? 1 : 0;
         if (a.has_scale) a.scale = ctx->n_inv_w[log_n];
@@ -578,6 +580,24 @@ int32_t lde4_batch_dev(plk_ctx *ctx, const Fr *const *coeffs, uint32_t count, ui
         done += b;
     }
     return PLK_OK;
+}
+
+// The inverse of lde4cm_batch_dev's first half: 4n values in coset-major order -> for every coset k the coefficients u_k of the
+// degree-< n polynomial that takes them on g_k * <omega_n>, in place (u_k at data + k * n): four inverse n-point transforms with
+// their output scaled by g_k^-j, one launch per pass.  poly.hip's icoset_combine turns the four u_k into the 4n coefficients.
+int32_t icoset4cm_dev(plk_ctx *ctx, Fr *data_4n, uint32_t log_n, hipStream_t stream, uint32_t lane) {
+    if (log_n + 2 > MAX_LOG_N) { set_error("icoset4: 4n exceeds 2^28"); return PLK_ERR_SIZE; }
+    const size_t n = (size_t)1 << log_n;
+    PLK_TRY(ntt_init_tables(ctx));
+    PowTable post[4];
+    {
+        Fr g = from_u64<FrParams>(7);
+        const Fr w = ntt_omega(log_n + 2);
+        for (int k = 0; k < 4; k++) { PLK_TRY(ntt_coset_table(ctx, cached_inverse(ctx, g), &post[k])); g = mul(g, w); }
+    }
+    const Fr *src[4]; Fr *dst[4];
+    for (uint32_t k = 0; k < 4; k++) { src[k] = data_4n + k * n; dst[k] = data_4n + k * n; }
+    return ntt_run(ctx, src, 0, dst, 4, log_n, true, nullptr, stream, lane, nullptr, post);
 }
 
 int32_t lde4_dev(plk_ctx *ctx, const Fr *coeffs, uint32_t log_n, Fr *out_4n, hipStream_t stream) {

@@ -74,6 +74,9 @@ int32_t mul3(Fr *out, const Fr *a, const Fr *b, const Fr &sc, uint32_t n, hipStr
 // totals: where the block totals live (default: the context's poly_tmp; two scans in flight on two streams need two)
 int32_t scan(plk_ctx *ctx, Fr *out, const Fr *in, uint32_t n, bool mult, bool reverse, bool exclusive, hipStream_t s, DevBuf *totals = nullptr);
 int32_t quotient(const QuotientArgs &a, hipStream_t s);
+// data = the four per-coset coefficient vectors u_k of icoset4cm_dev (u_k at data + k*n) -> the 4n coefficients, natural order, in place;
+// constants in the W domain: i^-1 (i = omega_4) and s_c = 7^(-N c) / 4
+int32_t icoset_combine(Fr *data, uint32_t n, const Fr &iinv_w, const Fr s_w[4], hipStream_t s);
 int32_t lincomb(const LinCombArgs &a, hipStream_t s);
 int32_t mul_powers(Fr *out, const Fr *in, const PowTable &t, uint32_t shift, uint32_t n, hipStream_t s);
 int32_t div_finish(Fr *q, const Fr *suffix, const PowTable &zinv, uint32_t n, hipStream_t s);

@@ -264,7 +264,29 @@ __global__ void __launch_bounds__(PT) k_quotient(QuotientArgs a) {
     }
     FrW9 t = addn(g, mulw(cw(a.alpha_pp), sub2(pa, pb)));
     t = addn(t, mulw(cw(a.alpha2_w), mulw(ldw(a.l0 + i), sub2(z, cw(Fr::one())))));
-    store_fp(a.out + jnat, pack<FrParams>(csub_p(mulw(t, cw(a.zh_inv_w[kc])))));
+    store_fp(a.out + i, pack<FrParams>(csub_p(mulw(t, cw(a.zh_inv_w[kc])))));
+}
+
+// Second half of the coset iNTT at 4N from the coset-major layout.  t(x) = sum_c x^(cN) T_c(x) with deg T_c < N; on the coset
+// g_k * <omega_N> (g_k = 7 * omega_4N^k) x^N = 7^N * i^k (i = omega_4), so the polynomial u_k interpolated there (icoset4cm_dev) is
+// u_k = sum_c (7^N i^k)^c T_c and, coefficient by coefficient,  T_c = 7^(-Nc) * (1/4) * sum_k i^(-kc) u_k : a 4-point inverse DFT
+// (one product by i^-1) and four constant scalings, in place (thread j owns the four slots {cN + j}).  Output: natural
+// coefficient order, canonical — what the three-pass 4N transform produced, at ~60 % of its cost together with the first half.
+__global__ void __launch_bounds__(PT) k_icoset_combine(Fr *data, uint32_t n, Fr iinv_w, Fr s0_w, Fr s1_w, Fr s2_w, Fr s3_w) {
+    const uint32_t j = blockIdx.x * PT + threadIdx.x;
+    if (j >= n) return;
+    const FrW9 u0 = ldw(data + j), u1 = ldw(data + n + j), u2 = ldw(data + 2 * (size_t)n + j), u3 = ldw(data + 3 * (size_t)n + j);
+    const FrW9 a = addn(u0, u2), b = sub2(u0, u2), c = addn(u1, u3);
+    const FrW9 d = mulw(sub2(u1, u3), cw(iinv_w));                                       // (u1 - u3) * i^-1
+    stw(data + j, csub_p(mulw(addw(a, c), cw(s0_w))));
+    stw(data + n + j, csub_p(mulw(addw(b, d), cw(s1_w))));
+    stw(data + 2 * (size_t)n + j, csub_p(mulw(sub4(a, c), cw(s2_w))));
+    stw(data + 3 * (size_t)n + j, csub_p(mulw(sub2(b, d), cw(s3_w))));
+}
+int32_t icoset_combine(Fr *data, uint32_t n, const Fr &iinv_w, const Fr s_w[4], hipStream_t s) {
+    hipLaunchKernelGGL(k_icoset_combine, dim3((n + PT - 1) / PT), dim3(PT), 0, s, data, n, iinv_w, s_w[0], s_w[1], s_w[2], s_w[3]);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
 }
 
 // ------------------------------------------------------------------- linear combinations

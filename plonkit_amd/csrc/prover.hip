@@ -180,6 +180,7 @@ struct plk_setup {
     mutable bool lde_ready = false;
     mutable bool zh_inv_ready = false;
     mutable plk::HFr zh_inv[4];
+    mutable plk::HFr icoset_c[5];            // i^-1 (i = omega_4) and 7^(-N c) / 4, c = 0..3: constants of the coset iNTT's combine step
     uint64_t num_circuit_vars = 0;         // circom wires; temporaries follow
     std::vector<plk::WitnessOp> ops;       // linear forms defining the transpiler's temporaries
     bool ops_independent = false;          // no temporary reads another temporary -> order-free evaluation
@@ -632,14 +633,25 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
         if (!S->zh_inv_ready) {                                   // 1 / Z_H on the four cosets of <omega_N> inside the 4N domain: circuit constants
             HFr gN = coset.pow_u64(N), iota = host_omega(log_m).pow_u64(N), ip = HFr::one();
             for (int k = 0; k < 4; k++) { S->zh_inv[k] = (gN * ip - HFr::one()).inv(); ip = ip * iota; }
+            const HFr gN_inv = gN.inv(), quarter = HFr::from_u64(4).inv();
+            S->icoset_c[0] = iota.inv();                           // iota = omega_4N^N = omega_4
+            S->icoset_c[1] = quarter;
+            for (int c = 1; c < 4; c++) S->icoset_c[1 + c] = S->icoset_c[c] * gN_inv;
             S->zh_inv_ready = true;
         }
         for (int k = 0; k < 4; k++) qa.zh_inv_w[k] = to_dev(S->zh_inv[k] * two5);
         qa.m = (uint32_t)M; qa.log_m = log_m;
         if (use_bg) PLK_HIP(hipStreamWaitEvent(st, ctx->bg_done, 0));      // the five extensions (+ PI) of the background stream
         PLK_TRY(quotient(qa, st));
-        Fr g = to_dev(coset);
-        PLK_TRY(ntt_dev(ctx, t_ext, log_m, true, &g, st));
+        // coset iNTT at 4N from the coset-major layout the kernel wrote: four inverse N-point coset transforms (one launch per
+        // pass) and a 4-point combine, instead of three passes over 4N (0.57 -> 0.48 ms at the 2^20 domain)
+        PLK_TRY(icoset4cm_dev(ctx, t_ext, log_n, st, 0));
+        {
+            const HFr two5 = HFr::from_u64(32);
+            Fr s_w[4];
+            for (int c = 0; c < 4; c++) s_w[c] = to_dev(S->icoset_c[1 + c] * two5);
+            PLK_TRY(icoset_combine(t_ext, (uint32_t)N, to_dev(S->icoset_c[0] * two5), s_w, st));
+        }
     }
     HAffine t_c[4];
     {
