@@ -478,9 +478,13 @@ def test_unsatisfied_witness_is_refused(ctx, golden_dir, golden_crs, tmp_path):
     wt = bytearray(big.export("wtns"))
     wt[-1] ^= 1                                                    # flip a bit of the last witness value
     broken = pa.Circuit(big.export("r1cs"), False, bytes(wt), False)
+    want = s2.prove(big)
     with pytest.raises(pa.PlkError) as e2:
         s2.prove(broken)
     assert e2.value.code == 5
+    # the refusal comes after round 1 has been enqueued (commitments on their slot stream, the wire extensions on the background
+    # stream): both are drained before the call returns, and the next proof on the same context is the expected one
+    assert s2.prove(big) == want
 
 
 def test_reference_binary_harness_with_a_stand_in(monkeypatch):
@@ -508,3 +512,31 @@ def test_reference_binary_harness_with_a_stand_in(monkeypatch):
     monkeypatch.setenv("PLONKIT_REF_BIN", "/nonexistent/plonkit")
     out = bench.reference_binary_baseline(12)                                 # a broken binary must not cost the bench line
     assert out is not None and "error" in out
+
+
+def test_single_stream_and_digit_array_paths_give_the_same_bytes():
+    """round 3 added two shortcuts with a switch each: the background stream of the prover (PLK_PROVE_BG=0: everything on the main
+    stream, the path domains above 2^24 take) and the fused scalar recoding of the MSM pre-phase (PLK_MSM_FUSED_RECODE=0: the
+    digit array + msm_partition, the path of commitments with several bucket sets).  With both off the proof and the
+    verification key must be the bytes of the default run (the switches are read once per process, hence the subprocess)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, hashlib
+import plonkit_amd as pa
+n = 1 << 14
+ctx = pa.Context(0)
+ctx.srs_generate(n, 0, 42)
+circ = pa.Circuit.synthetic(n - 2)
+setup = pa.SetupForProver(ctx, circ)
+vk, proof = setup.verification_key_bytes(pa.crs42_g2_bytes()), setup.prove(circ)
+assert setup.prove(circ) == proof and pa.verify(vk, proof)
+print("DIGEST", hashlib.sha256(vk + proof).hexdigest())
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for env_extra in ({}, {"PLK_PROVE_BG": "0", "PLK_MSM_FUSED_RECODE": "0"}, {"PLK_PROVE_BG": "0"}, {"PLK_MSM_FUSED_RECODE": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert len(set(digests)) == 1, digests
