@@ -212,16 +212,14 @@ __global__ void __launch_bounds__(PT) k_coset_points_w(Fr *out, PowTable tw_w, u
 
 // t(x) = [gate + PI + alpha*(perm) + alpha^2*L0*(z-1)] / Z_H(x) on the coset 7*<omega_4N>.
 // 24 products per point on the 29-bit layer, the seven gate products in two fused sums (one reduction per three).
-// Every input vector is in the COSET-MAJOR layout of lde4cm_batch_dev: position i = k * N + r holds the value at
-// x_j = 7 * omega_4N^j, j = 4 r + k.  f(omega * x) is then the next row of the same coset, 1 / Z_H depends on k only.  The
-// quotient itself is written at its natural index j (the coset iNTT that follows takes natural order): a workgroup takes
-// 256 rows of one coset and its three neighbours in the grid the same rows of the other cosets, so that the four 32-byte
-// quarters of a 128-byte line are written at about the same time.
+// Every vector — the inputs and the quotient itself — is in the COSET-MAJOR layout of lde4cm_batch_dev: position i = k * N + r
+// holds the value at x_j = 7 * omega_4N^j, j = 4 r + k.  f(omega * x) is then the next row of the same coset, 1 / Z_H depends
+// on k only; the coset iNTT that follows (icoset4cm_dev + k_icoset_combine) takes this order.
 __global__ void __launch_bounds__(PT) k_quotient(QuotientArgs a) {
     const uint32_t log_n = a.log_m - 2, nmask = (1u << log_n) - 1;
-    uint32_t i, kc, r;
-    if (a.m >= 4 * PT) { kc = blockIdx.x & 3; r = (blockIdx.x >> 2) * PT + threadIdx.x; i = (kc << log_n) | r; }
-    else { i = blockIdx.x * PT + threadIdx.x; if (i >= a.m) return; kc = i >> log_n; r = i & nmask; }      // tiny domains
+    const uint32_t i = blockIdx.x * PT + threadIdx.x;
+    if (i >= a.m) return;
+    const uint32_t kc = i >> log_n, r = i & nmask;
     const uint32_t jnat = (r << 2) | kc;
     const uint32_t nxt = (kc << log_n) | ((r + 1) & nmask);      // f(omega*x): the next row of this coset
     FrW9 w[4];
