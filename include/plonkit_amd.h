@@ -82,6 +82,10 @@ int32_t plk_lde4_dev(plk_ctx *ctx, const void *coeffs_dev, uint32_t log_n, void 
  * one launch per pass (prove_by_steps' ~18 coset_lde(4) calls, src/plonk.rs:152-159).  A permutation of plk_lde4_dev's output;
  * exposed so that the layout is testable on its own.                                                                      */
 int32_t plk_lde4_coset_major_dev(plk_ctx *ctx, const void *const *coeffs_dev, uint32_t count, uint32_t log_n, void *const *out_4n_dev, void *stream);
+/* The way back (round 3 of prove_by_steps: Polynomial::icoset_fft at 4n, src/plonk.rs:152-159): 4n values in that coset-major order
+ * -> the 4n coefficients in natural order, in place (four inverse n-point coset transforms in one launch per pass + a 4-point combine).
+ * Test hook like the function above.                                                                                              */
+int32_t plk_icoset4_coset_major_dev(plk_ctx *ctx, void *data_4n_dev, uint32_t log_n, void *stream);
 
 /* ---- kate_commitment::commit_using_monomials -> multiexp::dense_multiexp (src/plonk.rs:122-124 and
  *      the 11 commitments of prove): sum_i scalars[i] * srs[base_offset + i], scalars Montgomery Fr.

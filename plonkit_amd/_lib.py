@@ -233,6 +233,10 @@ class Context:
         outs = (ctypes.c_void_p * cnt)(*[_devptr(p).value for p in out_ptrs])
         _check(lib().plk_lde4_coset_major_dev(self._h, ins, ctypes.c_uint32(cnt), ctypes.c_uint32(log_n), outs, _stream(stream)))
 
+    def icoset4_coset_major_dev(self, ptr, log_n, stream=None):
+        """4n values in coset-major order -> the 4n coefficients (natural order), in place"""
+        _check(lib().plk_icoset4_coset_major_dev(self._h, _devptr(ptr), ctypes.c_uint32(log_n), _stream(stream)))
+
     # ---- MSM
     def msm(self, scalars, base_offset=0):
         s = np.ascontiguousarray(scalars, dtype=np.uint64)

@@ -4,6 +4,8 @@
 #include "ctx.h"
 #include <cstdlib>
 #include "ntt.h"
+#include "poly.h"
+#include "hostmath.h"
 #include "msm.h"
 #include "comm.h"
 #include <cstring>
@@ -230,6 +232,24 @@ int32_t plk_lde4_coset_major_dev(plk_ctx *ctx, const void *const *coeffs_dev, ui
     PLK_HIP(hipSetDevice(ctx->device));
     return lde4cm_batch_dev(ctx, reinterpret_cast<const Fr *const *>(coeffs_dev), count, log_n, reinterpret_cast<Fr *const *>(out_4n_dev),
                             stream ? (hipStream_t)stream : ctx->stream, 0);
+}
+
+int32_t plk_icoset4_coset_major_dev(plk_ctx *ctx, void *data_4n_dev, uint32_t log_n, void *stream) {
+    if (!ctx || !data_4n_dev) { set_error("plk_icoset4_coset_major_dev: bad argument"); return PLK_ERR_ARG; }
+    if (log_n + 2 > 28) { set_error("plk_icoset4_coset_major_dev: 4n exceeds 2^28"); return PLK_ERR_SIZE; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    PLK_TRY(icoset4cm_dev(ctx, (Fr *)data_4n_dev, log_n, st, 0));
+    // constants of the combine step: i^-1 (i = omega_4 = omega_4n^n) and 7^(-n c) / 4, in the 2^261 domain of the field layer
+    using host::HFr;
+    const uint64_t n = 1ull << log_n;
+    HFr w4; { Fr w = ntt_omega(2); memcpy(w4.l, w.l, 32); }
+    const HFr gN_inv = HFr::from_u64(7).pow_u64(n).inv(), two5 = HFr::from_u64(32);
+    HFr c = HFr::from_u64(4).inv();
+    Fr s_w[4], iinv;
+    { HFr t = w4.inv() * two5; memcpy(iinv.l, t.l, 32); }
+    for (int k = 0; k < 4; k++) { HFr t = c * two5; memcpy(s_w[k].l, t.l, 32); c = c * gN_inv; }
+    return icoset_combine((Fr *)data_4n_dev, (uint32_t)n, iinv, s_w, st);
 }
 
 int32_t plk_lde4(plk_ctx *ctx, const plk_fr *coeffs, uint32_t log_n, plk_fr *out_4n) {

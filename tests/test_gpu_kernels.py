@@ -101,6 +101,31 @@ def test_lde4_coset_major(ctx, log_n, count):
             assert np.array_equal(got[k], nat[:, k, :]), (p, k)
 
 
+@pytest.mark.parametrize("log_n", [1, 3, 9, 10, 11, 12, 16, 20])
+def test_icoset4_coset_major(ctx, log_n):
+    """the coset iNTT of the prover's round 3 (icoset4cm_dev + k_icoset_combine): a random polynomial of 4n coefficients is
+    evaluated on 7*<omega_4n> by the natural-order coset NTT (pinned to the oracle above), its values are put in coset-major
+    order on the host (position k*n + r <- natural index 4r + k), and the in-place transform must give the coefficients
+    back, canonical — bit-exact"""
+    import torch
+    n = 1 << log_n
+    coef = _rand_fr(4 * n, 700 + log_n)
+    d = torch.from_numpy(coef.view(np.int64)).to("cuda:0")
+    g = ol.fr_vec([7])[0]
+    ctx.ntt_dev(d, log_n + 2, inverse=False, coset=g)
+    ctx.synchronize()
+    nat = d.cpu().numpy().view(np.uint64).reshape(n, 4, 4)                # [r][k][limb]
+    if log_n <= 14:
+        assert np.array_equal(nat.reshape(4 * n, 4), ol.ntt(coef, log_n + 2, coset=7))
+    cm = np.ascontiguousarray(nat.transpose(1, 0, 2)).reshape(4 * n, 4)    # [k][r]
+    dcm = torch.from_numpy(cm.view(np.int64)).to("cuda:0")
+    torch.cuda.synchronize()
+    ctx.icoset4_coset_major_dev(dcm, log_n)
+    ctx.synchronize()
+    # the input was a raw 252-bit residue < r: already canonical, so equality is exact
+    assert np.array_equal(dcm.cpu().numpy().view(np.uint64), coef)
+
+
 def test_ntt_errors(ctx):
     import plonkit_amd as pa
     with pytest.raises(pa.PlkError) as e:
