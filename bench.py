@@ -588,6 +588,8 @@ def main():
                                  "(0.94 GiB fixed-base table in HBM)"},
         }
         if sustained is not None:
+            # (top-level copy of sustained.value: round 2's `value` was measured after 50 settle commitments, i.e. it corresponds to THIS figure)
+            line["value_sustained"] = round(world * n / (sustained / args.steps) / 1e6, 3)
             line["sustained"] = {"value": round(world * n / (sustained / args.steps) / 1e6, 3), "ms_per_step": round(sustained * 1e3 / args.steps, 4),
                                  "steps": args.steps, "untimed_steps_before": args.settle_steps + args.warmup + args.steps + args.sustained_settle_steps,
                                  "what": "the headline region repeated after %d further untimed commitments (GPU under load for >= 70 ms)" % args.sustained_settle_steps}
