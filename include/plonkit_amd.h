@@ -67,6 +67,16 @@ int32_t plk_srs_download(plk_ctx *ctx, uint64_t offset, uint64_t n, plk_g1_affin
  * MSM (15 shifted copies of the points, ~40 ms at 2^20 points).  A host program calls it on a second thread while it is
  * still parsing the circuit (the `plonkit` binary does); without it the first commitment pays for the table.           */
 int32_t plk_srs_precompute(plk_ctx *ctx);
+/* SEVERAL PROOFS IN FLIGHT ON ONE GPU.  SetupForProver::prove takes &self (src/plonk.rs:132-176): nothing stops a Rust host from
+ * proving from two threads against one setup, and on this hardware it pays — the strict challenge chain of one proof leaves
+ * latency-bound stretches (bucket-reduction tails, host round trips, small point-wise launches: ~3.5 ms of a 2^20 proof) that the
+ * kernels of a second proof fill.  The unit of concurrency is the context: one plk_ctx per host thread (a context is NOT
+ * thread-safe), any number of contexts per device, ONE plk_setup shared by all of them (its lazily cached extensions are
+ * filled under a lock), one plk_circuit per witness.  plk_ctx_share_srs makes `dst` borrow `src`'s resident key(s) and MSM
+ * fixed-base table(s) instead of building its own (0.94 GiB and ~40 ms per key at 2^20 points): `src` builds what is missing,
+ * keeps ownership, refuses to replace its key while a borrower exists (PLK_ERR_ARG) and must be destroyed after its borrowers.
+ * A borrower that is given a key of its own (upload / generate / set_dev) simply stops borrowing.                              */
+int32_t plk_ctx_share_srs(plk_ctx *dst, plk_ctx *src);
 
 /* ---- Polynomial::{fft,ifft,coset_fft,icoset_fft} over Fr (bellman_ce::plonk::polynomials; driven
  *      from setup() src/plonk.rs:104 and prove_by_steps src/plonk.rs:152-159).
@@ -219,6 +229,14 @@ int32_t plk_circuit_load(const uint8_t *r1cs, uint64_t r1cs_len, int32_t r1cs_is
 /* synthetic chain circuit of exactly `target_gates` PLONK gates + 1 public input, with witness
  * (xoshiro256** seed, pinned constraint shapes); bench / test input.    */
 int32_t plk_circuit_synthetic(uint64_t target_gates, uint64_t seed, plk_circuit **out);
+/* the same generator with two more knobs (bench / test input).  witness_seed != 0: the SAME R1CS (it depends on `seed` only) with
+ * another satisfying witness — what a prover serving many requests for one circuit sees (CircomCircuit{r1cs, witness},
+ * src/circom_circuit.rs:41-47: one r1cs, a witness per proof).  lc_terms = 5..64: "dense" body — every constraint's A side is a
+ * linear combination of lc_terms earlier wires plus a constant, the shape of a circom Poseidon round, which the transpiler folds
+ * through the d column with q_d_next = -1 (src/circom_circuit.rs:114-131): d, q_d_next and the fourth quotient chunk are live, so a
+ * proof does all 11 commitments (the pinned-subset circuit leaves two of them empty).  That chaining rule is unpinned (SURVEY.md
+ * A.3).  lc_terms = 0: exactly plk_circuit_synthetic.                                                                            */
+int32_t plk_circuit_synthetic_ex(uint64_t target_gates, uint64_t seed, uint64_t witness_seed, uint32_t lc_terms, plk_circuit **out);
 /* what = 0: iden3 .r1cs v1 bytes, 1: .wtns v2 bytes (the reference's own input formats,
  * src/r1cs_file.rs:100-154, src/reader.rs:124-175); out == NULL only reports the length.            */
 int32_t plk_circuit_export(const plk_circuit *c, int32_t what, uint8_t *out, uint64_t cap, uint64_t *len);

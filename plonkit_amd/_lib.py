@@ -188,6 +188,12 @@ class Context:
         """builds the MSM's fixed-base table of the resident key(s) now instead of at the first commitment"""
         _check(lib().plk_srs_precompute(self._h))
 
+    def share_srs_from(self, owner):
+        """borrow `owner`'s resident key(s) and MSM fixed-base table(s) (same device): a second context for proofs in flight
+        beside `owner`'s costs workspace only.  `owner` must outlive this context's use of the key."""
+        _check(lib().plk_ctx_share_srs(self._h, owner._h))
+        self._srs_owner = owner                                       # keep the lender alive
+
     def srs_download(self, offset, n):
         out = np.zeros((n, 8), dtype=np.uint64)
         _check(lib().plk_srs_download(self._h, ctypes.c_uint64(offset), ctypes.c_uint64(n), _np(out)))
@@ -341,6 +347,16 @@ class Circuit:
         _check(lib().plk_circuit_synthetic(ctypes.c_uint64(target_gates), ctypes.c_uint64(seed), ctypes.byref(self._h)))
         return self
 
+    @classmethod
+    def synthetic_ex(cls, target_gates, seed=0x706c6f6e6b6974, witness_seed=0, lc_terms=0):
+        """the same generator; witness_seed != 0: same R1CS, another satisfying witness; lc_terms >= 5: dense body (long
+        linear combinations folded through the d column: all 11 commitments of a proof are non-trivial; parity unpinned)"""
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        _check(lib().plk_circuit_synthetic_ex(ctypes.c_uint64(target_gates), ctypes.c_uint64(seed), ctypes.c_uint64(witness_seed),
+                                              ctypes.c_uint32(lc_terms), ctypes.byref(self._h)))
+        return self
+
     def export(self, what):
         """what = "r1cs" | "wtns": bytes in the reference's binary formats"""
         code = {"r1cs": 0, "wtns": 1}[what]
@@ -412,23 +428,25 @@ class SetupForProver:
         _check(lib().plk_setup_write_vk(self.ctx._h, self._h, bytes(g2_bytes), out, ctypes.c_uint64(len(out)), ctypes.byref(n)))
         return out.raw[:n.value]
 
-    def prove(self, circuit):
-        """proof.bin bytes (keccak transcript, monomial key — src/plonk.rs:152-159)"""
+    def prove(self, circuit, ctx=None):
+        """proof.bin bytes (keccak transcript, monomial key — src/plonk.rs:152-159).  `ctx`: another context on the same device
+        (one per host thread: several proofs of this setup may be in flight at once; ctypes releases the GIL for the call)"""
+        h = (ctx or self.ctx)._h
         cap = 1 << 16
         out = ctypes.create_string_buffer(cap)
         n = ctypes.c_uint64(0)
-        rc = lib().plk_prove(self.ctx._h, self._h, circuit._h, out, ctypes.c_uint64(cap), ctypes.byref(n))
+        rc = lib().plk_prove(h, self._h, circuit._h, out, ctypes.c_uint64(cap), ctypes.byref(n))
         if rc == 1 and n.value > cap:                                 # many public inputs: retry with the reported size
             cap = n.value
             out = ctypes.create_string_buffer(cap)
-            rc = lib().plk_prove(self.ctx._h, self._h, circuit._h, out, ctypes.c_uint64(cap), ctypes.byref(n))
+            rc = lib().plk_prove(h, self._h, circuit._h, out, ctypes.c_uint64(cap), ctypes.byref(n))
         _check(rc)
         return out.raw[:n.value]
 
-    def timings_ms(self):
+    def timings_ms(self, ctx=None):
         arr = (ctypes.c_double * 16)()
         cnt = ctypes.c_uint32(0)
-        _check(lib().plk_prove_timings(self.ctx._h, arr, ctypes.c_uint32(16), ctypes.byref(cnt)))
+        _check(lib().plk_prove_timings((ctx or self.ctx)._h, arr, ctypes.c_uint32(16), ctypes.byref(cnt)))
         names = ["witness", "round1", "round2", "round3", "round4", "round5", "serialise"]
         return {names[i] if i < len(names) else str(i): arr[i] for i in range(cnt.value)}
 

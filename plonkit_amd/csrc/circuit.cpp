@@ -606,36 +606,62 @@ struct Xoshiro256ss {
 }  // namespace
 }  // namespace plk
 
-static int32_t circuit_synthetic_impl(uint64_t target_gates, uint64_t seed, plk_circuit **out);
+static int32_t circuit_synthetic_impl(uint64_t target_gates, uint64_t seed, uint64_t witness_seed, uint32_t lc_terms, plk_circuit **out);
 extern "C" int32_t plk_circuit_synthetic(uint64_t target_gates, uint64_t seed, plk_circuit **out) {
     if (!out || target_gates < 4 || target_gates >= (1ull << 28)) { set_error("plk_circuit_synthetic: bad argument"); return PLK_ERR_ARG; }
     *out = nullptr;
-    return guarded("plk_circuit_synthetic", PLK_ERR_ARG, [&] { return circuit_synthetic_impl(target_gates, seed, out); });
+    return guarded("plk_circuit_synthetic", PLK_ERR_ARG, [&] { return circuit_synthetic_impl(target_gates, seed, 0, 0, out); });
 }
-static int32_t circuit_synthetic_impl(uint64_t target_gates, uint64_t seed, plk_circuit **out) {
+// The same generator with two more knobs:
+//   witness_seed != 0: the same R1CS (it depends on `seed` only) with ANOTHER satisfying witness — the free starting wires are
+//       drawn from `witness_seed` and the chain is re-walked: what a prover that serves many requests for one circuit sees.
+//   lc_terms >= 5 ("dense"): the body is made of constraints whose A side is a linear combination of `lc_terms` earlier wires
+//       plus a constant, (sum_j a_j w_{u-j} + k) * (cb * w_v) = cc * w_new — the shape of a circom Poseidon round (S-box input =
+//       MDS row of the previous state + round constant).  The transpiler folds such a combination through the d column
+//       (q_d_next = -1 chains, src/circom_circuit.rs:114-131), so the d wire, q_d_next and the fourth quotient chunk are all
+//       live: the prover does 11 non-trivial commitments instead of the 9 of the pinned-subset circuit.  PARITY UNPINNED: the
+//       chaining rule is a recollection of bellman's adaptor, equal in product and oracle, pinned by neither.
+//       1 + ceil((lc_terms - 3) / 3) + 1 gates per such constraint; the remainder to `target_gates` is filled with the
+//       one-gate pinned shape.  lc_terms = 0: the pinned-subset circuit of plk_circuit_synthetic.
+extern "C" int32_t plk_circuit_synthetic_ex(uint64_t target_gates, uint64_t seed, uint64_t witness_seed, uint32_t lc_terms, plk_circuit **out) {
+    if (!out || target_gates < 4 || target_gates >= (1ull << 28) || (lc_terms != 0 && (lc_terms < 5 || lc_terms > 64))) {
+        set_error("plk_circuit_synthetic_ex: bad argument (target_gates in [4, 2^28), lc_terms 0 or 5..64)"); return PLK_ERR_ARG; }
+    *out = nullptr;
+    return guarded("plk_circuit_synthetic_ex", PLK_ERR_ARG, [&] { return circuit_synthetic_impl(target_gates, seed, witness_seed, lc_terms, out); });
+}
+static int32_t circuit_synthetic_impl(uint64_t target_gates, uint64_t seed, uint64_t witness_seed, uint32_t lc_terms, plk_circuit **out) {
     std::unique_ptr<plk_circuit> holder(new plk_circuit());
     plk_circuit *c = holder.get();
     Xoshiro256ss rng(seed);
     big_vector<HFr> &w = c->witness;
-    w.reserve(target_gates + 8);
+    w.reserve(target_gates + 8 + lc_terms);
     w.push_back(HFr::one()); w.push_back(HFr::zero()); w.push_back(rng.fr()); w.push_back(rng.fr());
+    const uint32_t n_free = lc_terms ? lc_terms + 1 : 2;                // wires nothing constrains: private inputs of the chain
+    for (uint32_t i = 2; i < n_free; i++) w.push_back(rng.fr());
+    if (witness_seed) { Xoshiro256ss wr(witness_seed ^ 0x7769746e65737321ULL); for (uint32_t i = 0; i < n_free; i++) w[2 + i] = wr.fr(); }
     R1cs &R = c->r1cs;
     R.clear();
     R.terms.reserve(target_gates * 4); R.off.reserve(target_gates * 3 + 4);
     // Pass 1 draws every coefficient in the generator's order (the draws do not depend on the witness), pass 2 walks
     // the chain.  The divisions w = (...) / c are by those coefficients, so all of them are inverted together with
     // Montgomery's trick — one field inversion instead of one per constraint (4 s at 2^20 gates).
-    struct Draw { HFr ca, cb, kk, c1, cdiv; bool two; };
+    struct Draw { HFr ca, cb, kk, c1, cdiv; uint32_t kind; size_t lc0; };      // kind 0: one gate, 1: two gates, 2: dense
     std::vector<Draw> draws;
+    std::vector<HFr> lc_coeffs;                                           // lc_terms - 1 further A-side coefficients per dense constraint
     draws.reserve(target_gates);
     uint64_t gates = 0;
     const uint64_t body = target_gates - 1;                             // the last gate is the public-input tie
+    const uint64_t dense_gates = lc_terms ? 1 + (lc_terms + 1 - 4 + 2) / 3 + 1 : 0;
     while (gates < body) {
         Draw d;
         d.ca = rng.fr_nonzero(); d.cb = rng.fr_nonzero();
-        d.two = (draws.size() & 1) && (gates + 2 <= body);
-        if (!d.two) { d.cdiv = rng.fr_nonzero(); gates += 1; }
-        else { d.kk = rng.fr(); d.c1 = rng.fr_nonzero(); d.cdiv = rng.fr_nonzero(); gates += 2; }
+        if (lc_terms && gates + dense_gates <= body) {
+            d.kind = 2; d.lc0 = lc_coeffs.size();
+            for (uint32_t j = 1; j < lc_terms; j++) lc_coeffs.push_back(rng.fr_nonzero());
+            d.kk = rng.fr(); d.cdiv = rng.fr_nonzero(); gates += dense_gates;
+        } else if (!lc_terms && (draws.size() & 1) && (gates + 2 <= body)) {
+            d.kind = 1; d.kk = rng.fr(); d.c1 = rng.fr_nonzero(); d.cdiv = rng.fr_nonzero(); gates += 2;
+        } else { d.kind = 0; d.cdiv = rng.fr_nonzero(); gates += 1; }
         draws.push_back(d);
     }
     std::vector<HFr> inv_c(draws.size());
@@ -645,13 +671,26 @@ static int32_t circuit_synthetic_impl(uint64_t target_gates, uint64_t seed, plk_
         HFr run = acc.inv();
         for (size_t i = draws.size(); i-- > 0;) { HFr t = run * inv_c[i]; run = run * draws[i].cdiv; inv_c[i] = t; }
     }
+    std::vector<LcTerm> ka_long(lc_terms + 1);
     for (size_t i = 0; i < draws.size(); i++) {
         const Draw &d = draws[i];
         uint32_t u = (uint32_t)w.size() - 1, v = (uint32_t)w.size() - 2;
+        const LcTerm kb{v, d.cb};
+        if (d.kind == 2) {
+            // A = k + ca * w_u + sum_{j >= 1} a_j * w_{u - j}: distinct wires, the constant first (wire 0 is folded by the transpiler)
+            HFr a_val = d.kk + d.ca * w[u];
+            ka_long[0] = {0, d.kk}; ka_long[1] = {u, d.ca};
+            for (uint32_t j = 1; j < lc_terms; j++) { const HFr &a = lc_coeffs[d.lc0 + j - 1]; ka_long[1 + j] = {u - j, a}; a_val = a_val + a * w[u - j]; }
+            R.push_lc(ka_long.data(), lc_terms + 1); R.push_lc(&kb, 1);
+            w.push_back(a_val * d.cb * w[v] * inv_c[i]);
+            const LcTerm kc{(uint32_t)w.size() - 1, d.cdiv};
+            R.push_lc(&kc, 1);
+            continue;
+        }
         HFr prod = d.ca * w[u] * d.cb * w[v];
-        const LcTerm ka{u, d.ca}, kb{v, d.cb};
+        const LcTerm ka{u, d.ca};
         R.push_lc(&ka, 1); R.push_lc(&kb, 1);
-        if (!d.two) {
+        if (d.kind == 0) {
             w.push_back(prod * inv_c[i]);
             const LcTerm kc{(uint32_t)w.size() - 1, d.cdiv};
             R.push_lc(&kc, 1);

@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <mutex>
 #include "hostmath.h"
 
 #include <new>
@@ -132,6 +133,7 @@ struct plk_circuit {
     bool has_witness = false;
     mutable bool witness_registered = false;   // page-locked for fast upload (done by plk_prove from the second proof on)
     mutable uint32_t proofs_started = 0;
+    mutable std::mutex reg_mu;                 // the two fields above: one circuit object may be proved from two contexts / host threads at once
 };
 
 namespace plk {

@@ -2,6 +2,7 @@
 // Stands where bellman_ce's `Worker` stands in the reference (src/plonk.rs:41,47,183).
 #pragma once
 #include <utility>
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
@@ -39,12 +40,15 @@ struct PowTable {
     const uint32_t *hi_sliced = nullptr;     // optional: the hi table as 9 x 29-bit limbs, 48 B per entry (NTT stage twiddles)
 };
 
-// grows-only device buffer
+// grows-only device buffer.  `borrowed`: a view of another context's allocation (plk_ctx_share_srs) — never freed here,
+// never grown (reserve() beyond the capacity fails).
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool borrowed = false;
     int32_t reserve(size_t bytes);
     void release();
+    void borrow(const DevBuf &o) { release(); p = o.p; cap = o.cap; borrowed = o.p != nullptr; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -120,9 +124,21 @@ struct plk_ctx {
     void *comm = nullptr;                    // built-in communicator (plk_comm_init / _tcp, comm.cpp), or null
     std::vector<plk::host::HJac> commit_pieces;   // partial sums of a commitment longer than one MSM call (prover.hip)
     std::vector<plk::host::HJac> commit_done;     // finished commitments of a batch that is processed one at a time
+    // plk_ctx_share_srs: a context that proves beside another one on the same GPU borrows that one's resident key(s) and MSM
+    // fixed-base table(s) instead of holding a second copy.  The lender counts its borrowers and refuses to replace a key
+    // while one exists; a borrower drops the loan when it is given a key of its own or destroyed.
+    plk_ctx *srs_lender = nullptr;
+    std::atomic<int> srs_borrowers{0};
 };
 
 namespace plk {
+// every entry point that replaces a resident key goes through these two: the MSM table of the old key is void, and a table
+// (or key) that was only borrowed must not be written to when the next one is built
+int32_t srs_replace_guard(plk_ctx *c, const char *who);           // runtime.hip: PLK_ERR_ARG while another context borrows this one's key
+inline void srs_table_invalidate(plk_ctx *c) { c->srs_w_valid = false; if (c->srs_w.borrowed) c->srs_w.release(); }
+inline void lag_table_invalidate(plk_ctx *c) { c->lag.w_valid = false; if (c->lag.w.borrowed) c->lag.w.release(); }
+void srs_return_loan(plk_ctx *c);                                 // runtime.hip
+
 // makes the Lagrange key the context's active SRS for the lifetime of the guard (host-side pointer swap only;
 // kernels already enqueued keep the addresses they were launched with)
 struct SrsSlotSwap {

@@ -142,7 +142,7 @@ int32_t g1_intt_dev(plk_ctx *ctx, const G1Affine *in, uint32_t log_n, G1Affine *
     PLK_TRY(ctx->slot[0].c.reserve((size_t)n * sizeof(XyzzW)));
     XyzzW *pts = ctx->slot[0].c.as<XyzzW>();
     Fr n_inv = to_canonical(ctx->n_inv[log_n]);
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     if (!attr_set) {
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_load), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));

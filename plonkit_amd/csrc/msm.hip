@@ -897,7 +897,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     G1Xyzz *window_out = S.d.as<G1Xyzz>();
 
     PLK_HIP(hipMemsetAsync(hist, 0, total_bins * sizeof(uint32_t), stream));
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};                 // (several contexts may commit from several host threads)
     if (!attr_set) {
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_partition<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_recode_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -1167,6 +1167,29 @@ int32_t plk_srs_precompute(plk_ctx *ctx) {
         SrsSlotSwap active(ctx, true);
         PLK_TRY(ensure_base_table(ctx, table_copies_for(ctx->srs_n), ctx->stream));
     }
+    return PLK_OK;
+}
+
+// Two (or more) contexts proving side by side on ONE GPU — the latency-bound ends of one proof's commitments and its strict
+// challenge chain leave SIMD time that a second proof fills — need one resident key between them, not one each: `dst` borrows
+// `src`'s monomial key, its Lagrange-form key if there is one, and the MSM fixed-base tables of both (0.94 GiB and 40 ms per key
+// at 2^20 points), built here if `src` has not built them yet.  Read-only from then on, so commitments of both contexts may run
+// concurrently.  `src` keeps ownership: it refuses to replace a key while a borrower exists and must outlive its borrowers' use.
+int32_t plk_ctx_share_srs(plk_ctx *dst, plk_ctx *src) {
+    if (!dst || !src || dst == src) { set_error("plk_ctx_share_srs: bad argument"); return PLK_ERR_ARG; }
+    if (dst->device != src->device) { set_error("plk_ctx_share_srs: the two contexts are on different devices"); return PLK_ERR_ARG; }
+    if (src->srs_lender) { set_error("plk_ctx_share_srs: the source context itself borrows its key (share from the owner)"); return PLK_ERR_ARG; }
+    if (!src->srs) { set_error("plk_ctx_share_srs: the source context has no key resident"); return PLK_ERR_SRS; }
+    if (dst->msm_enq != dst->msm_fin) { set_error("plk_ctx_share_srs: a commitment is still in flight on the destination context"); return PLK_ERR_ARG; }
+    PLK_TRY(srs_replace_guard(dst, "plk_ctx_share_srs"));
+    PLK_TRY(plk_srs_precompute(src));                        // (synchronises src->stream: the tables are complete before anyone reads them)
+    dst->srs_own.release(); dst->lag.own.release();
+    dst->srs = src->srs; dst->srs_n = src->srs_n;
+    dst->srs_w.borrow(src->srs_w); dst->srs_w_valid = src->srs_w_valid; dst->srs_w_copies = src->srs_w_copies;
+    dst->lag.pts = src->lag.pts; dst->lag.n = src->lag.n;
+    dst->lag.w.borrow(src->lag.w); dst->lag.w_valid = src->lag.pts ? src->lag.w_valid : false; dst->lag.w_copies = src->lag.w_copies;
+    dst->srs_lender = src;
+    src->srs_borrowers.fetch_add(1);
     return PLK_OK;
 }
 

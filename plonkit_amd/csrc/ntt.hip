@@ -451,7 +451,7 @@ static int32_t ntt_direct_table(plk_ctx *ctx, bool inverse, uint32_t log_r, uint
 }
 
 // ------------------------------------------------------------------------------- driver
-static bool g_attr_set = false;
+static std::atomic<bool> g_attr_set{false};                    // (several contexts may transform from several host threads)
 
 // digits of the mixed-radix plan: up to 10 bits per pass
 static void digit_plan(uint32_t log_n, uint32_t d[4], uint32_t *passes) {

@@ -68,6 +68,9 @@ int32_t build_permutation_index(plk_ctx *ctx, const uint32_t *const vars[4], uin
 // the transpiler's temporaries on the device: values[first_tmp + i] = constant_i + sum_k coeff * values[var]  for the
 // linear forms recorded at setup (circuit.h: WitnessOp / WitnessTerm, uploaded as they are — 40-byte records)
 int32_t eval_witness_ops(Fr *values, const void *ops_dev, const void *terms_dev, uint32_t n_ops, uint32_t first_tmp, hipStream_t s);
+// the same when temporary i may read temporary i - 1 (the partial-sum chains of long linear combinations): one lane per run of such
+// temporaries, run_start = the index of every run's first temporary (ascending)
+int32_t eval_witness_runs(Fr *values, const void *ops_dev, const void *terms_dev, const void *run_start_dev, uint32_t n_runs, uint32_t n_ops, uint32_t first_tmp, hipStream_t s);
 int32_t perm_terms(const PermArgs &a, hipStream_t s);
 int32_t mul3(Fr *out, const Fr *a, const Fr *b, const Fr &sc, uint32_t n, hipStream_t s);
 // out may alias in.  mult: product scan, else sum; reverse: suffix; exclusive: shifted by one

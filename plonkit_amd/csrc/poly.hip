@@ -185,6 +185,36 @@ __global__ void __launch_bounds__(PT) k_eval_witness_ops(Fr *values, const DevWi
     }
     store_fp(values + first_tmp + i, acc);
 }
+// The temporaries of a long linear combination form a CHAIN (partial sums handed from gate to gate through d):
+// temporary i may read temporary i - 1 and nothing else that is not a circom wire.  One lane walks one such run from its head;
+// runs are independent of each other, so the whole table is still one launch (a 2^20-gate Poseidon-shaped circuit: 0.7 M
+// temporaries in runs of 1..20 — on the host this loop was 70 ms of every proof).
+__global__ void __launch_bounds__(PT) k_eval_witness_runs(Fr *values, const DevWitnessOp *ops, const DevWitnessTerm *terms, const uint32_t *run_start,
+                                                          uint32_t n_runs, uint32_t n_ops, uint32_t first_tmp) {
+    uint32_t r = blockIdx.x * PT + threadIdx.x;
+    if (r >= n_runs) return;
+    const uint32_t lo = run_start[r], hi = r + 1 < n_runs ? run_start[r + 1] : n_ops;
+    Fr prev; for (int k = 0; k < 8; k++) prev.l[k] = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t first = ops[i].first, count = ops[i].count;
+        Fr acc = fr_of(ops[i].constant);
+        for (uint32_t k = 0; k < count; k++) {
+            const uint32_t var = terms[first + k].var;
+            if (!var) continue;                                                       // id 0 is the dummy (zero)
+            const Fr v = (i > lo && var == first_tmp + i - 1) ? prev : load_fp(values + var);
+            acc = add(acc, mul(fr_of(terms[first + k].coeff), v));
+        }
+        store_fp(values + first_tmp + i, acc);
+        prev = acc;
+    }
+}
+int32_t eval_witness_runs(Fr *values, const void *ops_dev, const void *terms_dev, const void *run_start_dev, uint32_t n_runs, uint32_t n_ops, uint32_t first_tmp, hipStream_t s) {
+    if (!n_ops) return PLK_OK;
+    hipLaunchKernelGGL(k_eval_witness_runs, dim3((n_runs + PT - 1) / PT), dim3(PT), 0, s, values, (const DevWitnessOp *)ops_dev, (const DevWitnessTerm *)terms_dev,
+                       (const uint32_t *)run_start_dev, n_runs, n_ops, first_tmp);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
 int32_t eval_witness_ops(Fr *values, const void *ops_dev, const void *terms_dev, uint32_t n_ops, uint32_t first_tmp, hipStream_t s) {
     if (!n_ops) return PLK_OK;
     hipLaunchKernelGGL(k_eval_witness_ops, dim3((n_ops + PT - 1) / PT), dim3(PT), 0, s, values, (const DevWitnessOp *)ops_dev, (const DevWitnessTerm *)terms_dev, n_ops, first_tmp);

@@ -22,6 +22,7 @@
 #include <chrono>
 #include <memory>
 #include <thread>
+#include <mutex>
 #include <algorithm>
 #include <cstring>
 
@@ -181,10 +182,15 @@ struct plk_setup {
     mutable bool zh_inv_ready = false;
     mutable plk::HFr zh_inv[4];
     mutable plk::HFr icoset_c[5];            // i^-1 (i = omega_4) and 7^(-N c) / 4, c = 0..3: constants of the coset iNTT's combine step
+    mutable std::mutex lazy_mu;              // the cached extensions and constants above are filled by the FIRST proof: one setup may be
+                                             // proved from several contexts / host threads at once (SetupForProver::prove takes &self)
     uint64_t num_circuit_vars = 0;         // circom wires; temporaries follow
     std::vector<plk::WitnessOp> ops;       // linear forms defining the transpiler's temporaries
     bool ops_independent = false;          // no temporary reads another temporary -> order-free evaluation
-    plk::DevBuf ops_dev, terms_dev;        // the same records on the device (only when ops_independent): evaluated there
+    bool ops_chained = false;              // a temporary reads at most its immediate predecessor (partial-sum chains of long linear
+                                           // combinations): evaluated on the device run by run (run_start = first temporary of every run)
+    std::vector<uint32_t> run_start;
+    plk::DevBuf ops_dev, terms_dev, runs_dev;   // the records on the device (when ops_independent or ops_chained): evaluated there
     std::vector<plk::WitnessTerm> op_terms;
     plk::big_vector<plk::HFr> h_cols;      // host phase only: 7 selector columns x N, until plk_setup_upload
     plk::big_vector<uint32_t> h_vars;      // host phase only: 4 variable-index columns x N
@@ -199,7 +205,7 @@ void plk_circuit_unregister(plk_circuit *c) {
 extern "C" {
 
 uint64_t plk_setup_domain_size(const plk_setup *s) { return s ? s->N : 0; }
-void plk_setup_free(plk_setup *s) { if (s) { s->store.release(); s->lde_store.release(); s->ops_dev.release(); s->terms_dev.release(); delete s; } }
+void plk_setup_free(plk_setup *s) { if (s) { s->store.release(); s->lde_store.release(); s->ops_dev.release(); s->terms_dev.release(); s->runs_dev.release(); delete s; } }
 
 // SetupForProver::prepare_setup_for_prover in two phases, so that a host program can run the first one (pure CPU:
 // transpile, selector / variable-index columns) while the GPU side of its start-up is still under way on another thread
@@ -227,6 +233,22 @@ static int32_t setup_host_impl(const plk_circuit *c, plk_setup **out) {
     S->ops.swap(T.ops); S->op_terms.swap(T.op_terms);
     S->ops_independent = true;
     for (const WitnessTerm &t : S->op_terms) if (t.var >= c->r1cs.num_variables) { S->ops_independent = false; break; }
+    if (!S->ops_independent) {
+        // long linear combinations: temporary i (a partial sum) reads temporary i - 1 and circom wires only -> runs
+        const uint64_t ncv0 = c->r1cs.num_variables;
+        S->ops_chained = true;
+        for (size_t i = 0; i < S->ops.size() && S->ops_chained; i++) {
+            bool continues = false;
+            for (uint32_t k = 0; k < S->ops[i].count; k++) {
+                const uint32_t v = S->op_terms[S->ops[i].first + k].var;
+                if (v < ncv0) continue;
+                if (i > 0 && v == ncv0 + i - 1) continues = true;
+                else { S->ops_chained = false; break; }
+            }
+            if (!continues) S->run_start.push_back((uint32_t)i);
+        }
+        if (!S->ops_chained) std::vector<uint32_t>().swap(S->run_start);
+    }
     // rows of the trace: one gate per public input first (q_a = -1), then the transpiler's gates, then padding with the dummy
     // variable.  The gate pieces are read once, piece-parallel, straight into the seven selector columns and the four
     // variable-index columns.
@@ -273,9 +295,14 @@ static int32_t setup_upload_impl(plk_ctx *ctx, plk_setup *S) {
     const uint64_t N = S->N; const uint32_t log_n = S->log_n;
     static_assert(sizeof(WitnessOp) == 40 && sizeof(WitnessTerm) == 40, "records are uploaded as they are (poly.hip)");
     hipStream_t st = ctx->stream;
-    auto fail = [&](int32_t code) { S->store.release(); S->ops_dev.release(); S->terms_dev.release(); return code; };
+    auto fail = [&](int32_t code) { S->store.release(); S->ops_dev.release(); S->terms_dev.release(); S->runs_dev.release(); return code; };
     int32_t rc;
-    if (S->ops_independent && !S->ops.empty()) {                     // temporaries will be evaluated on the device
+    if (S->ops_chained && !S->ops.empty()) {
+        if ((rc = S->runs_dev.reserve(S->run_start.size() * sizeof(uint32_t))) != PLK_OK) return fail(rc);
+        if (hipMemcpyAsync(S->runs_dev.p, S->run_start.data(), S->run_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess)
+            return fail(hip_fail(hipGetLastError(), "H2D witness runs", __FILE__, __LINE__));
+    }
+    if ((S->ops_independent || S->ops_chained) && !S->ops.empty()) {                     // temporaries will be evaluated on the device
         if ((rc = S->ops_dev.reserve(S->ops.size() * sizeof(WitnessOp))) != PLK_OK) return fail(rc);
         if ((rc = S->terms_dev.reserve(S->op_terms.size() * sizeof(WitnessTerm) + 8)) != PLK_OK) return fail(rc);
         if (hipMemcpyAsync(S->ops_dev.p, S->ops.data(), S->ops.size() * sizeof(WitnessOp), hipMemcpyHostToDevice, st) != hipSuccess ||
@@ -402,11 +429,15 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     // un-pinning when the process ends: worth it from the second proof of the same circuit object on, not for the
     // one-proof-per-process pattern of the CLI (profiles/r02_cli_scale.txt: 0.36 -> 0.29 s whole `plonkit prove`)
     static const int reg_mode = [] { const char *e = getenv("PLK_HOST_REGISTER"); return !e ? 1 : (!strcmp(e, "always") ? 0 : (!strcmp(e, "never") ? 1 << 30 : 1)); }();
-    if (!c->witness_registered && (int)(c->proofs_started++) >= reg_mode) {
-        if (hipHostRegister((void *)c->witness.data(), c->witness.size() * sizeof(HFr), hipHostRegisterDefault) == hipSuccess) c->witness_registered = true;
-        else (void)hipGetLastError();                                        // not fatal: the copy is just slower
+    {
+        std::lock_guard<std::mutex> reg_lock(c->reg_mu);
+        if (!c->witness_registered && (int)(c->proofs_started++) >= reg_mode) {
+            if (hipHostRegister((void *)c->witness.data(), c->witness.size() * sizeof(HFr), hipHostRegisterDefault) == hipSuccess) c->witness_registered = true;
+            else (void)hipGetLastError();                                    // not fatal: the copy is just slower
+        }
     }
-    const bool tmp_on_device = S->ops_independent && (S->ops_dev.p || S->ops.empty());
+    static const bool tmp_host_env = [] { const char *e = getenv("PLK_WITNESS_TMP_HOST"); return e && e[0] == '1'; }();      // tests: the host loop
+    const bool tmp_on_device = !tmp_host_env && (S->ops_independent || S->ops_chained) && (S->ops_dev.p || S->ops.empty());
     PLK_TRY(ensure_pinned2(ctx, (tmp_on_device ? 1 : n_tmp + 1) * sizeof(HFr)));
     HFr *tmp_vals = reinterpret_cast<HFr *>(ctx->pinned2);
     const HFr *wit = c->witness.data();
@@ -459,7 +490,9 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     uint32_t *d_flag = A.take<uint32_t>(64);
     PLK_HIP(hipMemcpyAsync(d_values, wit, ncv * sizeof(Fr), hipMemcpyHostToDevice, st));
     PLK_HIP(hipMemsetAsync(d_values, 0, sizeof(Fr), st));
-    if (n_tmp && tmp_on_device) PLK_TRY(eval_witness_ops(d_values, S->ops_dev.p, S->terms_dev.p, (uint32_t)S->ops.size(), (uint32_t)ncv, st));
+    if (n_tmp && tmp_on_device && S->ops_chained)
+        PLK_TRY(eval_witness_runs(d_values, S->ops_dev.p, S->terms_dev.p, S->runs_dev.p, (uint32_t)S->run_start.size(), (uint32_t)S->ops.size(), (uint32_t)ncv, st));
+    else if (n_tmp && tmp_on_device) PLK_TRY(eval_witness_ops(d_values, S->ops_dev.p, S->terms_dev.p, (uint32_t)S->ops.size(), (uint32_t)ncv, st));
     else if (n_tmp) PLK_HIP(hipMemcpyAsync(d_values + ncv, tmp_vals, n_tmp * sizeof(Fr), hipMemcpyHostToDevice, st));
     std::vector<HFr> inputs(wit + 1, wit + 1 + S->num_inputs);
     {   // is_satisfied_using_one_shot_check (src/plonk.rs:137) on the device
@@ -585,6 +618,7 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     // ---- round 3: quotient on the coset 7*<omega_4N>: 18 x LDE, fused point-wise kernel, coset iNTT(4N)
     const HFr coset = HFr::from_u64(7);
     {
+        std::unique_lock<std::mutex> lazy_lock(S->lazy_mu);
         if (!S->lde_ready) {
             // the coset-point vector is a convenience (one load instead of two loads and two products per point):
             // above 2^24 gates its 4N * 32 bytes are better spent elsewhere (2^26 would not fit in 288 GB)
@@ -639,6 +673,7 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
             for (int c = 1; c < 4; c++) S->icoset_c[1 + c] = S->icoset_c[c] * gN_inv;
             S->zh_inv_ready = true;
         }
+        lazy_lock.unlock();
         for (int k = 0; k < 4; k++) qa.zh_inv_w[k] = to_dev(S->zh_inv[k] * two5);
         qa.m = (uint32_t)M; qa.log_m = log_m;
         if (use_bg) PLK_HIP(hipStreamWaitEvent(st, ctx->bg_done, 0));      // the five extensions (+ PI) of the background stream

@@ -27,6 +27,7 @@ int32_t hip_fail(hipError_t e, const char *what, const char *file, int line) {
 
 int32_t DevBuf::reserve(size_t bytes) {
     if (bytes <= cap) return PLK_OK;
+    if (borrowed) { set_error("a buffer borrowed from another context (plk_ctx_share_srs) cannot grow"); return PLK_ERR_ARG; }
     if (p) { PLK_HIP(hipFree(p)); p = nullptr; cap = 0; }
     size_t slack = bytes >> 3;                    // a little slack so that growth is rare ...
     if (slack > ((size_t)64 << 20)) slack = (size_t)64 << 20;     // ... but never 12 % of a 100 GB workspace (2^26 domains)
@@ -37,9 +38,10 @@ int32_t DevBuf::reserve(size_t bytes) {
 }
 
 void DevBuf::release() {
-    if (p) (void)hipFree(p);
+    if (p && !borrowed) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+    borrowed = false;
 }
 
 int32_t ensure_pinned(plk_ctx *ctx, size_t bytes) {
@@ -59,6 +61,23 @@ int32_t ensure_pinned2(plk_ctx *ctx, size_t bytes) {
     PLK_HIP(hipHostMalloc(&ctx->pinned2, want, hipHostMallocDefault));
     ctx->pinned2_cap = want;
     return PLK_OK;
+}
+
+// a context whose key is on loan must keep it: the borrowers' commitments read it (and its MSM table) at any time
+int32_t srs_replace_guard(plk_ctx *c, const char *who) {
+    if (c->srs_borrowers.load() > 0) {
+        set_error(std::string(who) + ": this context's key is shared with another context (plk_ctx_share_srs) — destroy the borrowers first");
+        return PLK_ERR_ARG;
+    }
+    srs_return_loan(c);                                  // a borrower that gets a key of its own stops borrowing
+    return PLK_OK;
+}
+void srs_return_loan(plk_ctx *c) {
+    if (!c->srs_lender) return;
+    c->srs_lender->srs_borrowers.fetch_sub(1);
+    c->srs_lender = nullptr;
+    c->srs = nullptr; c->srs_n = 0; c->srs_w.release(); c->srs_w_valid = false; c->srs_w_copies = 0;
+    c->lag.pts = nullptr; c->lag.n = 0; c->lag.w.release(); c->lag.w_valid = false; c->lag.w_copies = 0;
 }
 
 }  // namespace plk
@@ -114,6 +133,7 @@ void plk_destroy(plk_ctx *ctx) {
     for (auto &S : ctx->slot) if (S.stream) (void)hipStreamSynchronize(S.stream);     // commitments still in flight
     if (ctx->bg_stream) (void)hipStreamSynchronize(ctx->bg_stream);
     comm_release(ctx);
+    srs_return_loan(ctx);
     for (void *p : ctx->coset_allocs) (void)hipFree(p);
     for (auto &kv : ctx->ntt_direct) (void)hipFree(kv.second);
     ctx->tables.release(); ctx->ntt_scratch[0].release(); ctx->ntt_scratch[1].release(); ctx->srs_own.release(); ctx->srs_w.release(); ctx->lag.own.release(); ctx->lag.w.release();
@@ -146,21 +166,23 @@ int32_t plk_synchronize(plk_ctx *ctx) {
 // ------------------------------------------------------------------------------------ SRS
 int32_t plk_srs_upload(plk_ctx *ctx, const plk_g1_affine *bases, uint64_t n) {
     if (!ctx || !bases || n == 0) { set_error("plk_srs_upload: bad argument"); return PLK_ERR_ARG; }
+    PLK_TRY(srs_replace_guard(ctx, "plk_srs_upload"));
     PLK_HIP(hipSetDevice(ctx->device));
     PLK_TRY(ctx->srs_own.reserve(n * sizeof(plk_g1_affine)));
     PLK_HIP(hipMemcpyAsync(ctx->srs_own.p, bases, n * sizeof(plk_g1_affine), hipMemcpyHostToDevice, ctx->stream));
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->srs = ctx->srs_own.p;
     ctx->srs_n = n;
-    ctx->srs_w_valid = false;
+    srs_table_invalidate(ctx);
     return PLK_OK;
 }
 
 int32_t plk_srs_set_dev(plk_ctx *ctx, const void *bases_dev, uint64_t n) {
     if (!ctx || !bases_dev || n == 0) { set_error("plk_srs_set_dev: bad argument"); return PLK_ERR_ARG; }
+    PLK_TRY(srs_replace_guard(ctx, "plk_srs_set_dev"));
     ctx->srs = bases_dev;
     ctx->srs_n = n;
-    ctx->srs_w_valid = false;
+    srs_table_invalidate(ctx);
     return PLK_OK;
 }
 
@@ -177,21 +199,24 @@ int32_t plk_set_commit_shard(plk_ctx *ctx, uint64_t first_index, plk_combine_fn 
 // Lagrange-form key (Crs<E, CrsForLagrangeForm>): second resident SRS, see include/plonkit_amd.h
 int32_t plk_srs_lagrange_upload(plk_ctx *ctx, const plk_g1_affine *bases, uint64_t n) {
     if (!ctx || !bases || n == 0) { set_error("plk_srs_lagrange_upload: bad argument"); return PLK_ERR_ARG; }
+    PLK_TRY(srs_replace_guard(ctx, "plk_srs_lagrange_upload"));
     PLK_HIP(hipSetDevice(ctx->device));
     PLK_TRY(ctx->lag.own.reserve(n * sizeof(plk_g1_affine)));
     PLK_HIP(hipMemcpyAsync(ctx->lag.own.p, bases, n * sizeof(plk_g1_affine), hipMemcpyHostToDevice, ctx->stream));
     PLK_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->lag.pts = ctx->lag.own.p; ctx->lag.n = n; ctx->lag.w_valid = false;
+    ctx->lag.pts = ctx->lag.own.p; ctx->lag.n = n; lag_table_invalidate(ctx);
     return PLK_OK;
 }
 int32_t plk_srs_lagrange_set_dev(plk_ctx *ctx, const void *bases_dev, uint64_t n) {
     if (!ctx || !bases_dev || n == 0) { set_error("plk_srs_lagrange_set_dev: bad argument"); return PLK_ERR_ARG; }
-    ctx->lag.pts = bases_dev; ctx->lag.n = n; ctx->lag.w_valid = false;
+    PLK_TRY(srs_replace_guard(ctx, "plk_srs_lagrange_set_dev"));
+    ctx->lag.pts = bases_dev; ctx->lag.n = n; lag_table_invalidate(ctx);
     return PLK_OK;
 }
 int32_t plk_srs_lagrange_clear(plk_ctx *ctx) {
     if (!ctx) { set_error("plk_srs_lagrange_clear: bad argument"); return PLK_ERR_ARG; }
-    ctx->lag.pts = nullptr; ctx->lag.n = 0; ctx->lag.w_valid = false;
+    PLK_TRY(srs_replace_guard(ctx, "plk_srs_lagrange_clear"));
+    ctx->lag.pts = nullptr; ctx->lag.n = 0; lag_table_invalidate(ctx);
     return PLK_OK;
 }
 uint64_t plk_srs_lagrange_size(const plk_ctx *ctx) { return ctx ? ctx->lag.n : 0; }

@@ -63,6 +63,7 @@ using namespace plk;
 // the same for an arbitrary tau given as a field element (Montgomery, as everywhere at this boundary)
 extern "C" int32_t plk_srs_generate_fr(plk_ctx *ctx, uint64_t n, uint64_t start, const plk_fr *tau) {
     if (!ctx || n == 0 || !tau) { set_error("plk_srs_generate_fr: bad argument"); return PLK_ERR_ARG; }
+    PLK_TRY(srs_replace_guard(ctx, "plk_srs_generate_fr"));
     PLK_HIP(hipSetDevice(ctx->device));
     PLK_TRY(ctx->srs_own.reserve(n * sizeof(G1Affine)));
     Fr t; memcpy(t.l, tau->l, 32);
@@ -71,13 +72,14 @@ extern "C" int32_t plk_srs_generate_fr(plk_ctx *ctx, uint64_t n, uint64_t start,
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->srs = ctx->srs_own.p;
     ctx->srs_n = n;
-    ctx->srs_w_valid = false;
+    srs_table_invalidate(ctx);
     return PLK_OK;
 }
 
 // Fills the context's resident SRS with tau^(start+i) * G, i < n, tau a small integer (42 for crs_42).
 extern "C" int32_t plk_srs_generate(plk_ctx *ctx, uint64_t n, uint64_t start, uint32_t tau) {
     if (!ctx || n == 0 || tau < 2) { set_error("plk_srs_generate: bad argument"); return PLK_ERR_ARG; }
+    PLK_TRY(srs_replace_guard(ctx, "plk_srs_generate"));
     PLK_HIP(hipSetDevice(ctx->device));
     PLK_TRY(ctx->srs_own.reserve(n * sizeof(G1Affine)));
     uint64_t threads = (n + SRS_RUN - 1) / SRS_RUN;
@@ -87,7 +89,7 @@ extern "C" int32_t plk_srs_generate(plk_ctx *ctx, uint64_t n, uint64_t start, ui
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->srs = ctx->srs_own.p;
     ctx->srs_n = n;
-    ctx->srs_w_valid = false;
+    srs_table_invalidate(ctx);
     return PLK_OK;
 }
 

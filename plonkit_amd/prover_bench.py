@@ -27,6 +27,124 @@ def cold(device, log_n, circ):
                    "rounds_ms": {k: round(v, 2) for k, v in phases.items()}}
 
 
+def nonempty_commitments(proof):
+    """how many of the 11 commitments of a proof.bin (4 wires, z, 4 quotient chunks, 2 openings: SURVEY.md A.1) are not the
+    point at infinity — the all-zero vector commits to infinity, written as 0x40 00.. (or all zeros)"""
+    n_in = int.from_bytes(proof[8:16], "big")
+    off = 16 + 32 * n_in
+    pts = []
+    off += 8
+    pts += [proof[off + 64 * k: off + 64 * (k + 1)] for k in range(4)]; off += 256
+    pts.append(proof[off: off + 64]); off += 64
+    off += 8
+    pts += [proof[off + 64 * k: off + 64 * (k + 1)] for k in range(4)]
+    pts += [proof[-128:-64], proof[-64:]]
+    return sum(1 for p in pts if any(p[1:]) or p[0] not in (0, 0x40))
+
+
+def throughput(ctx, log_n, in_flight=2, proofs_each=10, lc_terms=0, setup=None, circs=None):
+    """prove THROUGHPUT on one GPU: `in_flight` host threads, one context each on the same device (the extra ones borrow
+    ctx's key and MSM table: plk_ctx_share_srs), ONE shared setup, every thread proving its own witness of the circuit
+    `proofs_each` times back to back.  A proof's challenge chain is strict, so ~3.5 ms of a 2^20 proof is latency-bound or
+    idle; a second proof in flight fills it.  Every proof must equal, byte for byte, the proof of the same witness made
+    alone on `ctx` before.  Returns proofs/s and ms per proof next to the sequential figures of the same run."""
+    import threading
+    n_gates = (1 << log_n) - 2
+    own_circs = circs is None
+    if own_circs:
+        circs = [_lib.Circuit.synthetic_ex(n_gates, witness_seed=(0 if k == 0 else 1000 + k), lc_terms=lc_terms) for k in range(in_flight)]
+    own_setup = setup is None
+    if own_setup:
+        setup = _lib.SetupForProver(ctx, circs[0])
+    ctxs = [ctx]
+    for _ in range(in_flight - 1):
+        c2 = _lib.Context(ctx.device)
+        c2.share_srs_from(ctx)
+        ctxs.append(c2)
+    # reference proofs, made one at a time on the first context (also the warm-up of that context)
+    want = [setup.prove(c) for c in circs]
+    assert len(set(want)) == len(want), "different witnesses must give different proofs"
+    for k in range(1, in_flight):                                   # warm-up of the other contexts (workspaces, twiddle tables)
+        assert setup.prove(circs[k], ctx=ctxs[k]) == want[k]
+    # sequential: the same number of proofs one after the other on one context
+    total = in_flight * proofs_each
+    t0 = time.perf_counter()
+    for i in range(total):
+        p = setup.prove(circs[i % in_flight])
+        assert p == want[i % in_flight]
+    seq_s = time.perf_counter() - t0
+    # concurrent
+    lat = [[] for _ in range(in_flight)]
+    bad = []
+    gate = threading.Barrier(in_flight + 1)
+
+    def worker(k):
+        gate.wait()
+        for _ in range(proofs_each):
+            t = time.perf_counter()
+            try:
+                p = setup.prove(circs[k], ctx=ctxs[k])
+            except Exception as exc:                                 # noqa: BLE001
+                bad.append(repr(exc)); return
+            lat[k].append(time.perf_counter() - t)
+            if p != want[k]:
+                bad.append("thread %d: proof differs from the sequential one" % k)
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(in_flight)]
+    for t in th:
+        t.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    par_s = time.perf_counter() - t0
+    for c2 in ctxs[1:]:
+        c2.close()
+    if own_setup:
+        setup.close()
+    if own_circs:
+        for c in circs:
+            c.close()
+    if bad:
+        raise RuntimeError("concurrent proving failed: " + "; ".join(bad[:3]))
+    all_lat = sorted(x for l in lat for x in l)
+    return {"in_flight": in_flight, "proofs": total, "proofs_per_s": round(total / par_s, 2), "ms_per_proof": round(par_s / total * 1e3, 3),
+            "latency_ms_median": round(all_lat[len(all_lat) // 2] * 1e3, 3), "latency_ms_max": round(all_lat[-1] * 1e3, 3),
+            "sequential": {"proofs_per_s": round(total / seq_s, 2), "ms_per_proof": round(seq_s / total * 1e3, 3)},
+            "speedup_vs_sequential": round(seq_s / par_s, 3), "byte_identical_to_sequential": True, "domain": 1 << log_n,
+            "what": "%d host threads x %d proofs, one context per thread on one GPU (key and MSM table shared: plk_ctx_share_srs), one shared setup, "
+                    "a different witness per thread; sequential = the same %d proofs one after the other on one context in the same run"
+                    % (in_flight, proofs_each, total)}
+
+
+def run_dense(ctx, log_n, lc_terms=7, reps=6):
+    """a proof that does ALL of the prover's work: circom-Poseidon-shaped constraints (A side = linear combination of
+    `lc_terms` wires + constant) that the transpiler folds through the d column with q_d_next = -1 — d, q_d_next and the
+    fourth quotient chunk are live, 11 of 11 commitments non-trivial.  PARITY UNPINNED for the chaining rule."""
+    circ = _lib.Circuit.synthetic_ex((1 << log_n) - 2, lc_terms=lc_terms)
+    setup = _lib.SetupForProver(ctx, circ)
+    assert setup.domain_size == 1 << log_n
+    proof = setup.prove(circ)
+    runs = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        p = setup.prove(circ)
+        dt = time.perf_counter() - t0
+        assert p == proof
+        runs.append((dt, setup.timings_ms()))
+    runs.sort(key=lambda r: r[0])
+    best, phases = runs[len(runs) // 2]
+    vk = setup.verification_key_bytes(_lib.crs42_g2_bytes())
+    ok = _lib.verify(vk, proof)
+    bad = bytearray(proof); bad[-200] ^= 1                             # an evaluation
+    rejected = not _lib.verify(vk, bytes(bad))
+    setup.close(); circ.close()
+    return {"wall_s": round(best, 4), "wall_s_min": round(runs[0][0], 4), "proves_timed": reps, "domain": 1 << log_n, "lc_terms": lc_terms,
+            "commitments_nonempty": nonempty_commitments(proof), "rounds_ms": {k: round(v, 2) for k, v in phases.items()},
+            "verified": bool(ok), "tampered_rejected": bool(rejected), "parity": "unpinned",
+            "what": "synthetic circuit whose constraints carry %d-term linear combinations (Poseidon-round shape): folded through the d column, "
+                    "so the d wire, q_d_next and t_3 are live; verified by the host verifier (real pairing) in the same run" % lc_terms}
+
+
 def run(ctx, log_n, reps=10):
     t0 = time.perf_counter()
     circ = _lib.Circuit.synthetic((1 << log_n) - 2)
@@ -50,6 +168,7 @@ def run(ctx, log_n, reps=10):
     gpu_ms = sum(v for k, v in phases.items() if k.startswith("round"))
     assert cold_proof == proof
     return {"wall_s": round(best, 4), "wall_s_min": round(runs[0][0], 4), "wall_s_max": round(runs[-1][0], 4), "proves_timed": reps,
+            "commitments_nonempty": nonempty_commitments(proof),
             "cold": cold_info, "domain": 1 << log_n, "proof_bytes": len(proof),
             "rounds_ms": {k: round(v, 2) for k, v in phases.items()},
             "gpu_rounds_s": round(gpu_ms / 1e3, 4),

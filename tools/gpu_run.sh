@@ -8,6 +8,7 @@
 #   bench[:<args>]          python bench.py <args> (default: the driver's --gpus 1 --steps 20 --warmup 5)
 #   prof-solo | prof-pipe   rocprofv3 --kernel-trace --stats of `bench.py --msm-only` with one / three commitments in flight
 #   prof-prove[:<log_n>]    rocprofv3 --kernel-trace --stats of tools/prove_probe.py <log_n> 6
+#   prof-py:<name>=<script and args>   rocprofv3 --kernel-trace --stats of `python <script and args>`; summary <name>_kernel_stats.csv
 #   pmc:<COUNTER>           one rocprofv3 --pmc pass (kernel trace only) of `bench.py --msm-only --pipeline-depth 1`
 #   fuzz | soak             tools/msm_fuzz.py + tools/prove_fuzz.py | tools/soak.py
 #   py:<script and args>    python <script and args>  (probes under tools/)
@@ -39,6 +40,7 @@ for st in "$@"; do
     prof-solo) prof solo python bench.py --msm-only --pipeline-depth 1 --steps 20 --warmup 5 ;;
     prof-pipe) prof pipe python bench.py --msm-only --steps 20 --warmup 5 ;;
     prof-prove) prof prove python tools/prove_probe.py ${arg:-20} 6 ;;
+    prof-py) prof "${arg%%=*}" python ${arg#*=} ;;
     pmc) timeout 600 rocprofv3 --kernel-trace --pmc $arg -d "$O/pmc_$arg" -o pmc --output-format csv -- python bench.py --msm-only --pipeline-depth 1 --steps 10 --warmup 2 > "$O/pmc_$arg.log" 2>&1; ls "$O/pmc_$arg" | head ;;
     fuzz) timeout 600 python tools/msm_fuzz.py 120 5 2>&1 | tail -2 | tee "$O/fuzz.txt"; timeout 600 python tools/prove_fuzz.py 40 9 2>&1 | tail -2 | tee -a "$O/fuzz.txt" ;;
     soak) timeout 600 python tools/soak.py 2>&1 | tail -3 | tee "$O/soak.txt" ;;
