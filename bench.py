@@ -39,6 +39,10 @@ import time
 # the library keeps up to three commitments in flight on three streams; with HIP's default of 4 hardware queues per device
 # those streams can land on one queue and serialise (measured: 2.04 ms per commitment instead of 1.66 ms)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# dmabuf IPC: on this driver RCCL (and any device-memory sharing) across processes fails with `hipIpcGetMemHandle: invalid argument`
+# unless this is set BEFORE the first HIP call of every rank — whoever launched us (this script's own spawn_ranks, the driver's
+# torch.distributed.run, a batch system): set it here, not only in the spawner
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
@@ -85,33 +89,42 @@ def rand_scalars(n, seed, device):
 
 
 # ------------------------------------------------------------------------------------------ CPU baselines
+CPU_BEST = {"split": "chunks", "threads": 16}          # filled by cpu_msm_baseline: the fastest (work split, thread count) of the port on this host
+
+
 def cpu_msm_baseline(ctx, log_sample, seed):
-    """bellman dense_multiexp restatement (oracle/, kind "port") on the host cores, bounded sample"""
+    """bellman dense_multiexp restatement (oracle/, kind "port") on the host cores, bounded sample.  SURVEY.md §8(d) says
+    "all host cores": the port is timed at 16 / 64 / 128 / every logical core in two work splits — "chunks" = bellman 0.3.2's
+    own (each thread owns 2^c - 1 buckets per window and folds them whatever its share of the terms: 2 * 16383 full additions
+    per thread per window at 2^20, which outweighs the useful work from ~32 threads up — that is the algorithm, not this
+    file), and "windows" = one task per (window, chunk) with thread-local, first-touched buckets, as later bellman revisions
+    split the work, which is what a 256-thread host needs.  The fastest of all of them is the baseline."""
     from oracle import oracle_lib as ol          # checker / baseline only — never on the product path
     m = 1 << log_sample
     bases = ctx.srs_download(0, m)
     rng = np.random.default_rng(seed)
     s = rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64)
     s[:, 3] &= np.uint64((1 << 60) - 1)
-    # the restatement keeps bellman's per-thread bucket arrays (each thread owns 2^c - 1 Jacobian buckets and sums them
-    # once per window), so its reduction cost grows with the thread count: on the 256-core GPU host 16 threads is the
-    # fastest setting (profiles/r01_cpu_msm_threads.txt: 1.49 M/s at 16, 0.06 at 256).  Both are timed and the better
-    # one is the baseline.
     ncpu = os.cpu_count() or 1
     ol.msm(bases[:1024], s[:1024], threads=min(ncpu, 16))     # warm the library
+    counts = sorted({min(ncpu, 16), min(ncpu, 64), min(ncpu, 128), ncpu})
     best = None
-    tried = {}
-    for cores in sorted({min(ncpu, 16), min(ncpu, 64)}):
-        t0 = time.perf_counter()
-        ref = ol.msm(bases, s, threads=cores)
-        dt = time.perf_counter() - t0
-        tried[str(cores)] = round(m / dt / 1e6, 3)
-        if best is None or dt < best[0]:
-            best = (dt, cores, ref)
-    dt, cores, ref = best
-    return {"value": m / dt / 1e6, "unit": "Mscalar·mul/s", "cores": cores, "kind": "port", "host_cores": ncpu,
+    tried = {"chunks": {}, "windows": {}}
+    for split in ("windows", "chunks"):
+        for cores in counts:
+            if split == "chunks" and cores > 64 and best and best[0] < 2.0:
+                continue                                   # (bellman 0.3.2's split beyond 64 threads: seconds per call, measured in profiles/, never the best)
+            t0 = time.perf_counter()
+            ref = ol.msm(bases, s, threads=cores, split=split)
+            dt = time.perf_counter() - t0
+            tried[split][str(cores)] = round(m / dt / 1e6, 3)
+            if best is None or dt < best[0]:
+                best = (dt, cores, ref, split)
+    dt, cores, ref, split = best
+    CPU_BEST["split"], CPU_BEST["threads"] = split, cores
+    return {"value": m / dt / 1e6, "unit": "Mscalar·mul/s", "cores": cores, "kind": "port", "host_cores": ncpu, "work_split": split,
             "by_threads_Mscalar_mul_s": tried,
-            "sample": "one dense_multiexp (c=ceil(ln n), per-thread buckets) of 2^%d uniform scalars, %.2f s" % (log_sample, dt)}, ref, s
+            "sample": "one dense_multiexp (c=ceil(ln n)) of 2^%d uniform scalars, %.2f s; best of %d thread counts x 2 work splits" % (log_sample, dt, len(counts))}, ref, s
 
 
 def cpu_msm_rows(ctx, device, log_n=20, big_log_n=24):
@@ -134,7 +147,8 @@ def cpu_msm_rows(ctx, device, log_n=20, big_log_n=24):
     idx = np.nonzero((pick >= 0.5) & (pick < 0.75))[0]
     wl[idx] = small[rng.integers(0, 1 << 16, size=idx.shape[0])]
     cases = {"uniform": uni, "witness_like": wl, "all_ones": np.tile(one, (n, 1)), "all_r_minus_1": np.tile(minus_one, (n, 1))}
-    cores = min(os.cpu_count() or 1, 16)
+    cores = CPU_BEST["threads"]
+    ol.MSM_SPLIT[0] = CPU_BEST["split"]
     out = {}
     for name, sc in cases.items():
         t0 = time.perf_counter()
@@ -172,13 +186,14 @@ def cpu_msm_rows(ctx, device, log_n=20, big_log_n=24):
 
 def cpu_g1_intt_row(ctx, device, log_n=16):
     """BASELINE.md §3 row B5 on a bounded sample: Crs::<Lagrange>::from_powers (the G1 iNTT of dump-lagrange) of the first
-    2^16 crs_42 points — 2^15 * 16 scalar multiplications of 254 bits, a few seconds on 16 host threads; 2^20 would be ~25x more"""
+    2^16 crs_42 points — 2^15 * 16 scalar multiplications of 254 bits on every host core; 2^20 would be ~25x more (the GPU
+    side of the full-size configuration is kernels["g1_intt_2^20"])"""
     from oracle import oracle_lib as ol
     n = 1 << log_n
     keep = ctx.srs_size()
     ctx.srs_generate(n, 0, 42)
     pts = ctx.srs_download(0, n)
-    cores = min(os.cpu_count() or 1, 16)
+    cores = os.cpu_count() or 1
     t0 = time.perf_counter()
     ref = ol.g1_intt(pts, log_n, threads=cores)
     cpu_s = time.perf_counter() - t0
@@ -223,29 +238,34 @@ def cpu_ntt_baseline(sizes=(20, 22)):
 
 
 def cpu_prove_baseline(ctx, log_domain):
-    """the oracle's restatement of the whole prove (numpy / Python glue + OpenMP C kernels, kind "port") at the
-    headline domain, beside the HIP prover on the SAME circuit, witness and SRS; the two proofs must be
-    byte-identical.  `cpu_c_kernels_s` is the part of the CPU time spent inside the C arithmetic (11 MSM, 25
-    NTT-equivalents, vector passes); the remainder is Python glue a compiled prover would not pay, so the ratio against
-    `cpu_c_kernels_s` is the conservative one."""
+    """the oracle's restatement of the whole prove at the headline domain (kind "port"), beside the HIP prover on the SAME
+    circuit, witness and SRS; the two proofs must be byte-identical.  Compiled code end to end since round 4: the files are
+    parsed, the circuit synthesised with the witness and the gates checked by the C front end of oracle/c/oracle.c
+    (single-threaded, as the reference's synthesis is), the rounds are OpenMP C kernels on the thread count and MSM work
+    split that cpu_msm_baseline found fastest on this host; `cpu_c_share` = the part of `cpu_s` spent inside liboracle.so
+    (the remainder is numpy buffer handling)."""
     import plonkit_amd as pa
     from oracle import oracle_lib as ol, plonk_oracle as po      # checker / baseline only
     circ = pa.Circuit.synthetic((1 << log_domain) - 2)
-    r1cs, wit = po.load_r1cs_bin(circ.export("r1cs")), po.parse_wtns(circ.export("wtns"))
+    raw_r1cs, raw_wtns = circ.export("r1cs"), circ.export("wtns")
     srs_keep = ctx.srs_size()
     ctx.srs_generate(1 << log_domain, 0, 42)
     crs = po.Crs(ctx.srs_download(0, 1 << log_domain), b"\x01" * 256)
+    ol.set_threads(CPU_BEST["threads"])
+    ol.MSM_SPLIT[0] = CPU_BEST["split"]
     t0 = time.perf_counter()
-    po.load_r1cs_bin(circ.export("r1cs")); po.parse_wtns(circ.export("wtns"))      # (timed once more: row B2 counts the parsing)
+    rf, wit = po.load_r1cs_flat(raw_r1cs), ol.wtns_parse(raw_wtns)      # row B2 counts the parsing
     parse_s = time.perf_counter() - t0
     t0 = time.perf_counter()
-    S = po.setup(r1cs)
+    S = po.setup_flat(rf)
     setup_s = time.perf_counter() - t0
     ol.C_SECONDS[0] = 0.0
     t0 = time.perf_counter()
-    ref = po.write_proof(po.prove(r1cs, wit, crs, S))
+    ref = po.write_proof(po.prove(rf, wit, crs, S))
     cpu_s = time.perf_counter() - t0
     c_s = ol.C_SECONDS[0]
+    ol.set_threads(None)
+    ol.MSM_SPLIT[0] = "chunks"
     setup = pa.SetupForProver(ctx, circ)
     setup.prove(circ)
     t0 = time.perf_counter()
@@ -254,11 +274,13 @@ def cpu_prove_baseline(ctx, log_domain):
     setup.close(); circ.close()
     if srs_keep:
         ctx.srs_generate(srs_keep, 0, 42)
-    return {"domain": 1 << log_domain, "cpu_s": round(cpu_s, 3), "cpu_c_kernels_s": round(c_s, 3), "cpu_setup_s": round(setup_s, 2),
-            "cpu_parse_s": round(parse_s, 2), "cpu_whole_s": round(parse_s + setup_s + cpu_s, 1),
-            "gpu_s": round(gpu_s, 5), "threads": ol.ncpu(), "kind": "port", "proof_bytes_identical": bool(got == ref),
+    return {"domain": 1 << log_domain, "cpu_s": round(cpu_s, 3), "cpu_c_kernels_s": round(c_s, 3), "cpu_c_share": round(c_s / cpu_s, 3),
+            "cpu_setup_s": round(setup_s, 2), "cpu_parse_s": round(parse_s, 2), "cpu_whole_s": round(parse_s + setup_s + cpu_s, 1),
+            "gpu_s": round(gpu_s, 5), "threads": CPU_BEST["threads"], "msm_work_split": CPU_BEST["split"], "host_cores": os.cpu_count(),
+            "kind": "port", "proof_bytes_identical": bool(got == ref),
             "speedup_vs_cpu_total": round(cpu_s / gpu_s, 1), "speedup_vs_cpu_c_kernels": round(c_s / gpu_s, 1),
-            "sample": "one prove (rounds 1-5, 11 MSM + 25 NTT-equivalents) of a synthetic 2^%d-gate circuit" % log_domain}
+            "sample": "one prove (synthesis + gate check, rounds 1-5: 11 MSM + 25 NTT-equivalents) of a synthetic 2^%d-gate circuit; "
+                      "a port of bellman's algorithms, not the reference binary (no Rust toolchain in this image)" % log_domain}
 
 
 def reference_binary_baseline(log_domain):
@@ -564,8 +586,12 @@ def main():
                        "terms_per_gpu": n, "parallelism": "srs-shard x%d + all_gather of partial sums" % world,
                        "pipeline_depth": args.pipeline_depth, "settle_steps": args.settle_steps,
                        "result_x_be": pa.g1_to_bytes(out).hex()[:64]},
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            # `bound`: what limits the kernel is VALU issue (v_mad_u64_u32), not HBM and not MFMA (integer modular arithmetic) — said so here;
+            # achieved / peak / frac stay the HBM figures north_star and the bench contract ask for (hbm_frac repeats frac under its own name),
+            # the VALU figures are in `valu`
+            "roofline": {"bound": "valu", "kernel": "msm_accumulate", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "hbm_frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "valu_frac": round(gmadd / VALU_PEAK_GMADD, 3),
                          "traffic": PMC_TRAFFIC_BYTES_2POW20 if (args.log_n == 20) else None,
                          "traffic_source": PMC_TRAFFIC_SOURCE if (args.log_n == 20) else None,
                          "kernel_ms": round(k_ms, 4), "kernel_ms_pipelined": round(k_pipe, 4),
@@ -613,6 +639,14 @@ def main():
         if world == 1 and not force_dist and not args.msm_only:
             from plonkit_amd import prover_bench
             line["prove"] = prover_bench.run(ctx, args.log_n)
+            # the same circuit shape with a live d column (11 of 11 commitments), and prove THROUGHPUT: two proofs in flight on this GPU
+            for key, fn in (("dense", lambda: prover_bench.run_dense(ctx, args.log_n)),
+                            ("throughput", lambda: prover_bench.throughput(ctx, args.log_n, in_flight=2, proofs_each=10)),
+                            ("throughput_dense", lambda: prover_bench.throughput(ctx, args.log_n, in_flight=2, proofs_each=6, lc_terms=7))):
+                try:
+                    line["prove"][key] = fn()
+                except Exception as exc:                               # noqa: BLE001 — must not cost the headline line
+                    line["prove"][key] = {"error": repr(exc)}
             line["kernels"] = prover_bench.kernel_table(ctx, device)
     if world > 1 or force_dist:
         # (a) strong scaling of ONE 2^24-term commitment (configs[2]); (b) multi-GPU prove at the 2^log_n domain: the SRS

@@ -284,6 +284,58 @@ EXPORT void orc_g1_msm(g1j_t *out, const g1a_t *bases, const fe_t *scalars_mont,
     *out = res;
     free(allb); free(region); free(k); }
 
+/* The same sum with the work split by (window, chunk) instead of by chunk alone — what later bellman revisions do
+ * (multiexp.rs: one task per window region, each over a slice of the bases).  dense_multiexp above gives EVERY thread its own
+ * 2^c - 1 buckets per window, so each thread pays 2 * (2^c - 1) full additions per window whatever its share of the terms:
+ * with c = 14 at 2^20 terms that reduction outweighs the useful additions from ~32 threads up, and on a 256-thread host the
+ * 0.3.2 shape is slower than on 16 threads.  Here all windows run at once: `groups` = max(1, threads / windows) chunks per
+ * window, one task per (window, chunk) with buckets allocated and first touched by the thread that runs the task.  Same c,
+ * same zero / one handling, same group element.  This is the baseline a many-core host deserves; kind stays "port". */
+EXPORT void orc_g1_msm_wc(g1j_t *out, const g1a_t *bases, const fe_t *scalars_mont, uint64_t n, int threads) {
+    if (threads < 1) threads = 1;
+    fe_t *k = malloc((n ? n : 1) * sizeof(fe_t));
+    #pragma omp parallel for num_threads(threads)
+    for (uint64_t i = 0; i < n; i++) fr_to_canonical(&k[i], &scalars_mont[i]);
+    uint32_t c = n < 32 ? 3 : (uint32_t)ceil(log((double)n));
+    uint32_t nwin = (254 + c - 1) / c;
+    size_t nb = ((size_t)1 << c) - 1;
+    uint32_t groups = (uint32_t)threads / nwin; if (groups < 1) groups = 1;
+    if ((uint64_t)groups > n / 256 + 1) groups = (uint32_t)(n / 256 + 1);
+    uint64_t chunk = (n + groups - 1) / groups; if (chunk == 0) chunk = 1;
+    uint32_t ntasks = nwin * groups;
+    g1j_t *part = malloc((size_t)ntasks * sizeof(g1j_t));
+    #pragma omp parallel num_threads(threads)
+    {
+        g1j_t *b = NULL;
+        #pragma omp for schedule(dynamic, 1)
+        for (uint32_t task = 0; task < ntasks; task++) {
+            if (!b) b = aligned_alloc(64, (nb * sizeof(g1j_t) + 63) & ~(size_t)63);     /* first touched by the thread that owns it */
+            uint32_t w = task / groups, g = task % groups;
+            uint32_t skip = w * c; int trivial = (w == 0);
+            uint64_t lo = (uint64_t)g * chunk, hi = lo + chunk > n ? n : lo + chunk;
+            g1j_t acc; g1j_set_inf(&acc);
+            if (lo < hi && b) {
+                for (size_t i = 0; i < nb; i++) g1j_set_inf(&b[i]);
+                for (uint64_t i = lo; i < hi; i++) {
+                    const uint64_t *e = k[i].l;
+                    if ((e[0] | e[1] | e[2] | e[3]) == 0) continue;
+                    if (e[0] == 1 && (e[1] | e[2] | e[3]) == 0) { if (trivial) g1j_add_mixed(&acc, &acc, &bases[i]); continue; }
+                    uint64_t d = window_bits(e, skip, c);
+                    if (d) g1j_add_mixed(&b[d - 1], &b[d - 1], &bases[i]); }
+                g1j_t run; g1j_set_inf(&run);
+                for (size_t i = nb; i-- > 0;) { g1j_add(&run, &run, &b[i]); g1j_add(&acc, &acc, &run); }
+            }
+            part[task] = acc;
+        }
+        free(b);
+    }
+    g1j_t res; g1j_set_inf(&res);
+    for (uint32_t w = nwin; w-- > 0;) {
+        for (uint32_t i = 0; i < c; i++) g1j_double(&res, &res);
+        for (uint32_t g = 0; g < groups; g++) g1j_add(&res, &res, &part[(size_t)w * groups + g]); }
+    *out = res;
+    free(part); free(k); }
+
 /* Crs::<Lagrange>::from_powers (src/plonk.rs:179-185): inverse NTT over G1,
  * out[i] = L_i(tau)*G given in[j] = tau^j*G.  Serial radix-2 DIT on Jacobian points. */
 EXPORT void orc_g1_intt(g1a_t *out, const g1a_t *in, uint32_t log_n, int threads) {
@@ -310,6 +362,213 @@ EXPORT void orc_g1_intt(g1a_t *out, const g1a_t *in, uint32_t log_n, int threads
     for (uint32_t i = 0; i < n; i++) g1j_mul_scalar(&a[i], &a[i], n_inv_c.l);
     batch_to_affine(out, a, n);
     free(a); }
+
+/* --------------------------------------------------------- circuit front end (CPU baseline) ----
+ * The part of `plonkit prove` that runs before the first FFT: read the iden3 .r1cs / .wtns files (src/r1cs_file.rs:100-154,
+ * src/reader.rs:124-175), synthesise the circuit gate by gate with the witness (CircomCircuit::synthesize fed to bellman's
+ * Width4 adaptor, src/circom_circuit.rs:114-131; rules of SURVEY.md A.3, the same ones oracle/plonk_oracle.py::transpile
+ * restates in Python and tests/ compare this code with) and check every gate (is_satisfied_using_one_shot_check,
+ * src/plonk.rs:137).  The reference does all of it single-threaded in compiled code; the Python restatement made the CPU
+ * baseline of bench.py half interpreter time, so the baseline leg uses these. */
+static int fr_from_le32(fe_t *out, const uint8_t *p) {
+    fe_t c; memcpy(c.l, p, 32);
+    if (fr_geq_p(c.l)) return 0;
+    fr_from_canonical(out, &c); return 1; }
+static uint32_t rd_u32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint64_t rd_u64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+/* pass 1 (off == NULL): header[0..4] = n_wires, n_pub_out, n_pub_in, n_constraints, n_terms.  pass 2: fills off (3 * nc + 1),
+ * wires, coeffs (Montgomery).  Returns 0, or a negative code for a malformed file. */
+EXPORT int orc_r1cs_parse(const uint8_t *d, uint64_t len, uint64_t *header, uint64_t *off, uint32_t *wires, fe_t *coeffs) {
+    if (len < 12 || memcmp(d, "r1cs", 4) != 0 || rd_u32(d + 4) != 1) return -1;
+    uint32_t nsec = rd_u32(d + 8);
+    uint64_t o = 12, s_off[4] = {0, 0, 0, 0}, s_len[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < nsec; i++) {
+        if (o + 12 > len) return -2;
+        uint32_t t = rd_u32(d + o); uint64_t sz = rd_u64(d + o + 4); o += 12;
+        if (sz > len - o) return -2;
+        if (t >= 1 && t <= 3) { s_off[t] = o; s_len[t] = sz; }
+        o += sz; }
+    if (!s_off[1] || !s_off[2] || s_len[1] != 64 || rd_u32(d + s_off[1]) != 32) return -3;
+    const uint8_t *h = d + s_off[1] + 36;
+    uint64_t n_wires = rd_u32(h), n_pub_out = rd_u32(h + 4), n_pub_in = rd_u32(h + 8), nc = rd_u32(h + 24);
+    uint64_t p = s_off[2], end = s_off[2] + s_len[2], nt = 0;
+    if (off) off[0] = 0;
+    for (uint64_t i = 0; i < 3 * nc; i++) {
+        if (p + 4 > end) return -4;
+        uint32_t k = rd_u32(d + p); p += 4;
+        if ((uint64_t)k * 36 > end - p) return -4;
+        if (off) for (uint32_t j = 0; j < k; j++) {
+            uint32_t w = rd_u32(d + p + 36 * (uint64_t)j);
+            if (w >= n_wires) return -5;
+            wires[nt + j] = w;
+            if (!fr_from_le32(&coeffs[nt + j], d + p + 36 * (uint64_t)j + 4)) return -6; }
+        nt += k; p += 36 * (uint64_t)k;
+        if (off) off[i + 1] = nt; }
+    header[0] = n_wires; header[1] = n_pub_out; header[2] = n_pub_in; header[3] = nc; header[4] = nt;
+    return 0; }
+
+/* .wtns -> Montgomery Fr values; out == NULL only reports the count.  Returns the count or a negative code. */
+EXPORT int64_t orc_wtns_parse(const uint8_t *d, uint64_t len, fe_t *out, uint64_t cap) {
+    if (len < 76 || memcmp(d, "wtns", 4) != 0 || rd_u32(d + 4) > 2 || rd_u32(d + 8) != 2) return -1;
+    if (rd_u32(d + 12) != 1 || rd_u64(d + 16) != 40 || rd_u32(d + 24) != 32) return -2;
+    uint64_t n = rd_u32(d + 60);
+    if (rd_u32(d + 64) != 2 || rd_u64(d + 68) != n * 32 || len < 76 + n * 32) return -3;
+    if (!out) return (int64_t)n;
+    if (cap < n) return -4;
+    for (uint64_t i = 0; i < n; i++) if (!fr_from_le32(&out[i], d + 76 + 32 * i)) return -5;
+    return (int64_t)n; }
+
+typedef struct { uint32_t var; fe_t coeff; } term_t;
+typedef struct {
+    uint32_t *vars; fe_t *q; uint64_t cap, rows;          /* vars[j * cap + row], q[k * cap + row] (q may be NULL) */
+    fe_t *values; uint64_t cap_vals, num_vars; int have_values, failed;
+} synth_t;
+static void sy_gate(synth_t *S, const uint32_t v[4], const fe_t q[7]) {
+    if (S->rows >= S->cap) { S->failed = 2; return; }
+    for (int j = 0; j < 4; j++) S->vars[(uint64_t)j * S->cap + S->rows] = v[j];
+    if (S->q) for (int k = 0; k < 7; k++) S->q[(uint64_t)k * S->cap + S->rows] = q[k];
+    S->rows++; }
+static uint32_t sy_alloc(synth_t *S, const fe_t *v) {
+    if (S->num_vars >= S->cap_vals) { S->failed = 2; return 0; }
+    if (S->have_values) S->values[S->num_vars] = *v;
+    return (uint32_t)S->num_vars++; }
+static fe_t sy_val(const synth_t *S, uint32_t v) { fe_t z = {{0, 0, 0, 0}}; return (S->have_values && v) ? S->values[v] : z; }
+/* stable de-duplication; wire 0 (ONE) goes to the constant; zero coefficients dropped */
+static size_t sy_split(const uint32_t *w, const fe_t *c, size_t n, fe_t *constant, term_t *out) {
+    fe_t z = {{0, 0, 0, 0}}; *constant = z; size_t m = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (w[i] == 0) { fr_add(constant, constant, &c[i]); continue; }
+        size_t j = 0;
+        for (; j < m; j++) if (out[j].var == w[i]) { fr_add(&out[j].coeff, &out[j].coeff, &c[i]); break; }
+        if (j == m) { out[m].var = w[i]; out[m].coeff = c[i]; m++; } }
+    size_t k = 0;
+    for (size_t j = 0; j < m; j++) if (!fr_is_zero(&out[j].coeff)) out[k++] = out[j];
+    return k; }
+static fe_t sy_eval(const synth_t *S, const term_t *lc, size_t n, const fe_t *free_) {
+    fe_t s = *free_;
+    if (S->have_values) for (size_t i = 0; i < n; i++) { fe_t v = sy_val(S, lc[i].var), t; fr_mul(&t, &lc[i].coeff, &v); fr_add(&s, &s, &t); }
+    return s; }
+/* lc has room for one more term.  [recollection of bellman's enforce_lc_as_gates; single gate pinned by SURVEY.md A.3] */
+static void sy_lc_as_gates(synth_t *S, term_t *lc, size_t n, fe_t free_, int collapse, uint32_t *var_out, fe_t *coeff_out) {
+    fe_t zero = {{0, 0, 0, 0}}, minus_one; fr_neg(&minus_one, &fr_ONE);
+    if (n == 1 && fr_is_zero(&free_) && collapse) { *var_out = lc[0].var; *coeff_out = lc[0].coeff; return; }
+    uint32_t fin = 0;
+    if (collapse) { fe_t v = sy_eval(S, lc, n, &free_); fin = sy_alloc(S, &v); lc[n].var = fin; lc[n].coeff = minus_one; n++; }
+    uint32_t v[4] = {0, 0, 0, 0}; fe_t q[7];
+    for (int i = 0; i < 7; i++) q[i] = zero;
+    if (n <= 4) {
+        for (size_t i = 0; i < n; i++) { v[i] = lc[i].var; q[i] = lc[i].coeff; }
+        q[5] = free_; sy_gate(S, v, q);
+    } else {                                              /* UNPINNED: chain through d / d_next */
+        size_t pos = 0;
+        fe_t s = sy_eval(S, lc, 4, &free_);
+        for (int i = 0; i < 4; i++, pos++) { v[i] = lc[pos].var; q[i] = lc[pos].coeff; }
+        q[5] = free_; q[6] = minus_one;
+        uint32_t nxt = sy_alloc(S, &s);
+        sy_gate(S, v, q);
+        while (n - pos > 3) {
+            for (int i = 0; i < 7; i++) q[i] = zero;
+            fe_t prev = sy_val(S, nxt);
+            s = sy_eval(S, lc + pos, 3, &prev);
+            for (int i = 0; i < 3; i++, pos++) { v[i] = lc[pos].var; q[i] = lc[pos].coeff; }
+            v[3] = nxt; q[3] = fr_ONE; q[6] = minus_one;
+            uint32_t nn = sy_alloc(S, &s);
+            sy_gate(S, v, q);
+            nxt = nn; }
+        for (int i = 0; i < 7; i++) q[i] = zero;
+        v[0] = v[1] = v[2] = 0;
+        for (int i = 0; pos < n; i++, pos++) { v[i] = lc[pos].var; q[i] = lc[pos].coeff; }
+        v[3] = nxt; q[3] = fr_ONE;
+        sy_gate(S, v, q); }
+    *var_out = fin; *coeff_out = fr_ONE; }
+
+/* Transpiles constraints [0, nc) into gate rows first_row.. of vars / q (q may be NULL) and, with a witness (Montgomery values
+ * indexed by wire; id 0 is the dummy variable = 0), the value of every variable including the temporaries it allocates
+ * (ids from num_variables up).  Returns the number of gates, -1 for an unsatisfiable constant constraint, -2 when a
+ * capacity is exceeded.  *num_vars_out = num_variables + temporaries. */
+EXPORT int64_t orc_transpile(const uint64_t *off, const uint32_t *wires, const fe_t *coeffs, uint64_t nc, uint64_t num_variables,
+                             const fe_t *witness, uint32_t *vars_out, fe_t *q_out, uint64_t cap, uint64_t first_row,
+                             fe_t *values_out, uint64_t cap_vals, uint64_t *num_vars_out) {
+    synth_t S = {vars_out, q_out, cap, first_row, values_out, cap_vals, num_variables, witness != NULL, 0};
+    fe_t zero = {{0, 0, 0, 0}};
+    if (witness) {
+        if (cap_vals < num_variables) return -2;
+        memcpy(values_out, witness, num_variables * sizeof(fe_t));
+        values_out[0] = zero; }
+    size_t max_terms = 1;
+    for (uint64_t i = 0; i < 3 * nc; i++) if (off[i + 1] - off[i] > max_terms) max_terms = off[i + 1] - off[i];
+    term_t *al = malloc((max_terms + 1) * sizeof(term_t)), *bl = malloc((max_terms + 1) * sizeof(term_t)),
+           *cl = malloc((2 * max_terms + 1) * sizeof(term_t));
+    uint32_t *mw = malloc(2 * max_terms * sizeof(uint32_t)); fe_t *mc = malloc(2 * max_terms * sizeof(fe_t));
+    int64_t rc = 0;
+    for (uint64_t idx = 0; idx < nc && !S.failed; idx++) {
+        const uint64_t a0 = off[3 * idx], b0 = off[3 * idx + 1], c0 = off[3 * idx + 2], c1 = off[3 * idx + 3];
+        if ((b0 == a0 || c0 == b0) && c1 == c0) continue;                        /* src/circom_circuit.rs:121-122 */
+        fe_t ac, bc, cc;
+        size_t na = sy_split(wires + a0, coeffs + a0, b0 - a0, &ac, al);
+        size_t nb = sy_split(wires + b0, coeffs + b0, c0 - b0, &bc, bl);
+        size_t ncl = sy_split(wires + c0, coeffs + c0, c1 - c0, &cc, cl);
+        uint32_t dv; fe_t dc, q[7];
+        for (int i = 0; i < 7; i++) q[i] = zero;
+        if (na == 0 && nb == 0) {
+            fe_t t, fr_; fr_mul(&t, &ac, &bc); fr_sub(&fr_, &cc, &t);
+            if (ncl == 0) { if (!fr_is_zero(&fr_)) { rc = -1; break; } }
+            else sy_lc_as_gates(&S, cl, ncl, fr_, 0, &dv, &dc);
+        } else if (na == 0 || nb == 0) {                                         /* UNPINNED: constant * LC = LC */
+            const fe_t *kk = na == 0 ? &ac : &bc; const term_t *lin = na == 0 ? bl : al; size_t nl = na == 0 ? nb : na;
+            const fe_t *lin_c = na == 0 ? &bc : &ac;
+            size_t m = 0;
+            for (size_t i = 0; i < nl; i++, m++) { mw[m] = lin[i].var; fr_mul(&mc[m], &lin[i].coeff, kk); }
+            for (size_t i = 0; i < ncl; i++, m++) { mw[m] = cl[i].var; fr_neg(&mc[m], &cl[i].coeff); }
+            fe_t t, fr_, dummy; fr_mul(&t, kk, lin_c); fr_sub(&fr_, &t, &cc);
+            size_t nm = sy_split(mw, mc, m, &dummy, cl);
+            if (nm) sy_lc_as_gates(&S, cl, nm, fr_, 0, &dv, &dc);
+            else if (!fr_is_zero(&fr_)) { rc = -1; break; }
+        } else {
+            int same = na == 1 && nb == 1 && al[0].var == bl[0].var && (ncl == 0 || (ncl == 1 && cl[0].var == al[0].var));
+            if (same) {                                                          /* UNPINNED: quadratic gate */
+                fe_t a1 = al[0].coeff, b1 = bl[0].coeff, c1f = ncl ? cl[0].coeff : zero, t1, t2;
+                uint32_t v[4] = {al[0].var, al[0].var, 0, 0};
+                fr_mul(&t1, &ac, &b1); fr_mul(&t2, &a1, &bc); fr_add(&t1, &t1, &t2); fr_sub(&q[0], &t1, &c1f);
+                fr_mul(&q[4], &a1, &b1);
+                fr_mul(&t1, &ac, &bc); fr_sub(&q[5], &t1, &cc);
+                sy_gate(&S, v, q);
+            } else {
+                uint32_t av, bv, cv; fe_t acoef, bcoef, ccoef;
+                sy_lc_as_gates(&S, al, na, ac, 1, &av, &acoef);
+                sy_lc_as_gates(&S, bl, nb, bc, 1, &bv, &bcoef);
+                fr_mul(&q[4], &acoef, &bcoef);
+                if (ncl == 0) { uint32_t v[4] = {av, bv, 0, 0}; fr_neg(&q[5], &cc); sy_gate(&S, v, q); }
+                else { sy_lc_as_gates(&S, cl, ncl, cc, 1, &cv, &ccoef); uint32_t v[4] = {av, bv, cv, 0}; fr_neg(&q[2], &ccoef); sy_gate(&S, v, q); }
+            }
+        }
+    }
+    free(al); free(bl); free(cl); free(mw); free(mc);
+    if (rc < 0) return rc;
+    if (S.failed) return -2;
+    *num_vars_out = S.num_vars;
+    return (int64_t)(S.rows - first_row); }
+
+/* cols[j][r] = values[vars[j][r]] for r < n (vars with leading dimension cap) */
+EXPORT void orc_gather_columns(fe_t *cols, const uint32_t *vars, uint64_t cap, const fe_t *values, uint64_t n, int threads) {
+    #pragma omp parallel for num_threads(threads) collapse(2)
+    for (int j = 0; j < 4; j++) for (uint64_t r = 0; r < n; r++) cols[(uint64_t)j * n + r] = values[vars[(uint64_t)j * cap + r]]; }
+
+/* is_satisfied_using_one_shot_check: every row r < n satisfies
+ * q_a a + q_b b + q_c c + q_d d + q_m a b + q_const + q_d_next d(r + 1) + (r < num_inputs ? a : 0) = 0.
+ * sel = 7 selector VALUE vectors of length n; cols = 4 wire-value vectors of length n.  Returns 1 / 0. */
+EXPORT int orc_check_gates(const fe_t *cols, const fe_t *sel, uint64_t n, uint64_t num_inputs, int threads) {
+    int ok = 1;
+    #pragma omp parallel for num_threads(threads) reduction(&&: ok)
+    for (uint64_t r = 0; r < n; r++) {
+        fe_t acc = sel[5 * n + r], t, ab;
+        for (int j = 0; j < 4; j++) { fr_mul(&t, &sel[(uint64_t)j * n + r], &cols[(uint64_t)j * n + r]); fr_add(&acc, &acc, &t); }
+        fr_mul(&ab, &cols[r], &cols[n + r]); fr_mul(&t, &sel[4 * n + r], &ab); fr_add(&acc, &acc, &t);
+        if (r + 1 < n) { fr_mul(&t, &sel[6 * n + r], &cols[3 * n + r + 1]); fr_add(&acc, &acc, &t); }
+        if (r < num_inputs) fr_add(&acc, &acc, &cols[r]);
+        ok = ok && fr_is_zero(&acc); }
+    return ok; }
 
 /* ----------------------------------------------------------------------- keccak ------- */
 static const uint64_t KRC[24] = {

@@ -74,9 +74,17 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+_THREADS = [None]
+
+
+def set_threads(n):
+    """thread count of every call that does not name one (None: back to the default); bench.py's cpu_baseline leg sets it"""
+    _THREADS[0] = int(n) if n else None
+
+
 def ncpu():
-    """default thread count of the checker (tests); the cpu_baseline leg passes its own (all cores)"""
-    return min(os.cpu_count() or 1, 16)
+    """default thread count of the checker (tests: at most 16); the cpu_baseline leg sets its own with set_threads()"""
+    return _THREADS[0] or min(os.cpu_count() or 1, 16)
 
 
 # ----------------------------------------------------------------- int <-> limb conversions
@@ -159,7 +167,7 @@ def _vec2(name, a, b, threads=None):
     a = np.ascontiguousarray(a, dtype=np.uint64)
     b = np.ascontiguousarray(b, dtype=np.uint64)
     assert a.shape == b.shape
-    out = np.zeros_like(a)
+    out = np.empty_like(a)
     getattr(lib(), name)(_p(out), _p(a), _p(b), ctypes.c_uint64(a.shape[0]), ctypes.c_int(threads or ncpu()))
     return out
 
@@ -178,7 +186,7 @@ def vsub(a, b):
 
 def vscale(a, s):
     a = np.ascontiguousarray(a, dtype=np.uint64)
-    out = np.zeros_like(a)
+    out = np.empty_like(a)
     sm = fr_mont(s)
     lib().orc_fr_vec_scale(_p(out), _p(a), _p(sm), ctypes.c_uint64(a.shape[0]), ctypes.c_int(ncpu()))
     return out
@@ -186,7 +194,7 @@ def vscale(a, s):
 
 def vadd_scalar(a, s):
     a = np.ascontiguousarray(a, dtype=np.uint64)
-    out = np.zeros_like(a)
+    out = np.empty_like(a)
     sm = fr_mont(s)
     lib().orc_fr_vec_add_scalar(_p(out), _p(a), _p(sm), ctypes.c_uint64(a.shape[0]), ctypes.c_int(ncpu()))
     return out
@@ -196,7 +204,7 @@ def vaxpy(a, s, b):
     """a + s*b"""
     a = np.ascontiguousarray(a, dtype=np.uint64)
     b = np.ascontiguousarray(b, dtype=np.uint64)
-    out = np.zeros_like(a)
+    out = np.empty_like(a)
     sm = fr_mont(s)
     lib().orc_fr_vec_axpy(_p(out), _p(a), _p(sm), _p(b), ctypes.c_uint64(a.shape[0]), ctypes.c_int(ncpu()))
     return out
@@ -295,8 +303,12 @@ def crs42(n, threads=None):
     return out
 
 
-def msm(bases, scalars, threads=None, naive=False):
-    """sum scalars[i]*bases[i] -> affine limbs [8].  bellman dense_multiexp restatement."""
+MSM_SPLIT = ["chunks"]       # default work split of msm(): "chunks" = bellman 0.3.2's dense_multiexp, "windows" = (window, chunk) tasks
+
+
+def msm(bases, scalars, threads=None, naive=False, split=None):
+    """sum scalars[i]*bases[i] -> affine limbs [8].  bellman dense_multiexp restatement; split="windows": the same sum with
+    the work cut by (window, chunk) as later bellman revisions do (orc_g1_msm_wc: what scales past ~32 threads)."""
     bases = np.ascontiguousarray(bases, dtype=np.uint64)
     scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
     n = scalars.shape[0]
@@ -304,6 +316,8 @@ def msm(bases, scalars, threads=None, naive=False):
     out = np.zeros(12, dtype=np.uint64)
     if naive:
         lib().orc_g1_msm_naive(_p(out), _p(bases), _p(scalars), ctypes.c_uint64(n))
+    elif (split or MSM_SPLIT[0]) == "windows":
+        lib().orc_g1_msm_wc(_p(out), _p(bases), _p(scalars), ctypes.c_uint64(n), ctypes.c_int(threads or ncpu()))
     else:
         lib().orc_g1_msm(_p(out), _p(bases), _p(scalars), ctypes.c_uint64(n), ctypes.c_int(threads or ncpu()))
     return jac_to_affine(out)[0]
@@ -323,6 +337,77 @@ def g1_intt(points, log_n, threads=None):
     out = np.zeros((1 << log_n, 8), dtype=np.uint64)
     lib().orc_g1_intt(_p(out), _p(points), ctypes.c_uint32(log_n), ctypes.c_int(threads or ncpu()))
     return out
+
+
+# ------------------------------------------------------- circuit front end in C (CPU baseline leg)
+def r1cs_parse(data: bytes):
+    """iden3 .r1cs -> (header dict, off uint64[3 nc + 1], wires uint32[nt], coeffs Montgomery [nt, 4])"""
+    hdr = np.zeros(5, dtype=np.uint64)
+    L = lib()
+    L.orc_r1cs_parse.raw.restype = ctypes.c_int
+    rc = L.orc_r1cs_parse(data, ctypes.c_uint64(len(data)), _p(hdr), None, None, None)
+    if rc != 0:
+        raise ValueError("InvalidData: malformed r1cs (%d)" % rc)
+    n_wires, n_pub_out, n_pub_in, nc, nt = (int(x) for x in hdr)
+    off = np.zeros(3 * nc + 1, dtype=np.uint64)
+    wires = np.zeros(max(nt, 1), dtype=np.uint32)
+    coeffs = np.zeros((max(nt, 1), 4), dtype=np.uint64)
+    rc = L.orc_r1cs_parse(data, ctypes.c_uint64(len(data)), _p(hdr), _p(off), _p(wires), _p(coeffs))
+    if rc != 0:
+        raise ValueError("InvalidData: malformed r1cs (%d)" % rc)
+    return dict(n_wires=n_wires, n_pub_out=n_pub_out, n_pub_in=n_pub_in, n_constraints=nc), off, wires, coeffs
+
+
+def wtns_parse(data: bytes):
+    """iden3 .wtns -> Montgomery Fr array [n, 4]"""
+    L = lib()
+    L.orc_wtns_parse.raw.restype = ctypes.c_int64
+    n = L.orc_wtns_parse(data, ctypes.c_uint64(len(data)), None, ctypes.c_uint64(0))
+    if n < 0:
+        raise ValueError("malformed wtns (%d)" % n)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    if L.orc_wtns_parse(data, ctypes.c_uint64(len(data)), _p(out), ctypes.c_uint64(n)) != n:
+        raise ValueError("malformed wtns")
+    return out
+
+
+def transpile_c(off, wires, coeffs, num_variables, witness=None, first_row=0, want_q=True, cap=None):
+    """gate rows (vars uint32 [4, cap], q Montgomery [7, cap, 4] or None), number of gates, values [num_vars, 4] or None"""
+    nc = (off.shape[0] - 1) // 3
+    nt = int(off[-1])
+    cap = cap or (first_row + nc + nt + 8)                     # a constraint makes at most (terms + 3) gates
+    cap_vals = num_variables + 2 * nt + 3 * nc + 8
+    vars_ = np.zeros((4, cap), dtype=np.uint32)
+    q = np.zeros((7, cap, 4), dtype=np.uint64) if want_q else None
+    values = np.zeros((cap_vals, 4), dtype=np.uint64) if witness is not None else None
+    nv = ctypes.c_uint64(0)
+    L = lib()
+    L.orc_transpile.raw.restype = ctypes.c_int64
+    if witness is not None:
+        witness = np.ascontiguousarray(witness, dtype=np.uint64)
+        assert witness.shape[0] >= num_variables, "witness shorter than the number of variables"
+    g = L.orc_transpile(_p(off), _p(wires), _p(coeffs), ctypes.c_uint64(nc), ctypes.c_uint64(num_variables),
+                        _p(witness) if witness is not None else None, _p(vars_), _p(q) if want_q else None, ctypes.c_uint64(cap),
+                        ctypes.c_uint64(first_row), _p(values) if values is not None else None, ctypes.c_uint64(cap_vals), ctypes.byref(nv))
+    if g == -1:
+        raise AssertionError("unsatisfiable constant constraint")
+    if g < 0:
+        raise MemoryError("orc_transpile: capacity exceeded")
+    return vars_, q, int(g), (values[:nv.value] if values is not None else None), int(nv.value)
+
+
+def gather_columns(vars_, values, n):
+    """cols [4, n, 4]: cols[j][r] = values[vars[j][r]]"""
+    cols = np.empty((4, n, 4), dtype=np.uint64)
+    lib().orc_gather_columns(_p(cols), _p(vars_), ctypes.c_uint64(vars_.shape[1]), _p(values), ctypes.c_uint64(n), ctypes.c_int(ncpu()))
+    return cols
+
+
+def check_gates(cols, sel, n, num_inputs):
+    L = lib()
+    L.orc_check_gates.raw.restype = ctypes.c_int
+    cols = np.ascontiguousarray(cols, dtype=np.uint64); sel = np.ascontiguousarray(sel, dtype=np.uint64)
+    return bool(L.orc_check_gates(_p(cols), _p(sel), ctypes.c_uint64(n), ctypes.c_uint64(num_inputs), ctypes.c_int(ncpu())))
 
 
 def keccak256(data: bytes) -> bytes:

@@ -121,6 +121,23 @@ def load_r1cs_bin(data: bytes):
     return R1CS(num_inputs, hdr["n_wires"] - num_inputs, hdr["n_wires"], cons)
 
 
+class R1CSFlat:
+    """the same R1CS held flat (all linear combinations back to back + one offset table), parsed by the C front end of
+    oracle/c/oracle.c: what bench.py's cpu_baseline leg proves from, so that its prove is compiled code end to end"""
+    def __init__(self, num_inputs, num_variables, off, wires, coeffs):
+        self.num_inputs, self.num_variables, self.num_aux = num_inputs, num_variables, num_variables - num_inputs
+        self.off, self.wires, self.coeffs = off, wires, coeffs
+
+    @property
+    def num_constraints(self):
+        return (self.off.shape[0] - 1) // 3
+
+
+def load_r1cs_flat(data: bytes) -> R1CSFlat:
+    hdr, off, wires, coeffs = ol.r1cs_parse(data)
+    return R1CSFlat(1 + hdr["n_pub_in"] + hdr["n_pub_out"], hdr["n_wires"], off, wires, coeffs)
+
+
 def load_witness_json(path):
     return [int(x) % R_MOD for x in json.load(open(path))]
 
@@ -395,6 +412,55 @@ def setup(r1cs: R1CS, T: Transpiled = None) -> Setup:
     return S
 
 
+def _rows_flat(rf: R1CSFlat, witness=None):
+    """public-input rows + the C transpiler's gates, padded: vars uint32 [4, N], q [7, N, 4] (Montgomery), values"""
+    n_in = rf.num_inputs - 1
+    vars_, q, g, values, _ = ol.transpile_c(rf.off, rf.wires, rf.coeffs, rf.num_variables, witness, first_row=n_in)
+    n_real = n_in + g
+    N = 1
+    while N < n_real + 1:
+        N *= 2
+    V = np.zeros((4, N), dtype=np.uint32)
+    V[:, :n_real] = vars_[:, :n_real]
+    V[0, :n_in] = np.arange(1, n_in + 1, dtype=np.uint32)
+    V[1:, :n_in] = 0
+    Q = np.zeros((7, N, 4), dtype=np.uint64)
+    Q[:, :n_real] = q[:, :n_real]
+    Q[:, :n_in] = 0
+    Q[0, :n_in] = ol.fr_mont(R_MOD - 1)
+    return V, Q, n_in, N, values
+
+
+def setup_flat(rf: R1CSFlat) -> Setup:
+    """setup() from the flat form: gates by the C transpiler, the permutation by one stable sort (numpy) — same
+    polynomials as setup(load_r1cs_bin(..)) (tests/test_oracle_golden.py)"""
+    V, Q, n_in, N, _ = _rows_flat(rf)
+    log_n = N.bit_length() - 1
+    S = Setup()
+    S.n, S.N, S.log_n, S.num_inputs = N - 1, N, log_n, n_in
+    S.selector_values = [np.ascontiguousarray(Q[k]) for k in range(7)]
+    dom = ol.vpowers(ol.omega(log_n), N)
+    kdom = np.stack([ol.vscale(dom, NON_RESIDUES[j]) for j in range(4)])          # [4, N, 4]: k_j * omega^r
+    # occurrences in row-major order (gate by gate, a -> d inside a gate): slot index r * 4 + j
+    flat = np.ascontiguousarray(V.T).reshape(-1)                                 # [N * 4], value = variable id
+    order = np.argsort(flat, kind="stable")
+    sv = flat[order]
+    nxt = np.arange(4 * N, dtype=np.int64)                                       # identity
+    same_next = np.empty(4 * N, dtype=bool); same_next[:-1] = sv[1:] == sv[:-1]; same_next[-1] = False
+    first = np.empty(4 * N, dtype=bool); first[0] = True; first[1:] = sv[1:] != sv[:-1]
+    # group start of every sorted position
+    starts = np.maximum.accumulate(np.where(first, np.arange(4 * N), 0))
+    succ = np.where(same_next, np.roll(order, -1), order[starts])                # next occurrence, the last wraps to the first
+    live = sv != 0
+    nxt[order[live]] = succ[live]
+    jj, rr = nxt % 4, nxt // 4                                                   # successor slot of slot (r * 4 + j)
+    sig = kdom[jj, rr].reshape(N, 4, 4)                                          # [r, j, limbs]
+    S.sigma_values = [np.ascontiguousarray(sig[:, j]) for j in range(4)]
+    S.selectors = [ol.ntt(v, log_n, inverse=True) for v in S.selector_values]
+    S.sigmas = [ol.ntt(v, log_n, inverse=True) for v in S.sigma_values]
+    return S
+
+
 def commit(crs: Crs, coeffs):
     n = coeffs.shape[0]
     assert crs.g1.shape[0] >= n, "SRS too small"
@@ -495,22 +561,32 @@ def is_satisfied(r1cs, T, S, rows=None):
 def prove(r1cs: R1CS, witness, crs: Crs, S: Setup = None, return_debug=False) -> Proof:
     """prove_by_steps with RollingKeccakTranscript and the monomial-form key only
     (src/plonk.rs:152-159) — rounds per SURVEY.md Appendix A.4; no blinding."""
-    T = transpile(r1cs, witness)
-    S = S or setup(r1cs, T)
-    rows, n_in, N = _assemble(r1cs, T)
-    assert N == S.N
-    assert is_satisfied(r1cs, T, S, rows), "must satisfy"
+    if isinstance(r1cs, R1CSFlat):
+        # compiled front end (oracle/c/oracle.c): synthesis with the witness (a Montgomery array, ol.wtns_parse), gate check
+        S = S or setup_flat(r1cs)
+        V, _, n_in, N, values = _rows_flat(r1cs, witness)
+        assert N == S.N
+        cols = ol.gather_columns(V, values, N)
+        assert ol.check_gates(cols, np.stack(S.selector_values), N, n_in), "must satisfy"
+        inputs = ol.fr_ints(values[1:n_in + 1]) if n_in else []
+        w_vals = [cols[j] for j in range(4)]
+    else:
+        T = transpile(r1cs, witness)
+        S = S or setup(r1cs, T)
+        rows, n_in, N = _assemble(r1cs, T)
+        assert N == S.N
+        assert is_satisfied(r1cs, T, S, rows), "must satisfy"
+        vals = T.values
+        inputs = [vals[i] for i in range(1, n_in + 1)]
+        cols = [[0] * N for _ in range(4)]
+        for r, g in enumerate(rows):
+            for j in range(4):
+                cols[j][r] = vals[g.vars[j]]
+        w_vals = [ol.fr_vec(c) for c in cols]
     log_n, log_4n = S.log_n, S.log_n + 2
-    vals = T.values
-    inputs = [vals[i] for i in range(1, n_in + 1)]
     w_omega = ol.omega(log_n)
 
     # ---- round 1: wire polynomials
-    cols = [[0] * N for _ in range(4)]
-    for r, g in enumerate(rows):
-        for j in range(4):
-            cols[j][r] = vals[g.vars[j]]
-    w_vals = [ol.fr_vec(c) for c in cols]
     w_coef = [ol.ntt(v, log_n, inverse=True) for v in w_vals]                      # 4 x iNTT(N)
     P = Proof()
     P.n, P.inputs = S.n, inputs
@@ -548,12 +624,13 @@ def prove(r1cs: R1CS, witness, crs: Crs, S: Setup = None, return_debug=False) ->
     z_e = lde(z_coef)
     q_e = [lde(c) for c in S.selectors]
     s_e = [lde(c) for c in S.sigmas]
-    pi_vals = [0] * N
-    for i, x in enumerate(inputs):
-        pi_vals[i] = x
-    pi_e = lde(ol.ntt(ol.fr_vec(pi_vals), log_n, inverse=True))
-    l0_vals = [1] + [0] * (N - 1)
-    l0_e = lde(ol.ntt(ol.fr_vec(l0_vals), log_n, inverse=True))
+    pi_vals = ol.fr_zeros(N)
+    if inputs:
+        pi_vals[:len(inputs)] = ol.fr_vec(inputs)
+    pi_e = lde(ol.ntt(pi_vals, log_n, inverse=True))
+    l0_vals = ol.fr_zeros(N)
+    l0_vals[0] = ol.fr_mont(1)
+    l0_e = lde(ol.ntt(l0_vals, log_n, inverse=True))
     x_e = ol.vpowers(ol.omega(log_4n), M, COSET_GEN)                               # the coset points
     shift = lambda v: np.roll(v, -4, axis=0)                                       # f(w x) on the 4N domain
     gate = q_e[5]

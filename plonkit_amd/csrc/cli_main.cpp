@@ -184,6 +184,9 @@ static Ranks ranks_from_env() {
     if (const char *k = getenv("PLONKIT_RANK")) r.rank = atoi(k);
     if (const char *c = getenv("PLONKIT_COMM")) r.comm = c;
     if (r.world < 1 || r.rank < 0 || r.rank >= r.world) { fprintf(stderr, "PLONKIT_RANK / PLONKIT_WORLD out of range\n"); exit(2); }
+    // (a rank other than 0 can only tell this run's id file from a crashed run's leftover by the nonce inside it)
+    if (r.world > 1 && r.comm.rfind("rccl:", 0) == 0 && !(getenv("PLONKIT_RUN_ID") && *getenv("PLONKIT_RUN_ID"))) {
+        fprintf(stderr, "PLONKIT_WORLD > 1 with PLONKIT_COMM=rccl:<id file> needs PLONKIT_RUN_ID=<nonce of this run> on every rank\n"); exit(2); }
     if (r.world > 1 && r.comm.rfind("rccl:", 0) != 0 && r.comm.rfind("tcp:", 0) != 0) { fprintf(stderr, "PLONKIT_WORLD > 1 needs PLONKIT_COMM=rccl:<id file> or tcp:<port>\n"); exit(2); }
     return r;
 }
@@ -202,12 +205,11 @@ static void join_ranks(plk_ctx *ctx, const Ranks &rk, uint64_t N) {
     // The id file is 128 bytes of ncclUniqueId followed by the run id (PLONKIT_RUN_ID, may be empty).  A file left behind
     // by an earlier run must never be taken for this run's: rank 0 unlinks the path before it does anything else and
     // removes the file again once the communicator exists (every rank has read it by then: ncclCommInitRank is
-    // collective); the other ranks accept only a file that carries THEIR run id and — when no run id is given — one
-    // that is not older than the two-minute window they are prepared to wait (a crashed run's leftover is older).
+    // collective); the other ranks accept only a file that carries THEIR run id — mandatory for more than one rank (a rank
+    // cannot tell a crashed run's leftover, written seconds ago, from this run's file by its age alone).
     const std::string path = rk.comm.substr(5);
     const char *rid_env = getenv("PLONKIT_RUN_ID");
     const std::string run_id = rid_env ? rid_env : "";
-    const time_t started = time(nullptr);
     plk_comm_id id;
     if (rk.rank == 0) {
         (void)unlink(path.c_str());
@@ -220,8 +222,7 @@ static void join_ranks(plk_ctx *ctx, const Ranks &rk, uint64_t N) {
         bool got = false;
         for (int i = 0; i < 1200 && !got; i++) {                                    // up to two minutes for rank 0
             struct stat st;
-            if (stat(path.c_str(), &st) == 0 && (size_t)st.st_size == sizeof id.bytes + run_id.size() &&
-                (!run_id.empty() || st.st_mtime + 120 >= started)) {
+            if (stat(path.c_str(), &st) == 0 && (size_t)st.st_size == sizeof id.bytes + run_id.size()) {
                 std::vector<uint8_t> raw = slurp(path, "RCCL unique id");
                 if (raw.size() == sizeof id.bytes + run_id.size() && memcmp(raw.data() + sizeof id.bytes, run_id.data(), run_id.size()) == 0) {
                     memcpy(id.bytes, raw.data(), sizeof id.bytes);
@@ -463,6 +464,9 @@ static int run(int argc, char **argv) {
 // runtime and freeing gigabytes of device memory one buffer at a time (0.25 s at the 2^20 domain) — the
 // driver reclaims everything at exit.
 int main(int argc, char **argv) {
+    // one process per GPU joined over RCCL: on this driver device-memory IPC between processes only works in dmabuf mode, and the
+    // switch is read when the HSA runtime initialises — before the first HIP call, whoever launched the ranks
+    if (const char *w = getenv("PLONKIT_WORLD")) if (atoi(w) > 1) setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     int rc = run(argc, argv);
     fflush(stdout); fflush(stderr);
     _exit(rc);

@@ -25,6 +25,7 @@
 #include <cstring>
 #include <chrono>
 #include <thread>
+#include <mutex>
 #include <vector>
 
 namespace plk {
@@ -45,9 +46,10 @@ struct Rccl {
 
 Rccl *rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r.so ? &r : nullptr;
-    tried = true;
+    static std::once_flag once;
+    bool first = false;
+    std::call_once(once, [&] { first = true; });             // (contexts on several host threads may come here at once)
+    if (!first) return r.so ? &r : nullptr;
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (r.so) break;
@@ -76,9 +78,16 @@ int32_t rccl_fail(ncclResult_t e, const char *what) {
 constexpr int COMM_TIMEOUT_S = 180;
 long comm_timeout_ms() {
     const char *e = getenv("PLK_COMM_TIMEOUT_MS");
-    if (e && *e) { char *end = nullptr; long v = strtol(e, &end, 10); if (end != e && v >= 0) return v; }
-    return COMM_TIMEOUT_S * 1000L;
+    if (e && *e) { char *end = nullptr; long v = strtol(e, &end, 10); if (end != e && v > 0) return v; }      // (0 or junk: the default —
+    return COMM_TIMEOUT_S * 1000L;                                       //  a zero deadline would fail every exchange on its first poll)
 }
+// TEST HOOK (tests/test_gpu_sharded_prove.py): PLK_COMM_TEST_STALL_MS=<ms> parks the exchange stream for that long before
+// every all-gather — a peer that does not answer —, so that the watchdog's abort path MUST run when the deadline is shorter
+long comm_test_stall_ms() {
+    static const long v = [] { const char *e = getenv("PLK_COMM_TEST_STALL_MS"); return e && *e ? strtol(e, nullptr, 10) : 0L; }();
+    return v;
+}
+void stall_host_fn(void *ms) { std::this_thread::sleep_for(std::chrono::milliseconds((long)(intptr_t)ms)); }
 void set_timeouts(int fd) {
     timeval tv{COMM_TIMEOUT_S, 0};
     ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
@@ -112,6 +121,7 @@ struct Comm {
     plk_ctx *ctx = nullptr;
     uint64_t gathers = 0;                    // number of exchanges performed (tracing / tests)
     bool dead = false;                       // the watchdog aborted the communicator: every later exchange fails at once
+    bool leak = false;                       // ... and could not abort the collective: stream and buffers are abandoned, not freed
 };
 
 // Waits for the exchange stream with a deadline instead of hipStreamSynchronize: if a peer died, ncclAllGather never
@@ -138,6 +148,8 @@ static int32_t watch_exchange(Comm *C, hipStream_t st) {
         if (failed) {
             C->dead = true;
             if (R->CommAbort && C->nccl) { (void)R->CommAbort(C->nccl); C->nccl = nullptr; }
+            else C->leak = true;              // no ncclCommAbort in this librccl: the collective may never drain — comm_free must not
+                                              // wait for it (hipStreamDestroy / hipFree would hang the way the watchdog exists to avoid)
             set_error(std::string("RCCL exchange aborted: ") + why);
             return PLK_ERR_HIP;
         }
@@ -171,6 +183,7 @@ static int32_t gather(Comm *C, const plk_g1_jacobian *mine, uint32_t count, plk_
     PLK_TRY(C->d_send.reserve(8 * sizeof(plk_g1_jacobian)));
     PLK_TRY(C->d_recv.reserve((size_t)C->world * 8 * sizeof(plk_g1_jacobian)));
     PLK_HIP(hipMemcpyAsync(C->d_send.p, mine, bytes, hipMemcpyHostToDevice, st));
+    if (comm_test_stall_ms() > 0) PLK_HIP(hipLaunchHostFunc(st, stall_host_fn, (void *)(intptr_t)comm_test_stall_ms()));
     ncclResult_t e = R->AllGather(C->d_send.p, C->d_recv.p, bytes, ncclUint8, C->nccl, st);
     if (e != ncclSuccess) return rccl_fail(e, "ncclAllGather");
     PLK_HIP(hipMemcpyAsync(all, C->d_recv.p, bytes * C->world, hipMemcpyDeviceToHost, st));
@@ -197,6 +210,7 @@ static int32_t builtin_combine(void *user, plk_g1_jacobian *sums, uint32_t count
 
 static void comm_free(Comm *C) {
     if (!C) return;
+    if (C->leak) { C->stream = nullptr; C->d_send.p = nullptr; C->d_recv.p = nullptr; C->nccl = nullptr; }      // see watch_exchange
     if (C->nccl) { Rccl *R = rccl(); if (R) (void)R->CommDestroy(C->nccl); }
     if (C->stream) (void)hipStreamDestroy(C->stream);
     C->d_send.release(); C->d_recv.release();

@@ -117,8 +117,13 @@ static int32_t commit_end(plk_ctx *ctx, uint32_t count, HAffine *out) {
     if (ctx->combine) {
         plk_g1_jacobian raw[8];
         for (uint32_t k = 0; k < count; k++) { memcpy(raw[k].x, j[k].x.l, 32); memcpy(raw[k].y, j[k].y.l, 32); memcpy(raw[k].z, j[k].z.l, 32); }
+        set_error("");
         const int32_t rc = ctx->combine(ctx->combine_user, raw, count);
-        if (rc != PLK_OK) { set_error("commitment combiner (plk_set_commit_shard) failed"); return rc; }
+        if (rc != PLK_OK) {                                        // (the built-in combiner says why: keep its words)
+            const std::string why = plk_last_error();
+            set_error(why.empty() ? std::string("commitment combiner (plk_set_commit_shard) failed") : "commitment combiner failed: " + why);
+            return rc;
+        }
         for (uint32_t k = 0; k < count; k++) { memcpy(j[k].x.l, raw[k].x, 32); memcpy(j[k].y.l, raw[k].y, 32); memcpy(j[k].z.l, raw[k].z, 32); }
     }
     jac_to_affine_batch(j, count, out);                       // one field inversion for the whole batch (13 us each on the host)

@@ -89,7 +89,16 @@ extern "C" {
 const char *plk_last_error(void) { return g_last_error.c_str(); }
 const char *plk_version(void) { return "plonkit_amd 0.1 (gfx950)"; }
 
+// read by the runtimes when they initialise, i.e. at the first HIP call of the process: more hardware queues than HIP's default of 4
+// (a proof keeps 4-5 streams busy, several proofs may be in flight), and dmabuf device-memory IPC — RCCL between the per-GPU processes
+// of plk_comm_init fails with `hipIpcGetMemHandle: invalid argument` on this driver without it.  Never overrides the caller's setting.
+static void runtime_env_defaults() {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+}
+
 int32_t plk_device_count(void) {
+    runtime_env_defaults();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
@@ -98,7 +107,7 @@ int32_t plk_device_count(void) {
 int32_t plk_create(int32_t device, plk_ctx **out) {
     // up to three commitments may be in flight on three streams (MsmSlot): ask for enough hardware queues that they do not
     // share one (HIP's default is 4 per device; no effect if the runtime is already initialised by the host program)
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    runtime_env_defaults();
     if (!out) { set_error("plk_create: null out"); return PLK_ERR_ARG; }
     *out = nullptr;
     int n = 0;

@@ -261,15 +261,17 @@ def test_eight_rank_rehearsal_on_one_gpu():
 
 def test_rccl_watchdog_aborts_instead_of_hanging():
     """comm.cpp watches the RCCL exchange with a deadline (hipStreamQuery polling + ncclCommAbort) instead of a blind
-    hipStreamSynchronize: with a deadline of zero the very first poll of an exchange that is still in flight counts as a
-    dead peer.  The call must come back with PLK_ERR_HIP (not hang), later exchanges on the aborted communicator must
-    fail at once, and after plk_comm_destroy the context proves again.  (The reference panics and exits when a worker
-    fails, src/bin/main.rs:335,371,399.)"""
+    hipStreamSynchronize.  Deterministic: the test hook PLK_COMM_TEST_STALL_MS parks the exchange stream for 1.5 s before
+    every all-gather (a peer that does not answer) and the deadline is 100 ms, so the abort path MUST run: the first
+    proof comes back with PLK_ERR_HIP "RCCL exchange aborted" (within the deadline, not after the stall), the second
+    fails at once as "aborted earlier", and after plk_comm_destroy the context proves again.  (The reference panics and
+    exits when a worker fails, src/bin/main.rs:335,371,399.)"""
     import subprocess
     import sys
     code = r"""
-import os, sys
-os.environ["PLK_COMM_TIMEOUT_MS"] = "0"
+import os, sys, time
+os.environ["PLK_COMM_TIMEOUT_MS"] = "100"
+os.environ["PLK_COMM_TEST_STALL_MS"] = "1500"
 import plonkit_amd as pa
 n = 1 << 12
 ctx = pa.Context(0)
@@ -280,20 +282,21 @@ want = setup.prove(circ)
 ctx.comm_init(0, 1, pa.comm_unique_id(), 0)
 errs = []
 for _ in range(2):
+    t0 = time.perf_counter()
     try:
         setup.prove(circ)
-        errs.append("no error")
-    except Exception as e:
-        errs.append(str(e))
+        errs.append(("no error", 0, time.perf_counter() - t0))
+    except pa.PlkError as e:
+        errs.append((str(e), e.code, time.perf_counter() - t0))
 ctx.comm_destroy()
 assert setup.prove(circ) == want
-print("ERRS", errs)
+print("ERRS", repr(errs))
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     out = [ln for ln in r.stdout.splitlines() if ln.startswith("ERRS")][0]
-    # the first exchange may win the race against a 0 ms deadline on a fast box; if it lost, the second must fail fast as "aborted earlier"
-    assert "aborted" in out or "no error" in out, out
-    if "RCCL exchange aborted" in out:
-        assert "aborted earlier" in out or out.count("RCCL exchange aborted") == 2, out
+    errs = eval(out[5:])                                                # noqa: S307 — our own repr of two tuples
+    assert errs[0][1] == 4 and "RCCL exchange aborted" in errs[0][0] and "deadline" in errs[0][0], out
+    assert errs[0][2] < 1.2, "the abort must come from the 100 ms deadline, not from the end of the 1.5 s stall: %r" % (errs,)
+    assert errs[1][1] == 4 and "aborted earlier" in errs[1][0] and errs[1][2] < 0.5, out

@@ -160,3 +160,48 @@ def test_crosscheck_manifest_simple_case_is_the_reference_golden(golden_dir):
     sha = lambda name: hashlib.sha256(open(os.path.join(golden_dir, name), "rb").read()).hexdigest()
     assert m["simple"]["vk.bin"] == sha("vk.bin") and m["simple"]["proof.bin"] == sha("proof.bin") and m["simple"]["setup.key"] == sha("setup_2pow10.key")
     assert set(m) == {"simple", "poseidon_12", "poseidon_14", "poseidon_16", "long_lc"}
+
+
+def test_compiled_front_end_equals_the_python_one(golden_dir, golden_crs):
+    """the C front end of the oracle (r1cs / wtns parsers, gate synthesis with the witness, gate check, permutation by one
+    stable sort: oracle/c/oracle.c + setup_flat) — what bench.py's cpu_baseline proves from — against the Python restatement
+    pinned above: same setup polynomials and same proof bytes on the reference's `simple` circuit (its r1cs re-encoded in the
+    binary format by the product's exporter), on pinned-subset and dense synthetic circuits and on a Poseidon-shaped one
+    (constant x LC merges, 60-term chains); and the two work splits of the MSM give one group element."""
+    import json
+    import numpy as np
+    import plonkit_amd as pa
+    from tests.gen import poseidon_like as pl
+    cases = []
+    c = pa.Circuit.from_files(os.path.join(golden_dir, "circuit.r1cs.json"), os.path.join(golden_dir, "witness.json"))
+    cases.append((c.export("r1cs"), c.export("wtns")))
+    for lc in (0, 6, 12):
+        c = pa.Circuit.synthetic_ex(510, 5 + lc, 0, lc)
+        cases.append((c.export("r1cs"), c.export("wtns")))
+    ni, nv, cons, wit = pl.build(1, 1056, rp=56)
+    js = pl.as_circom_json(ni, nv, cons)
+    c = pa.Circuit(json.dumps(js).encode(), True, json.dumps([str(x) for x in wit]).encode(), True)
+    cases.append((c.export("r1cs"), c.export("wtns")))
+    crs = po.Crs(ol.crs42(1 << 12), golden_crs.g2_raw)
+    for k, (raw, wt) in enumerate(cases):
+        r1, w = po.load_r1cs_bin(raw), po.parse_wtns(wt)
+        rf, wf = po.load_r1cs_flat(raw), ol.wtns_parse(wt)
+        assert ol.fr_ints(wf) == [x % ol.R_MOD for x in w]
+        S1, S2 = po.setup(r1), po.setup_flat(rf)
+        assert (S1.N, S1.num_inputs) == (S2.N, S2.num_inputs)
+        for a, b in zip(S1.selectors + S1.sigmas, S2.selectors + S2.sigmas):
+            assert np.array_equal(a, b)
+        p1 = po.write_proof(po.prove(r1, w, crs, S1))
+        ol.MSM_SPLIT[0] = "windows"
+        try:
+            p2 = po.write_proof(po.prove(rf, wf, crs, S2))
+        finally:
+            ol.MSM_SPLIT[0] = "chunks"
+        assert p1 == p2
+        if k == 0:
+            assert p1 == open(os.path.join(golden_dir, "proof.bin"), "rb").read()
+    bad = bytearray(cases[1][1]); bad[76 + 32 * 5] ^= 1                 # a broken witness entry: the compiled gate check refuses
+    with pytest.raises(AssertionError):
+        po.prove(po.load_r1cs_flat(cases[1][0]), ol.wtns_parse(bytes(bad)), crs)
+    with pytest.raises(ValueError):
+        po.load_r1cs_flat(cases[1][0][:200])
