@@ -9,11 +9,13 @@
 //
 // Scalar multiplication on a SIMT machine: with double-and-add (or any sparse recoding) some lane of the wave has a
 // non-zero digit at nearly every bit, so the whole wave pays one addition per bit.  Fixed signed 3-bit windows make
-// all lanes add at the same 85 positions: 255 doublings + 85 additions per multiplication (3500 products instead of
-// 5800 at wave level); the window table {1,2,3,4}*B of every lane lives in LDS, limb-major (conflict-free).
+// all lanes add at the same positions; the window table {1,2,3,4}*B of every lane lives in LDS, limb-major
+// (conflict-free).  Round 1: 255 doublings + 85 additions (~3500 field products).  Round 4: the GLV endomorphism halves
+// the doubling chain — 129 doublings + 86 additions + 43 products by beta (~2400), see g1_mul_scalar / glv_dev.h.
 #include "ctx.h"
 #include "ec_dev.h"
 #include "ec29_dev.h"
+#include "glv_dev.h"
 #include "ntt.h"
 
 namespace plk {
@@ -41,8 +43,12 @@ __device__ __forceinline__ XyzzW lds_get(const uint32_t *tab, int e) {
     return p;
 }
 
-// k * b for a canonical (non-Montgomery) scalar k < 2^254.  Signed 3-bit windows, digits in [-3, 4], low to high:
-// v = window + carry; v <= 4 -> digit v; v >= 5 -> digit v - 8, carry 1 (the top window holds <= 3, so no carry leaves it).
+// k * b for a canonical (non-Montgomery) scalar k < r, by the GLV endomorphism (glv_dev.h): k = k1 + k2 lambda with
+// |k1|, |k2| < 2^128 and lambda * (x, y) = (beta x, y), so both halves share ONE chain of 129 doublings:
+//     acc <- 8 acc ; acc += d1_w * b ; acc += d2_w * phi(b)          for the 43 signed 3-bit windows, high to low,
+// d in [-3, 4] as in round 1, phi of a table entry = its x times beta (one more product).  129 doublings + 86 additions + 43
+// products by beta = ~2400 field products per multiplication instead of the ~3500 of 255 doublings + 85 additions.  The two
+// additions of a window go through ONE inlined addition site (a two-trip loop that is not unrolled: instruction cache).
 __device__ __forceinline__ XyzzW g1_mul_scalar(const XyzzW &b, const Fr &k, uint32_t *tab) {
     if (is_inf(b)) return xyzzw_identity();
     {   // table: b, 2b, 3b, 4b
@@ -55,29 +61,31 @@ __device__ __forceinline__ XyzzW g1_mul_scalar(const XyzzW &b, const Fr &k, uint
         g1_double_call(&t2);
         lds_put(tab, 3, t2);
     }
-    uint32_t dig[11];                                             // 85 digits x 4 bits: bit 3 = negative, bits 0-2 = magnitude
-#pragma unroll
-    for (int i = 0; i < 11; i++) dig[i] = 0;
-    uint32_t carry = 0;
-    for (int w = 0; w < 85; w++) {
-        const uint32_t pos = 3 * w, limb = pos >> 5, off = pos & 31;
-        uint64_t two = k.l[limb];
-        if (limb + 1 < 8) two |= (uint64_t)k.l[limb + 1] << 32;
-        uint32_t v = ((uint32_t)(two >> off) & 7u) + carry;
-        uint32_t code;
-        if (v >= 5) { code = 8u | (8u - v); carry = 1; } else { code = v; carry = 0; }
-        dig[w >> 3] |= code << (4 * (w & 7));
+    uint32_t dig[2][6];
+    uint32_t flip[2];                                             // sign of the half: XORed into the digit's sign bit
+    {
+        const GlvSplit sp = glv_split(k.l);
+        glv_digits(sp.k1, dig[0]);
+        glv_digits(sp.k2, dig[1]);
+        flip[0] = sp.neg1 ? 8u : 0u; flip[1] = sp.neg2 ? 8u : 0u;
     }
+    FqW9 beta;
+#pragma unroll
+    for (int i = 0; i < 9; i++) beta.l[i] = glv::BETA_W[i];
     XyzzW acc = xyzzw_identity();
-    for (int w = 84; w >= 0; w--) {
+    for (int w = 42; w >= 0; w--) {
         for (int r = 0; r < 3; r++) acc = xyzzw_double(acc);      // one inlined doubling site (identity passes through)
-        const uint32_t code = (dig[w >> 3] >> (4 * (w & 7))) & 15u, mag = code & 7u;
-        XyzzW t = xyzzw_identity();
-        if (mag) {
-            t = lds_get(tab, (int)mag - 1);
-            if (code & 8u) t.y = sub6(w_zero<FqW>(), t.y);         // 6p - y: y < 6p by the bounds of ec29_dev.h
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            const uint32_t code = ((dig[h][w >> 3] >> (4 * (w & 7))) & 15u), mag = code & 7u;
+            XyzzW t = xyzzw_identity();
+            if (mag) {
+                t = lds_get(tab, (int)mag - 1);
+                if (h) t.x = WM(t.x, beta);                        // phi: x -> beta x (entries are normalised, x < 6p -> < 1.04p)
+                if ((code ^ flip[h]) & 8u) t.y = sub6(w_zero<FqW>(), t.y);     // 6p - y: y < 6p by the bounds of ec29_dev.h
+            }
+            xyzzw_add(acc, t);                                    // the one inlined addition site (identity operand: no-op)
         }
-        xyzzw_add(acc, t);                                        // the one inlined addition site (identity operand: no-op)
     }
     return acc;
 }

@@ -263,6 +263,25 @@ def kernel_table(ctx, device):
     ms = (time.perf_counter() - t0) / 3 * 1e3
     out["msm_2^24"] = {"ms": round(ms, 3), "Mscalar_mul_s": round(n / ms / 1e3, 1), "algorithmic_GBs": round(96 * n / ms / 1e6, 1)}
     del s
+    # BASELINE.json configs[3] at its stated size: dump-lagrange = Crs::<Lagrange>::from_powers (src/plonk.rs:179-185), the inverse
+    # NTT over G1 of the first 2^20 points of the resident key (the 2^24-point key generated above)
+    lg = 20
+    m = 1 << lg
+    o = torch.empty((m, 8), dtype=torch.int64, device=device)
+    ctx.g1_intt_srs_dev(lg, o)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        ctx.g1_intt_srs_dev(lg, o)
+    ctx.synchronize()
+    ms = (time.perf_counter() - t0) / 2 * 1e3
+    muls = (m // 2) * lg - (m - 1) + m                                # butterflies with a twiddle != 1, + the 1/N scaling of every point
+    ec_ops = muls * (129 + 86) + (m // 2) * lg * 2                    # GLV: 129 doublings + 86 additions per multiplication; 2 additions per butterfly
+    out["g1_intt_2^20"] = {"ms": round(ms, 2), "scalar_muls": muls, "G_ec_ops_s": round(ec_ops / ms / 1e6, 2), "algorithmic_GBs": round(128 * m / ms / 1e6, 3),
+                           "hbm_frac": round(128 * m / ms / 1e6 / 8000.0, 6),
+                           "what": "2^20 points in, 2^20 Lagrange-basis points out (64 + 64 B per point algorithmic); 20 radix-2 stages of "
+                                   "254-bit scalar multiplications on group elements, GLV (129 doublings + 86 additions each): VALU-bound"}
+    del o
     if keep:
         ctx.srs_generate(keep, 0, 42)
     return out

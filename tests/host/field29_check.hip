@@ -2,6 +2,7 @@
 // compile for the host too) against the 8 x 32-bit layer (field_dev.h / ec_dev.h), which the GPU tests pin to the oracle.
 // Built and run by tests/test_field29_host.py with hipcc; needs no GPU.
 #include "ec29_dev.h"
+#include "glv_dev.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -129,5 +130,41 @@ int main() {
         (void)d;
         printf("KAT Fq "); hex(cc.l); printf(" "); hex(cc.l); printf(" "); hex(qc.l); printf("\n");
     }
-    return bad + ebad;
+    // GLV split of canonical scalars (glv_dev.h, used by the G1 iNTT): known-answer lines "GLV k |k1| neg1 |k2| neg2"
+    // (Python checks k1 + k2 lambda = k mod r and both halves < 2^128), the signed 3-bit window digits re-summed here, and
+    // phi(P) = (beta x, y) = lambda P on the 29-bit layer by double-and-add with lambda
+    int gbad = 0;
+    auto hex5 = [](const uint32_t *l) { for (int i = 4; i >= 0; i--) printf("%08x", l[i]); };
+    for (int it = 0; it < 2000; it++) {
+        Fr k = to_canonical(rnd_fp<FrParams>());
+        if (it == 0) { for (int i = 0; i < 8; i++) k.l[i] = 0; }
+        if (it == 1) { for (int i = 0; i < 8; i++) k.l[i] = FrParams::P[i]; k.l[0] -= 1; }            // r - 1
+        if (it == 2) { for (int i = 0; i < 8; i++) k.l[i] = 0; k.l[0] = 1; }
+        const GlvSplit sp = glv_split(k.l);
+        if (sp.k1[4] != 0 || sp.k2[4] != 0) { gbad++; if (gbad < 5) printf("glv half >= 2^128 at %d\n", it); }
+        for (int h = 0; h < 2; h++) {                              // digits: sum d_w 8^w must give the magnitude back
+            const uint32_t *m = h ? sp.k2 : sp.k1;
+            uint32_t dig[6]; glv_digits(m, dig);
+            __int128 acc = 0; unsigned __int128 want = 0;
+            for (int w = 42; w >= 0; w--) { const uint32_t c = (dig[w >> 3] >> (4 * (w & 7))) & 15u; const int d = (c & 8u) ? -(int)(c & 7u) : (int)(c & 7u); if ((c & 7u) > 4 || (c == 12u)) gbad++; acc = acc * 8 + d; }
+            for (int i = 3; i >= 0; i--) want = (want << 32) | m[i];
+            if (acc < 0 || (unsigned __int128)acc != want) { gbad++; if (gbad < 5) printf("glv digits mismatch at %d half %d\n", it, h); }
+        }
+        if (it < 40) { printf("GLV "); hex(k.l); printf(" "); hex5(sp.k1); printf(" %d ", sp.neg1 ? 1 : 0); hex5(sp.k2); printf(" %d\n", sp.neg2 ? 1 : 0); }
+    }
+    {
+        // lambda * P by double-and-add on the W layer against (beta x, y)
+        const uint32_t lam[8] = {0x36636f23u, 0xb8ca0b2du, 0xec2bc5e9u, 0xcc37a73fu, 0x3fd84104u, 0x048b6e19u, 0xe131a029u, 0x30644e72u};
+        FqW9 beta; for (int i = 0; i < 9; i++) beta.l[i] = glv::BETA_W[i];
+        for (int k = 0; k < 8; k++) {
+            XyzzW p; p.x = ptsw[k].x; p.y = ptsw[k].y; p.zz = w_one<FqW>(); p.zzz = w_one<FqW>();
+            XyzzW acc2 = xyzzw_identity();
+            for (int bit = 253; bit >= 0; bit--) { acc2 = xyzzw_double(acc2); if ((lam[bit >> 5] >> (bit & 31)) & 1u) xyzzw_add(acc2, p); }
+            XyzzW ph = p; ph.x = WM(p.x, beta);
+            G1Affine x = to_aff(exportw(acc2)), y = to_aff(exportw(ph));
+            if (x.x != y.x || x.y != y.y) { gbad++; printf("phi(P) != lambda P for point %d\n", k); }
+        }
+    }
+    printf("glv: %d mismatches\n", gbad);
+    return bad + ebad + gbad;
 }
