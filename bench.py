@@ -89,6 +89,23 @@ def rand_scalars(n, seed, device):
 
 
 # ------------------------------------------------------------------------------------------ CPU baselines
+def cpu_quota_cores():
+    """CPUs' worth of time the container may use per scheduling period (cgroup cpu.max / cfs quota), or None when unlimited.  The GPU
+    boxes of this pool show 256 logical CPUs (2 x EPYC 9575F) but run the job under `cpu.max = 1600000 100000`: sixteen CPUs of quota —
+    beyond ~32 runnable threads the CFS throttles the whole group every period, which is the "collapse" rounds 1-3 attributed to the
+    port's memory behaviour (profiles/r04_cpu_host_quota.txt: nr_throttled 401 of 593 periods during a thread sweep)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:                                              # noqa: BLE001
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:                                              # noqa: BLE001
+        return None
+
+
 CPU_BEST = {"split": "chunks", "threads": 16}          # filled by cpu_msm_baseline: the fastest (work split, thread count) of the port on this host
 
 
@@ -107,7 +124,8 @@ def cpu_msm_baseline(ctx, log_sample, seed):
     s[:, 3] &= np.uint64((1 << 60) - 1)
     ncpu = os.cpu_count() or 1
     ol.msm(bases[:1024], s[:1024], threads=min(ncpu, 16))     # warm the library
-    counts = sorted({min(ncpu, 16), min(ncpu, 64), min(ncpu, 128), ncpu})
+    quota = cpu_quota_cores()
+    counts = sorted({min(ncpu, 16), min(ncpu, 32), min(ncpu, 64), min(ncpu, 128), ncpu})
     best = None
     tried = {"chunks": {}, "windows": {}}
     for split in ("windows", "chunks"):
@@ -122,7 +140,7 @@ def cpu_msm_baseline(ctx, log_sample, seed):
                 best = (dt, cores, ref, split)
     dt, cores, ref, split = best
     CPU_BEST["split"], CPU_BEST["threads"] = split, cores
-    return {"value": m / dt / 1e6, "unit": "Mscalar·mul/s", "cores": cores, "kind": "port", "host_cores": ncpu, "work_split": split,
+    return {"value": m / dt / 1e6, "unit": "Mscalar·mul/s", "cores": cores, "kind": "port", "host_cores": ncpu, "host_cpu_quota_cores": quota, "work_split": split,
             "by_threads_Mscalar_mul_s": tried,
             "sample": "one dense_multiexp (c=ceil(ln n)) of 2^%d uniform scalars, %.2f s; best of %d thread counts x 2 work splits" % (log_sample, dt, len(counts))}, ref, s
 
@@ -193,7 +211,7 @@ def cpu_g1_intt_row(ctx, device, log_n=16):
     keep = ctx.srs_size()
     ctx.srs_generate(n, 0, 42)
     pts = ctx.srs_download(0, n)
-    cores = os.cpu_count() or 1
+    cores = CPU_BEST["threads"]
     t0 = time.perf_counter()
     ref = ol.g1_intt(pts, log_n, threads=cores)
     cpu_s = time.perf_counter() - t0
@@ -277,6 +295,7 @@ def cpu_prove_baseline(ctx, log_domain):
     return {"domain": 1 << log_domain, "cpu_s": round(cpu_s, 3), "cpu_c_kernels_s": round(c_s, 3), "cpu_c_share": round(c_s / cpu_s, 3),
             "cpu_setup_s": round(setup_s, 2), "cpu_parse_s": round(parse_s, 2), "cpu_whole_s": round(parse_s + setup_s + cpu_s, 1),
             "gpu_s": round(gpu_s, 5), "threads": CPU_BEST["threads"], "msm_work_split": CPU_BEST["split"], "host_cores": os.cpu_count(),
+            "host_cpu_quota_cores": cpu_quota_cores(),
             "kind": "port", "proof_bytes_identical": bool(got == ref),
             "speedup_vs_cpu_total": round(cpu_s / gpu_s, 1), "speedup_vs_cpu_c_kernels": round(c_s / gpu_s, 1),
             "sample": "one prove (synthesis + gate check, rounds 1-5: 11 MSM + 25 NTT-equivalents) of a synthetic 2^%d-gate circuit; "

@@ -87,7 +87,11 @@ long comm_test_stall_ms() {
     static const long v = [] { const char *e = getenv("PLK_COMM_TEST_STALL_MS"); return e && *e ? strtol(e, nullptr, 10) : 0L; }();
     return v;
 }
-void stall_host_fn(void *ms) { std::this_thread::sleep_for(std::chrono::milliseconds((long)(intptr_t)ms)); }
+// (a kernel, not hipLaunchHostFunc: on this runtime a host function makes the enqueueing side wait for it)
+__global__ void comm_test_stall_kernel(unsigned long long ticks) {           // wall_clock64: constant 100 MHz counter
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
 void set_timeouts(int fd) {
     timeval tv{COMM_TIMEOUT_S, 0};
     ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
@@ -113,6 +117,9 @@ struct Comm {
     ncclComm_t nccl = nullptr;
     hipStream_t stream = nullptr;            // the exchange has a stream of its own: synchronising the context's main stream
     DevBuf d_send, d_recv;                   // would wait for whatever the prover overlaps with the commitments (LDEs)
+    void *h_pin = nullptr; size_t h_pin_cap = 0;   // page-locked staging of both directions: a copy to or from PAGEABLE memory is synchronous —
+                                             // the host would sit inside hipMemcpyAsync behind a collective that never ends, and the watchdog
+                                             // below would never get to run (found with PLK_COMM_TEST_STALL_MS in round 4)
     // TCP hub transport (rank 0 listens; fds[r] = connection of rank r on the hub, fds[0] = the hub's socket on a spoke)
     bool tcp = false;
     int listen_fd = -1;
@@ -182,12 +189,23 @@ static int32_t gather(Comm *C, const plk_g1_jacobian *mine, uint32_t count, plk_
     hipStream_t st = C->stream;
     PLK_TRY(C->d_send.reserve(8 * sizeof(plk_g1_jacobian)));
     PLK_TRY(C->d_recv.reserve((size_t)C->world * 8 * sizeof(plk_g1_jacobian)));
-    PLK_HIP(hipMemcpyAsync(C->d_send.p, mine, bytes, hipMemcpyHostToDevice, st));
-    if (comm_test_stall_ms() > 0) PLK_HIP(hipLaunchHostFunc(st, stall_host_fn, (void *)(intptr_t)comm_test_stall_ms()));
+    const size_t pin_need = bytes * ((size_t)C->world + 1);
+    if (C->h_pin_cap < pin_need) {
+        if (C->h_pin) (void)hipHostFree(C->h_pin);
+        C->h_pin = nullptr; C->h_pin_cap = 0;
+        PLK_HIP(hipHostMalloc(&C->h_pin, (size_t)8 * sizeof(plk_g1_jacobian) * ((size_t)C->world + 1), hipHostMallocDefault));
+        C->h_pin_cap = (size_t)8 * sizeof(plk_g1_jacobian) * ((size_t)C->world + 1);
+    }
+    char *pin_send = static_cast<char *>(C->h_pin), *pin_recv = pin_send + bytes;
+    memcpy(pin_send, mine, bytes);
+    PLK_HIP(hipMemcpyAsync(C->d_send.p, pin_send, bytes, hipMemcpyHostToDevice, st));
+    if (comm_test_stall_ms() > 0) hipLaunchKernelGGL(comm_test_stall_kernel, dim3(1), dim3(1), 0, st, (unsigned long long)comm_test_stall_ms() * 100000ull);
     ncclResult_t e = R->AllGather(C->d_send.p, C->d_recv.p, bytes, ncclUint8, C->nccl, st);
     if (e != ncclSuccess) return rccl_fail(e, "ncclAllGather");
-    PLK_HIP(hipMemcpyAsync(all, C->d_recv.p, bytes * C->world, hipMemcpyDeviceToHost, st));
-    return watch_exchange(C, st);
+    PLK_HIP(hipMemcpyAsync(pin_recv, C->d_recv.p, bytes * C->world, hipMemcpyDeviceToHost, st));
+    PLK_TRY(watch_exchange(C, st));
+    memcpy(all, pin_recv, bytes * C->world);
+    return PLK_OK;
 }
 
 // the built-in plk_combine_fn: sums[k] <- sum over ranks of sums[k]; every rank ends with the same group elements
@@ -210,10 +228,11 @@ static int32_t builtin_combine(void *user, plk_g1_jacobian *sums, uint32_t count
 
 static void comm_free(Comm *C) {
     if (!C) return;
-    if (C->leak) { C->stream = nullptr; C->d_send.p = nullptr; C->d_recv.p = nullptr; C->nccl = nullptr; }      // see watch_exchange
+    if (C->leak) { C->stream = nullptr; C->d_send.p = nullptr; C->d_recv.p = nullptr; C->nccl = nullptr; C->h_pin = nullptr; }      // see watch_exchange
     if (C->nccl) { Rccl *R = rccl(); if (R) (void)R->CommDestroy(C->nccl); }
     if (C->stream) (void)hipStreamDestroy(C->stream);
     C->d_send.release(); C->d_recv.release();
+    if (C->h_pin) (void)hipHostFree(C->h_pin);
     for (int fd : C->fds) if (fd >= 0) ::close(fd);
     if (C->listen_fd >= 0) ::close(C->listen_fd);
     delete C;
