@@ -66,7 +66,11 @@ struct plk_ctx {
     std::map<std::vector<uint32_t>, plk::PowTable> coset_tabs;   // keyed by the 8 limbs of the shift
     std::vector<void *> coset_allocs;
     std::map<uint32_t, void *> ntt_direct;                       // ntt.hip: inter-pass twiddle tables by (direction, digit plan)
-    size_t ntt_direct_bytes = 0;                                 // what they hold together (capped: ntt.hip, NTT_DIRECT_CAP_BYTES)
+    size_t ntt_direct_bytes = 0;                                 // what they hold together (capped: ntt.hip, PLK_NTT_DIRECT_CAP_MB)
+    std::map<uint32_t, uint64_t> ntt_direct_used;                // per table: value of ntt_direct_clock at its last request (eviction order)
+    std::map<uint32_t, size_t> ntt_direct_size;
+    uint64_t ntt_direct_clock = 0;
+    struct CosetDirect { plk::DevBuf buf; uint32_t log_n = 0; } coset_direct[2];   // ntt.hip: coset-shift powers of the extensions as tables ([1]: inverse)
     std::map<std::vector<uint32_t>, plk::Fr> inv_cache;
     plk::Fr n_inv[plk::MAX_LOG_N + 1];      // 2^-k
     plk::Fr n_inv_w[plk::MAX_LOG_N + 1];    // 2^-k in the 2^261 domain

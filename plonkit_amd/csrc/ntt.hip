@@ -35,6 +35,8 @@
 #include "poly.h"
 #include "field29_dev.h"
 #include <cstdlib>
+#include <algorithm>
+#include <vector>
 
 namespace plk {
 
@@ -58,7 +60,10 @@ struct NttPassArgs {
     const Fr *tw_direct;                       // optional (ntt_pass_cols): the inter-pass twiddles of this pass as a table,
                                                // entry (k << log_inner | column), W domain, 1/n folded in on inverse transforms
     uint32_t quarter;                          // first pass of an LDE by 4 with an even number of stages: only every fourth
-};                                             // (bit-reversed) row is non-zero, the first pair of stages is a broadcast
+                                               // (bit-reversed) row is non-zero, the first pair of stages is a broadcast
+    const Fr *pre_direct_b[NTT_MAX_BATCH];     // optional, per transform: pre^i as a table of its own (W domain), index = element index:
+    const Fr *post_direct_b[NTT_MAX_BATCH];    // one load + one product per element instead of two loads + two products (the composition
+};                                             // lo[e & 16383] * hi[e >> 14] is itself a product) — the coset shifts of the prover's extensions
 
 // ---- all butterfly arithmetic runs on the carry-free 9 x 29-bit layer (field29_dev.h): data words are
 // ---- re-sliced, never converted; the constants (twiddles, coset powers, 1/n) live in its 2^261 domain.
@@ -198,6 +203,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
     const Fr *const in = a.in_b[blockIdx.y];
     Fr *const out = a.out_b[blockIdx.y];
     const PowTable pre = a.pre_b[blockIdx.y];
+    const Fr *const pre_direct = a.pre_direct_b[blockIdx.y];
     const uint32_t tiles_log = a.log_inner - log_c;
     const uint32_t o = t >> tiles_log, c0 = (t & ((1u << tiles_log) - 1)) << log_c;
     const size_t base = ((size_t)o << (log_r + a.log_inner)) + c0;
@@ -208,7 +214,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
         FrW9 v = w_zero<FrW>();
         if (!a.nonzero || g < a.nonzero) {
             v = ldw(in + g);
-            if (pre.lo) v = mulw(v, pow2l_w(pre, (uint32_t)g));
+            if (pre_direct) v = mulw(v, ldw(pre_direct + g));
+            else if (pre.lo) v = mulw(v, pow2l_w(pre, (uint32_t)g));
         }
         L.put(idx, v);
     }
@@ -237,6 +244,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
     const Fr *const in = a.in_b[blockIdx.y];
     Fr *const out = a.out_b[blockIdx.y];
     const PowTable pre = a.pre_b[blockIdx.y], post = a.post_b[blockIdx.y];
+    const Fr *const pre_direct = a.pre_direct_b[blockIdx.y], *const post_direct = a.post_direct_b[blockIdx.y];
     const uint32_t kb_log = a.log_r1 - log_c, log_m = a.log_m1 + a.log_m2;
     const uint32_t k1_0 = (t & ((1u << kb_log) - 1)) << log_c, mu = t >> kb_log;
 
@@ -247,7 +255,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
         FrW9 v = w_zero<FrW>();
         if (!a.nonzero || g < a.nonzero) {
             v = ldw(in + g);
-            if (pre.lo) v = mulw(v, pow2l_w(pre, (uint32_t)g));
+            if (pre_direct) v = mulw(v, ldw(pre_direct + g));
+            else if (pre.lo) v = mulw(v, pow2l_w(pre, (uint32_t)g));
         }
         L.put(brev(n, log_r) * C + c, v);                                    // bit reversal as an LDS scatter
     }
@@ -260,7 +269,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
         uint32_t c = idx & (C - 1), k = idx >> log_c;
         size_t o = (size_t)(k1_0 + c) + (drev << a.log_r1) + ((size_t)k << (a.log_n - log_r));
         FrW9 v = L.get(k * C + c);
-        if (post.lo) v = mulw(v, pow2l_w(post, (uint32_t)o));
+        if (post_direct) v = mulw(v, ldw(post_direct + o));
+        else if (post.lo) v = mulw(v, pow2l_w(post, (uint32_t)o));
         v = a.has_scale ? csub_p(mulw(v, last)) : reduce_small(v);          // canonical output (values here are < 24p)
         store_fp(out + o, pack<FrParams>(v));
     }
@@ -424,18 +434,32 @@ static int32_t ntt_direct_table(plk_ctx *ctx, bool inverse, uint32_t log_r, uint
     const uint32_t bits = log_r + log_inner;
     if (!ntt_direct_enabled() || MAX_LOG_N - bits >= POW_SPLIT || bits > NTT_DIRECT_MAX_LOG) return PLK_OK;
     const uint32_t key = (inverse ? 1u << 31 : 0) | (scaled ? log_n << 16 : 0) | log_r << 8 | log_inner;
+    ctx->ntt_direct_clock++;
     auto it = ctx->ntt_direct.find(key);
-    if (it != ctx->ntt_direct.end()) { *out = static_cast<const Fr *>(it->second); return PLK_OK; }
-    // A long-lived context that proves many domain sizes would otherwise collect tables for ever (up to 1 GiB each): when
-    // the next one would take the total past the cap, every table is dropped first — after the device has drained, since
-    // passes in flight on any stream may still be reading them — and the sizes in use come back on demand.
+    if (it != ctx->ntt_direct.end()) { ctx->ntt_direct_used[key] = ctx->ntt_direct_clock; *out = static_cast<const Fr *>(it->second); return PLK_OK; }
+    // A long-lived context that proves many domain sizes would otherwise collect tables for ever (up to 1 GiB each).  When the next
+    // one would take the total past the cap, the tables that have not been asked for during the last NTT_DIRECT_KEEP requests (about
+    // two proofs' worth) go, oldest first, until it fits — after the device has drained, since passes in flight on any stream may
+    // still be reading them.  Tables of the plan in use are never dropped: if they alone fill the cap (a small
+    // PLK_NTT_DIRECT_CAP_MB, or one proof whose shapes exceed it) the new pass composes its twiddles instead — round 3 dropped
+    // everything, which made such a proof rebuild its tables, and stall every stream, on every pass.
     static const size_t cap = [] { const char *e = getenv("PLK_NTT_DIRECT_CAP_MB"); size_t mb = e ? strtoull(e, nullptr, 10) : 0; return (mb ? mb : 6144) << 20; }();
     const size_t want = sizeof(Fr) << bits;
-    if (ctx->ntt_direct_bytes + want > cap && !ctx->ntt_direct.empty()) {
+    if (ctx->ntt_direct_bytes + want > cap) {
+        constexpr uint64_t NTT_DIRECT_KEEP = 96;
+        std::vector<std::pair<uint64_t, uint32_t>> idle;             // (last use, key) of the evictable tables
+        for (auto &kv : ctx->ntt_direct) { const uint64_t u = ctx->ntt_direct_used[kv.first]; if (u + NTT_DIRECT_KEEP < ctx->ntt_direct_clock) idle.emplace_back(u, kv.first); }
+        std::sort(idle.begin(), idle.end());
+        size_t freed = 0;
+        for (auto &e : idle) { if (ctx->ntt_direct_bytes - freed + want <= cap) break; freed += ctx->ntt_direct_size[e.second]; }
+        if (ctx->ntt_direct_bytes - freed + want > cap) return PLK_OK;            // the tables in use fill the cap: compose
         PLK_HIP(hipDeviceSynchronize());
-        for (auto &kv : ctx->ntt_direct) (void)hipFree(kv.second);
-        ctx->ntt_direct.clear();
-        ctx->ntt_direct_bytes = 0;
+        for (auto &e : idle) {
+            if (ctx->ntt_direct_bytes + want <= cap) break;
+            (void)hipFree(ctx->ntt_direct[e.second]);
+            ctx->ntt_direct_bytes -= ctx->ntt_direct_size[e.second];
+            ctx->ntt_direct.erase(e.second); ctx->ntt_direct_used.erase(e.second); ctx->ntt_direct_size.erase(e.second);
+        }
     }
     Fr *buf = nullptr;
     if (hipMalloc(&buf, want) != hipSuccess) { (void)hipGetLastError(); return PLK_OK; }   // no room: compose
@@ -445,6 +469,8 @@ static int32_t ntt_direct_table(plk_ctx *ctx, bool inverse, uint32_t log_r, uint
     PLK_HIP(hipGetLastError());
     PLK_HIP(hipStreamSynchronize(stream));                 // other streams may use the table right after this call
     ctx->ntt_direct[key] = buf;
+    ctx->ntt_direct_used[key] = ctx->ntt_direct_clock;
+    ctx->ntt_direct_size[key] = want;
     ctx->ntt_direct_bytes += want;
     *out = buf;
     return PLK_OK;
@@ -475,7 +501,8 @@ static void digit_plan(uint32_t log_n, uint32_t d[4], uint32_t *passes) {
 // `lane` selects the ping-pong scratch: transforms enqueued on different streams at the same time must not share it
 // (lane 1 = the prover's background stream).
 static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr *const *data, uint32_t count, uint32_t log_n, bool inverse,
-                       const Fr *coset, hipStream_t stream, uint32_t lane, const PowTable *pre_each = nullptr, const PowTable *post_each = nullptr);
+                       const Fr *coset, hipStream_t stream, uint32_t lane, const PowTable *pre_each = nullptr, const PowTable *post_each = nullptr,
+                       const Fr *const *pre_direct = nullptr, const Fr *const *post_direct = nullptr);
 
 int32_t ntt_dev(plk_ctx *ctx, Fr *data, uint32_t log_n, bool inverse, const Fr *coset, hipStream_t stream) {
     const Fr *src = data;
@@ -496,7 +523,8 @@ int32_t ntt_batch_dev(plk_ctx *ctx, Fr *const *data, uint32_t count, uint32_t lo
 // pre_each / post_each: one input- / output-scaling table per transform of the batch (the four cosets of lde4cm_batch_dev and
 // of icoset4cm_dev) instead of `coset`
 static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr *const *data, uint32_t count, uint32_t log_n, bool inverse,
-                       const Fr *coset, hipStream_t stream, uint32_t lane, const PowTable *pre_each, const PowTable *post_each) {
+                       const Fr *coset, hipStream_t stream, uint32_t lane, const PowTable *pre_each, const PowTable *post_each,
+                       const Fr *const *pre_direct, const Fr *const *post_direct) {
     if (!data || !src || count == 0 || count > NTT_MAX_BATCH || lane >= 2) { set_error("ntt: bad argument"); return PLK_ERR_ARG; }
     for (uint32_t b = 0; b < count; b++) if (!data[b] || !src[b]) { set_error("ntt: null data"); return PLK_ERR_ARG; }
     if (log_n > MAX_LOG_N) { set_error("ntt: log_n exceeds the 2-adicity of Fr (28)"); return PLK_ERR_SIZE; }
@@ -532,6 +560,7 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
         a.log_c = (LOG_TILE - d[i]) < rem ? (LOG_TILE - d[i]) : rem;
         for (uint32_t b = 0; b < count; b++) a.pre_b[b] = (i == 0) ? (pre_each ? pre_each[b] : pre) : PowTable{};
         for (uint32_t b = 0; b < count; b++) a.post_b[b] = PowTable{};
+        for (uint32_t b = 0; b < count; b++) { a.pre_direct_b[b] = (i == 0 && pre_direct) ? pre_direct[b] : nullptr; a.post_direct_b[b] = nullptr; }
         a.has_scale = 0;
         PLK_TRY(ntt_direct_table(ctx, inverse, d[i], rem, inverse && i == 0, log_n, stream, &a.tw_direct));
         if (a.tw_direct && inverse && i == 0) scale_folded = true;
@@ -553,6 +582,7 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
         }
         for (uint32_t b = 0; b < count; b++) a.pre_b[b] = (p == 1) ? (pre_each ? pre_each[b] : pre) : PowTable{};
         for (uint32_t b = 0; b < count; b++) a.post_b[b] = post_each ? post_each[b] : post;
+        for (uint32_t b = 0; b < count; b++) { a.pre_direct_b[b] = (p == 1 && pre_direct) ? pre_direct[b] : nullptr; a.post_direct_b[b] = post_direct ? post_direct[b] : nullptr; }
         a.tw_direct = nullptr; a.quarter = 0;
         a.has_scale = (inverse && !scale_folded) ? 1 : 0;
         if (a.has_scale) a.scale = ctx->n_inv_w[log_n];
@@ -562,6 +592,39 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
     }
     PLK_HIP(hipGetLastError());
     if (p == 1) for (uint32_t b = 0; b < count; b++) PLK_HIP(hipMemcpyAsync(data[b], scratch + (size_t)b * n, n * sizeof(Fr), hipMemcpyDeviceToDevice, stream));
+    return PLK_OK;
+}
+
+// ------------------------------------------------------------------------------- coset-shift tables of the prover's extensions
+// lde4cm_batch_dev scales the input of coset k by g_k^i (g_k = 7 * omega_4n^k), icoset4cm_dev the output by g_k^-j.  From the
+// two-level power table that is two loads and TWO products per element (the composition lo * hi is a product itself) — a fifth
+// of the arithmetic of an extension, whose passes are bound by instruction issue at 5 % of the HBM bandwidth.  For these two
+// callers the powers are kept as tables of their own: 4 x n entries per (log_n, direction), W domain, built at first use.
+// 128 MiB at 2^20; above 2^24 (2 GiB) the passes compose as before.  One entry per direction is kept (the domain in use).
+__global__ void ntt_fill_coset_direct(Fr *out, PowTable t0, PowTable t1, PowTable t2, PowTable t3, uint32_t log_n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> (log_n + 2)) return;
+    const uint32_t k = (uint32_t)(i >> log_n), e = (uint32_t)i & ((1u << log_n) - 1);
+    const PowTable &t = k == 0 ? t0 : (k == 1 ? t1 : (k == 2 ? t2 : t3));
+    store_fp(out + i, pack<FrParams>(csub_p(pow2l_w(t, e))));
+}
+static int32_t coset_direct_tables(plk_ctx *ctx, uint32_t log_n, bool inverse, const PowTable tabs[4], hipStream_t stream, const Fr *out[4]) {
+    for (int k = 0; k < 4; k++) out[k] = nullptr;
+    static const bool on = [] { const char *e = getenv("PLK_NTT_COSET_DIRECT"); return !(e && e[0] == '0'); }();       // A/B knob
+    if (!on || !ntt_direct_enabled() || log_n > 24 || log_n <= POW_SPLIT) return PLK_OK;      // (<= 2^14 points: the low table alone holds the power)
+    plk_ctx::CosetDirect &C = ctx->coset_direct[inverse ? 1 : 0];
+    const size_t n = (size_t)1 << log_n;
+    if (C.log_n != log_n || !C.buf.p) {
+        if (C.buf.p) PLK_HIP(hipDeviceSynchronize());        // passes of another domain may still be reading the old tables
+        C.log_n = 0;
+        if (C.buf.cap < 4 * n * sizeof(Fr)) C.buf.release();
+        if (C.buf.reserve(4 * n * sizeof(Fr)) != PLK_OK) { (void)hipGetLastError(); return PLK_OK; }       // no room: compose
+        hipLaunchKernelGGL(ntt_fill_coset_direct, dim3((uint32_t)((4 * n + 255) / 256)), dim3(256), 0, stream, C.buf.as<Fr>(), tabs[0], tabs[1], tabs[2], tabs[3], log_n);
+        PLK_HIP(hipGetLastError());
+        PLK_HIP(hipStreamSynchronize(stream));               // other streams may use the tables right after this call
+        C.log_n = log_n;
+    }
+    for (int k = 0; k < 4; k++) out[k] = C.buf.as<Fr>() + (size_t)k * n;
     return PLK_OK;
 }
 
@@ -597,7 +660,9 @@ int32_t icoset4cm_dev(plk_ctx *ctx, Fr *data_4n, uint32_t log_n, hipStream_t str
     }
     const Fr *src[4]; Fr *dst[4];
     for (uint32_t k = 0; k < 4; k++) { src[k] = data_4n + k * n; dst[k] = data_4n + k * n; }
-    return ntt_run(ctx, src, 0, dst, 4, log_n, true, nullptr, stream, lane, nullptr, post);
+    const Fr *direct[4];
+    PLK_TRY(coset_direct_tables(ctx, log_n, true, post, stream, direct));
+    return ntt_run(ctx, src, 0, dst, 4, log_n, true, nullptr, stream, lane, nullptr, post, nullptr, direct[0] ? direct : nullptr);
 }
 
 int32_t lde4_dev(plk_ctx *ctx, const Fr *coeffs, uint32_t log_n, Fr *out_4n, hipStream_t stream) {
@@ -622,15 +687,17 @@ int32_t lde4cm_batch_dev(plk_ctx *ctx, const Fr *const *coeffs, uint32_t count, 
         const Fr w = ntt_omega(log_n + 2);
         for (int k = 0; k < 4; k++) { PLK_TRY(ntt_coset_table(ctx, g, &pre[k])); g = mul(g, w); }
     }
+    const Fr *direct[4];
+    PLK_TRY(coset_direct_tables(ctx, log_n, false, pre, stream, direct));
     // polynomials per launch: 4 transforms each, at most NTT_MAX_BATCH per launch and 2 GiB of ping-pong scratch
     uint32_t per = NTT_MAX_BATCH / 4;
     while (per > 1 && (size_t)per * 4 * n * sizeof(Fr) > ((size_t)2 << 30)) per--;
     for (uint32_t done = 0; done < count;) {
         const uint32_t b = count - done > per ? per : count - done;
-        const Fr *src[NTT_MAX_BATCH]; Fr *dst[NTT_MAX_BATCH]; PowTable pe[NTT_MAX_BATCH];
+        const Fr *src[NTT_MAX_BATCH]; Fr *dst[NTT_MAX_BATCH]; PowTable pe[NTT_MAX_BATCH]; const Fr *pd[NTT_MAX_BATCH];
         for (uint32_t q = 0; q < b; q++)
-            for (uint32_t k = 0; k < 4; k++) { src[4 * q + k] = coeffs[done + q]; dst[4 * q + k] = out_4n[done + q] + k * n; pe[4 * q + k] = pre[k]; }
-        PLK_TRY(ntt_run(ctx, src, 0, dst, 4 * b, log_n, false, nullptr, stream, lane, pe));
+            for (uint32_t k = 0; k < 4; k++) { src[4 * q + k] = coeffs[done + q]; dst[4 * q + k] = out_4n[done + q] + k * n; pe[4 * q + k] = pre[k]; pd[4 * q + k] = direct[k]; }
+        PLK_TRY(ntt_run(ctx, src, 0, dst, 4 * b, log_n, false, nullptr, stream, lane, pe, nullptr, direct[0] ? pd : nullptr));
         done += b;
     }
     return PLK_OK;

@@ -34,14 +34,41 @@ __global__ void __launch_bounds__(64) k_rs_hist(const uint32_t *keys, uint32_t n
 }
 
 // exclusive scan of the whole (digit, tile) table in place, digit-major: entry (d, t) becomes the number of elements with a
-// smaller digit plus those with digit d in earlier tiles — the first output position of tile t's digit-d elements
-__global__ void __launch_bounds__(1024) k_rs_scan(uint32_t *table, uint32_t total) {
-    __shared__ uint32_t sums[1024];
-    const uint32_t tid = threadIdx.x, per = (total + 1023) / 1024;
-    uint32_t lo = tid * per, hi = lo + per < total ? lo + per : total;
-    if (lo > total) lo = total;
+// smaller digit plus those with digit d in earlier tiles — the first output position of tile t's digit-d elements.
+// Two levels since round 4 (rounds 1-3: ONE 1024-thread workgroup walking the table with a per-thread stride — 0.39 ms per pass
+// at the 2^20 domain, the slowest kernel of the sort, and uncoalesced tens of megabytes at 2^26): blocks of 2048 words scanned
+// in parallel with coalesced 16-byte accesses, their totals scanned by one workgroup, the offsets added back.
+constexpr uint32_t RS_SCAN_BLOCK = 2048, RS_SCAN_THREADS = 256;     // 8 words per thread
+__global__ void __launch_bounds__(RS_SCAN_THREADS) k_rs_scan_blocks(uint32_t *table, uint32_t total, uint32_t *block_sums) {
+    __shared__ uint32_t sums[RS_SCAN_THREADS];
+    const uint32_t tid = threadIdx.x, base = blockIdx.x * RS_SCAN_BLOCK + tid * 8;
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = base + k < total ? table[base + k] : 0;
     uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += table[i];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const uint32_t c = v[k]; v[k] = s; s += c; }
+    sums[tid] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < RS_SCAN_THREADS; off <<= 1) {
+        const uint32_t x = tid >= off ? sums[tid - off] : 0;
+        __syncthreads();
+        sums[tid] += x;
+        __syncthreads();
+    }
+    const uint32_t before = tid ? sums[tid - 1] : 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (base + k < total) table[base + k] = v[k] + before;
+    if (tid == RS_SCAN_THREADS - 1) block_sums[blockIdx.x] = sums[tid];
+}
+// exclusive scan of the block totals in place (one workgroup; up to 2^28 / 4096 * 256 / 2048 = 8192 of them)
+__global__ void __launch_bounds__(1024) k_rs_scan_tops(uint32_t *block_sums, uint32_t nblocks) {
+    __shared__ uint32_t sums[1024];
+    const uint32_t tid = threadIdx.x, per = (nblocks + 1023) / 1024;
+    uint32_t lo = tid * per, hi = lo + per < nblocks ? lo + per : nblocks;
+    if (lo > nblocks) lo = nblocks;
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += block_sums[i];
     sums[tid] = s;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
@@ -51,7 +78,14 @@ __global__ void __launch_bounds__(1024) k_rs_scan(uint32_t *table, uint32_t tota
         __syncthreads();
     }
     uint32_t run = tid ? sums[tid - 1] : 0;
-    for (uint32_t i = lo; i < hi; i++) { const uint32_t c = table[i]; table[i] = run; run += c; }
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t c = block_sums[i]; block_sums[i] = run; run += c; }
+}
+__global__ void __launch_bounds__(RS_SCAN_THREADS) k_rs_scan_add(uint32_t *table, uint32_t total, const uint32_t *block_sums) {
+    const uint32_t add = block_sums[blockIdx.x];
+    if (!add) return;
+    const uint32_t base = blockIdx.x * RS_SCAN_BLOCK + threadIdx.x * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (base + k < total) table[base + k] += add;
 }
 
 // one wave per tile, elements in index order, 64 at a time: lanes holding the same digit find each other with eight
@@ -85,7 +119,7 @@ __global__ void __launch_bounds__(64) k_rs_scatter(const uint32_t *keys, const u
 }
 
 // stable sort of n (key, value) pairs by the low `bits` bits of the key; the result lands in (keys_out, vals_out); the inputs are
-// clobbered (ping-pong).  scratch: 256 * tiles words.
+// clobbered (ping-pong).  scratch: 256 * tiles words + one word per 2048 of them (block totals of the scan).
 static int32_t radix_sort_pairs_stable(uint32_t *keys, uint32_t *vals, uint32_t *keys_out, uint32_t *vals_out, uint32_t n, uint32_t bits,
                                        uint32_t *scratch, hipStream_t st) {
     const uint32_t tiles = (n + RS_TILE - 1) / RS_TILE;
@@ -100,7 +134,15 @@ static int32_t radix_sort_pairs_stable(uint32_t *keys, uint32_t *vals, uint32_t 
     }
     for (uint32_t p = 0; p < passes; p++) {
         hipLaunchKernelGGL(k_rs_hist, dim3(tiles), dim3(64), 0, st, (const uint32_t *)keys, n, 8 * p, tiles, scratch);
-        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, st, scratch, 256 * tiles);
+        {
+            const uint32_t total = 256 * tiles, nblocks = (total + RS_SCAN_BLOCK - 1) / RS_SCAN_BLOCK;
+            uint32_t *block_sums = scratch + total;
+            hipLaunchKernelGGL(k_rs_scan_blocks, dim3(nblocks), dim3(RS_SCAN_THREADS), 0, st, scratch, total, block_sums);
+            if (nblocks > 1) {
+                hipLaunchKernelGGL(k_rs_scan_tops, dim3(1), dim3(1024), 0, st, block_sums, nblocks);
+                hipLaunchKernelGGL(k_rs_scan_add, dim3(nblocks), dim3(RS_SCAN_THREADS), 0, st, scratch, total, (const uint32_t *)block_sums);
+            }
+        }
         hipLaunchKernelGGL(k_rs_scatter, dim3(tiles), dim3(64), 0, st, (const uint32_t *)keys, (const uint32_t *)vals, n, 8 * p, tiles,
                            (const uint32_t *)scratch, keys_out, vals_out);
         uint32_t *t = keys; keys = keys_out; keys_out = t;
@@ -146,7 +188,7 @@ int32_t build_permutation_index(plk_ctx *ctx, const uint32_t *const vars[4], uin
     const uint32_t tiles = (n4 + RS_TILE - 1) / RS_TILE;
     DevBuf buf;
     const size_t arr = ((size_t)n4 * 4 + 255) & ~(size_t)255;
-    PLK_TRY(buf.reserve(4 * arr + (size_t)256 * tiles * 4 + 256));
+    PLK_TRY(buf.reserve(4 * arr + (size_t)256 * tiles * 4 + ((size_t)256 * tiles / RS_SCAN_BLOCK + 2) * 4 + 256));
     uint32_t *keys = buf.as<uint32_t>(), *vals = keys + arr / 4, *skeys = vals + arr / 4, *svals = skeys + arr / 4;
     uint32_t *scratch = svals + arr / 4;
     const uint32_t blocks = (n4 + 255) / 256;

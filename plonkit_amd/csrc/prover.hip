@@ -434,10 +434,16 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     // un-pinning when the process ends: worth it from the second proof of the same circuit object on, not for the
     // one-proof-per-process pattern of the CLI (profiles/r02_cli_scale.txt: 0.36 -> 0.29 s whole `plonkit prove`)
     static const int reg_mode = [] { const char *e = getenv("PLK_HOST_REGISTER"); return !e ? 1 : (!strcmp(e, "always") ? 0 : (!strcmp(e, "never") ? 1 << 30 : 1)); }();
+    // Only a witness that owns its pages is page-locked: >= 4 MB sits in a 2 MiB-aligned block of its own (circuit.h, HugeAlloc).
+    // A small one lives on the malloc heap and shares its 4 KiB pages with unrelated objects — numpy buffers, other circuits'
+    // witnesses — that the runtime locks and unlocks on its own for pageable copies; pinning and unpinning such pages behind its
+    // back ended, once in two or three runs of the whole GPU test suite, in "Memory access fault by GPU ... on address <heap page>"
+    // during a LATER, unrelated host-to-device copy (round 4; profiles/r04_host_register_fault.txt).  A small upload gains nothing anyway.
     {
         std::lock_guard<std::mutex> reg_lock(c->reg_mu);
-        if (!c->witness_registered && (int)(c->proofs_started++) >= reg_mode) {
-            if (hipHostRegister((void *)c->witness.data(), c->witness.size() * sizeof(HFr), hipHostRegisterDefault) == hipSuccess) c->witness_registered = true;
+        const size_t wit_bytes = c->witness.size() * sizeof(HFr);
+        if (!c->witness_registered && wit_bytes >= ((size_t)4 << 20) && (int)(c->proofs_started++) >= reg_mode) {
+            if (hipHostRegister((void *)c->witness.data(), wit_bytes, hipHostRegisterDefault) == hipSuccess) c->witness_registered = true;
             else (void)hipGetLastError();                                    // not fatal: the copy is just slower
         }
     }

@@ -145,6 +145,7 @@ void plk_destroy(plk_ctx *ctx) {
     srs_return_loan(ctx);
     for (void *p : ctx->coset_allocs) (void)hipFree(p);
     for (auto &kv : ctx->ntt_direct) (void)hipFree(kv.second);
+    ctx->coset_direct[0].buf.release(); ctx->coset_direct[1].buf.release();
     ctx->tables.release(); ctx->ntt_scratch[0].release(); ctx->ntt_scratch[1].release(); ctx->srs_own.release(); ctx->srs_w.release(); ctx->lag.own.release(); ctx->lag.w.release();
     for (auto &S : ctx->slot) {
         S.a.release(); S.b.release(); S.c.release(); S.d.release(); S.e.release(); S.f.release();

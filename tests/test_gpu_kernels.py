@@ -372,3 +372,37 @@ def test_batches_in_flight(ctx, srs16):
     assert [o.shape[0] for o in outs] == [3, 3, 1]
     got = [o[k] for o in outs for k in range(o.shape[0])]
     assert all(np.array_equal(g, s) for g, s in zip(got, single + single[:1]))
+
+
+def test_ntt_twiddle_table_cap_evicts_idle_tables_and_composes_when_full():
+    """ntt.hip keeps the inter-pass twiddles of a (direction, digit plan) as a table, under a cap (PLK_NTT_DIRECT_CAP_MB).  With a
+    64 MB cap: 2^20 transforms (32 MB per table, forward + inverse fill the cap) stay bit-exact against the oracle when a 2^21
+    transform (64 MB: does not fit beside tables in recent use -> its passes compose their twiddles), then >= 96 further requests
+    (the idle 2^20 tables become evictable and are dropped for the 2^21 one), then 2^20 again (rebuilt) are interleaved; and
+    PLK_NTT_DIRECT=0 (no tables at all) gives the same bits."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+import numpy as np, torch
+import plonkit_amd as pa
+from oracle import oracle_lib as ol
+ctx = pa.Context(0)
+def run(log_n, inverse, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 1 << 62, size=(1 << log_n, 4), dtype=np.uint64); a[:, 3] &= np.uint64((1 << 60) - 1)
+    t = torch.from_numpy(a.view(np.int64)).to("cuda:0")
+    ctx.ntt_dev(t, log_n, inverse=inverse); ctx.synchronize()
+    return a, t.cpu().numpy().view(np.uint64)
+checks = []
+for step, (log_n, inv) in enumerate([(20, False), (20, True), (21, False), (20, False)] + [(21, True)] * 100 + [(21, False), (20, True), (20, False)]):
+    a, got = run(log_n, inv, step)
+    if step < 6 or step > 100:
+        checks.append(bool(np.array_equal(got, ol.ntt(a, log_n, inverse=inv))))
+print("CHECKS", all(checks), len(checks))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({"PLK_NTT_DIRECT_CAP_MB": "64"}, {"PLK_NTT_DIRECT": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        assert "CHECKS True" in r.stdout, r.stdout[-500:]
