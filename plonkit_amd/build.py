@@ -18,6 +18,14 @@ CLI = os.path.join(LIBDIR, "plonkit")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result", "-DPLK_BUILD"]
+# experiments only (tools/ab_flags.sh): extra compiler flags for every source, or for the sources named in PLK_HIPCC_EXTRA_FILES
+_EXTRA, _EXTRA_FILES = os.environ.get("PLK_HIPCC_EXTRA", "").split(), [f for f in os.environ.get("PLK_HIPCC_EXTRA_FILES", "").split(",") if f]
+if not _EXTRA_FILES:
+    FLAGS += _EXTRA
+# per-source flags: the bucket accumulation is scheduled for ILP (-2.2 % on that kernel, same-box A/B in
+# profiles/r04_msm_accumulate_sched_ab.txt; the same flag on the whole library makes a proof 0.3 ms slower)
+FILE_FLAGS = {"msm_accumulate.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+              "g1ntt.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}         # dump-lagrange: 192.0 -> 188.8 ms at 2^20, same file
 
 
 def _sources():
@@ -30,7 +38,7 @@ def _headers_digest():
         for f in sorted(os.listdir(root)):
             if f.endswith(".h"):
                 h.update(open(os.path.join(root, f), "rb").read())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(FILE_FLAGS.items())) + repr((_EXTRA, _EXTRA_FILES))).encode())
     return h.hexdigest()[:16]
 
 
@@ -39,7 +47,7 @@ def _compile(src, digest, verbose):
     srcp = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(srcp):
         return obj
-    cmd = ["hipcc"] + FLAGS + ["-x", "hip", "-c", srcp, "-o", obj]
+    cmd = ["hipcc"] + FLAGS + FILE_FLAGS.get(src, []) + (_EXTRA if src in _EXTRA_FILES else []) + ["-x", "hip", "-c", srcp, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

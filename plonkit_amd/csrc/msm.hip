@@ -32,9 +32,7 @@
 //     the digit / partition kernels of the one after next share the GPU with the accumulation in between.
 // No MFMA (256-bit modular integers), bound by v_mad_u64_u32 issue; HBM sees the algorithmic 96 B/term plus the
 // per-window gathers (64 B x W per term) from the table.
-#include "ctx.h"
-#include "ec_dev.h"
-#include "ec29_dev.h"
+#include "msm_shape.h"
 #include "msm.h"
 #include "hostmath.h"
 #include <cstring>
@@ -42,41 +40,6 @@
 #include <type_traits>
 
 namespace plk {
-
-constexpr int MSM_THREADS = 256;
-// Buckets per accumulate workgroup = 2^FB ("fine" part of the bucket index; the coarse part selects the bin).  Two shapes
-// are compiled (template parameter FB of the kernels below) and chosen per commitment by pick_fine_bits():
-//   FB = 6: 64 buckets per task.  At c = 17 that is 1024 coarse bins of ~15 K entries at 2^20 terms = ONE task per bin,
-//           so every bucket is reduced once (65 K task-buckets) — the bucket reduction (msm_task_reduce) is not a latency
-//           detail: in VALU work it was 38 % of the accumulation (992 waves x 37 dependent full additions of 14 products
-//           against 15.7 M mixed additions of 9.3), and it shares the GPU with the next commitment's accumulation.
-//   FB = 7: 128 buckets per task, 512 bins of ~31 K entries = two tasks per bin (131 K task-buckets): the round-1 shape.
-constexpr uint32_t FINE_BITS_MAX = 7;
-constexpr uint32_t CHUNK = 16384;                // entries per accumulate workgroup (sorted in 64 KB of LDS; two workgroups per CU)
-constexpr uint32_t DIGIT_CHUNK = 16384;            // scalars per partition workgroup (per window): 64 KB of LDS staging
-constexpr uint32_t TASK_MAX = CHUNK;
-                   // per-chunk bucket population handled cooperatively
-
-constexpr uint32_t MSM_MAX_BATCH = 8;              // commitments sharing one pass over the same bases
-
-struct MsmParams {
-    uint32_t n;
-    uint32_t c;               // window bits
-    uint32_t windows;         // W per commitment
-    uint32_t fine_bits;       // FB: buckets per accumulate task = 2^FB
-    uint32_t coarse_bits;     // c - 1 - fine_bits
-    uint32_t nbins;           // 1 << coarse_bits
-    uint32_t batch;           // number of scalar vectors (same n, same bases); "global window" = m * W + w
-    uint32_t debug;           // experiments only: 1 = skip the additions (sort cost), 0 = normal
-    // Shifted copies of the bases (fixed-base precomputation): window w = j*groups + g takes its points from
-    // copy j*groups of the table (2^(16*j*groups) * P_i) and drops them into bucket set g, so only `groups`
-    // bucket sets have to be reduced and only c*groups doublings are left for the host Horner.
-    uint32_t groups;          // bucket sets per commitment (= windows when there is one copy)
-    uint32_t nbits;           // entry index = (j << nbits) | i
-    uint32_t copy_stride;     // points between table copies j and j+1 (= groups * srs_n)
-};
-
-struct ScalarSet { const Fr *v[MSM_MAX_BATCH]; };
 
 // -------------------------------------------------------------------------- scalar recoding
 __device__ __forceinline__ uint32_t extract_bits(const uint32_t *k, uint32_t pos, uint32_t c) {
@@ -462,111 +425,8 @@ static int32_t ensure_base_table(plk_ctx *ctx, uint32_t copies, hipStream_t stre
     return PLK_OK;
 }
 
-// Per-task output of kernel A: 128 PRIMARY slots (a bucket whose run lies inside one lane's slice), and per
-// lane one HEAD slot (its first run continues a bucket begun by an earlier lane) and one TAIL slot (its last
-// run is continued by a later lane).  Which slots are live follows from the bucket offsets alone.
-template <uint32_t FB> struct Shape {
-    static constexpr uint32_t FINE = 1u << FB;
-    static constexpr uint32_t SLOT_PRIMARY = 0, SLOT_HEAD = FINE, SLOT_TAIL = FINE + MSM_THREADS, SLOTS_PER_TASK = FINE + 2 * MSM_THREADS;
-    static constexpr uint32_t META_PER_TASK = FINE + 2;   // start[0..FINE] and the entry count
-};
 static uint32_t slots_per_task(uint32_t fb) { return (1u << fb) + 2 * MSM_THREADS; }
 static uint32_t meta_per_task(uint32_t fb) { return (1u << fb) + 2; }
-
-// Kernel A — one workgroup per task = one slice (<= CHUNK entries) of a (window, coarse bin): 128 buckets.
-//  1. counting sort of the slice by fine bucket inside LDS
-//  2. the sorted slice is cut into 256 equal pieces, one per lane: every lane performs the same number of
-//     mixed additions whatever the bucket populations are (uniform, witness-like or one hot bucket);
-//     a lane starts a new accumulator at each bucket boundary inside its piece
-// Only mixed additions happen here (10 products each, ~25 KB of code).  One wave per SIMD already saturates the
-// VALU (tools/ubench_w: 15 G mixed-adds/s at any occupancy, 25 % less when squeezed into 128 VGPRs with
-// spills), so the register budget is the full 256 and nothing is spilled.  Kernel B folds the partial sums.
-template <uint32_t FB, int MINW = 2>
-__global__ void __launch_bounds__(MSM_THREADS, MINW) msm_accumulate(const G1Affine *bases, const uint32_t *entries,
-                                                                  const uint32_t *bin_start, const uint32_t *task_start,
-                                                                  XyzzW *partials, uint32_t *task_meta, MsmParams p) {
-    constexpr uint32_t FINE = Shape<FB>::FINE, SLOT_PRIMARY = Shape<FB>::SLOT_PRIMARY, SLOT_HEAD = Shape<FB>::SLOT_HEAD,
-                       SLOT_TAIL = Shape<FB>::SLOT_TAIL, SLOTS_PER_TASK = Shape<FB>::SLOTS_PER_TASK, META_PER_TASK = Shape<FB>::META_PER_TASK;
-    extern __shared__ uint32_t sorted[];                      // [CHUNK]
-    __shared__ uint32_t cnt[FINE], start[FINE + 1], cursor[FINE];
-    const uint32_t tid = threadIdx.x, task = blockIdx.x;
-    const uint32_t total_bins = p.batch * p.groups * p.nbins;
-    if (task >= task_start[total_bins]) return;
-    uint32_t blo = 0, bhi = total_bins;                       // bin = last index with task_start[bin] <= task
-    // (one task per bin is the common case — uniform scalars at 2^20 —: then bin == task, two independent loads instead of
-    //  the ten dependent ones of the search, which were ~10 us of a ~580 us task)
-    if (task < total_bins && task_start[task] <= task && task_start[task + 1] > task) { blo = task; bhi = task + 1; }
-    while (bhi - blo > 1) { uint32_t mid = (blo + bhi) >> 1; if (task_start[mid] <= task) blo = mid; else bhi = mid; }
-    const uint32_t bin = blo, slice = task - task_start[bin];
-    const uint32_t bs = bin_start[bin], be = bin_start[bin + 1];
-    // a bin that needs k tasks is cut into k EQUAL slices (not CHUNK, CHUNK, ..., remainder): with ~6 tasks per
-    // workgroup slot a mix of full and quarter-size tasks left the last full ones running alone (measured at 2^21:
-    // 3.7 ms instead of 2.6 ms for the same additions)
-    const uint32_t k_bin = task_start[bin + 1] - task_start[bin], per = (be - bs + k_bin - 1) / k_bin;
-    const uint32_t s = bs + slice * per < be ? bs + slice * per : be, e = (s + per < be) ? s + per : be, nc = e - s;
-
-    if (tid < FINE) { cnt[tid] = 0; cursor[tid] = 0; }
-    __syncthreads();
-    // Both passes of the sort work from registers: a lane's <= 64 entries are loaded up front with all loads in flight (one
-    // dependent global load per loop iteration left the wave waiting on memory 64 times per pass, and at the start of a launch
-    // every workgroup of the chip is in this phase); the registers are free here, the accumulator state is not live yet.
-    constexpr uint32_t PER_LANE = CHUNK / MSM_THREADS;                    // 64
-    uint32_t ent[PER_LANE];
-#pragma unroll
-    for (uint32_t k = 0; k < PER_LANE; k++) { const uint32_t idx = tid + k * MSM_THREADS; ent[k] = idx < nc ? entries[s + idx] : 0u; }
-#pragma unroll
-    for (uint32_t k = 0; k < PER_LANE; k++) if (tid + k * MSM_THREADS < nc) atomicAdd(&cnt[ent[k] & (FINE - 1)], 1u);
-    __syncthreads();
-    if (tid < 64) {                                           // exclusive scan of the FINE counts by one wave
-        constexpr uint32_t PER = FINE / 64;                   // 1 or 2 buckets per lane
-        uint32_t own[PER], sum = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < PER; k++) { own[k] = cnt[PER * tid + k]; sum += own[k]; }
-        uint32_t v = sum;
-        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off); if ((int)tid >= off) v += t; }
-        uint32_t run = v - sum;
-#pragma unroll
-        for (uint32_t k = 0; k < PER; k++) { start[PER * tid + k] = run; run += own[k]; }
-        if (tid == 63) start[FINE] = v;
-    }
-    __syncthreads();
-    uint32_t *meta = task_meta + (size_t)task * META_PER_TASK;
-    if (tid <= FINE) meta[tid] = start[tid];
-    if (tid == 0) meta[FINE + 1] = nc;
-#pragma unroll
-    for (uint32_t k = 0; k < PER_LANE; k++)
-        if (tid + k * MSM_THREADS < nc) { const uint32_t f = ent[k] & (FINE - 1); sorted[start[f] + atomicAdd(&cursor[f], 1u)] = ent[k]; }
-    __syncthreads();
-    if (nc == 0 || p.debug == 3) return;                      // (debug 3: time the sort alone)
-    const uint32_t mu = (nc + MSM_THREADS - 1) / MSM_THREADS;
-    const uint32_t lo = tid * mu < nc ? tid * mu : nc, hi = lo + mu < nc ? lo + mu : nc;
-    XyzzW *out = partials + (size_t)task * SLOTS_PER_TASK;
-    if (lo >= hi) return;
-    // one flat loop over the lane's piece: every lane of the wave executes the same number of mixed additions
-    // in lockstep; a bucket boundary only costs the (divergent) 144-byte flush of the finished accumulator
-    const uint32_t imask = (1u << p.nbits) - 1;
-    auto point_of = [&](uint32_t entry) -> const G1Affine * {          // (copy j, index i) -> address in the table
-        const uint32_t t = entry >> 8;
-        return bases + (size_t)(t >> p.nbits) * p.copy_stride + (t & imask);
-    };
-    uint32_t en = sorted[lo], b = en & (FINE - 1), bend = start[b + 1], run_start = lo;
-    G1Affine pt = load_affine(point_of(en));
-    XyzzW acc = xyzzw_identity();
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t e_cur = en;
-        AffW cur; cur.x = unpack<FqW>(pt.x); cur.y = unpack<FqW>(pt.y);
-        if (i + 1 < hi) { en = sorted[i + 1]; pt = load_affine(point_of(en)); }   // prefetch the next gather
-        if (i == bend) {                                      // the previous bucket ended inside this piece
-            const bool from_prev = (run_start == lo) && (start[b] < lo);
-            store_xyzzw(out + (from_prev ? SLOT_HEAD + tid : SLOT_PRIMARY + b), acc);
-            acc = xyzzw_identity();
-            run_start = i; b = e_cur & (FINE - 1); bend = start[b + 1];
-        }
-        if (p.debug != 1) xyzzw_add_mixed(acc, cur, (e_cur & 0x80u) != 0);
-    }
-    const bool from_prev = (run_start == lo) && (start[b] < lo), into_next = bend > hi;
-    store_xyzzw(out + (from_prev ? SLOT_HEAD + tid : (into_next ? SLOT_TAIL + tid : SLOT_PRIMARY + b)), acc);
-}
 
 // Kernel B0 — folds a bucket that kernel A spread over more than HOT_SPAN lanes (repeated scalars: a witness
 // full of 0/1 values) into that bucket's otherwise unused PRIMARY slot, RL lanes per task working together.
@@ -901,9 +761,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     if (!attr_set) {
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_partition<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_recode_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<6>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<7>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<6, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
+        PLK_TRY(msm_accumulate_prepare());
         attr_set = true;
     }
     // PLK_MSM_FUSED_RECODE=0 (A/B knob): the three-launch pre-phase through the digit array, as for several bucket sets
@@ -933,12 +791,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
         constexpr uint32_t FB = decltype(fb_tag)::value;
         // PLK_MSM_ONE_WAVE=1 (measurement knob): the same kernel compiled for one wave per SIMD (512 registers, no spill)
         static const bool one_wave = getenv("PLK_MSM_ONE_WAVE") != nullptr;
-        if (one_wave && FB == 6)
-            hipLaunchKernelGGL((msm_accumulate<6, 1>), dim3(max_tasks), dim3(MSM_THREADS), CHUNK * sizeof(uint32_t), stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
-                               (const uint32_t *)task_start, partials, task_meta, p);
-        else
-        hipLaunchKernelGGL(msm_accumulate<FB>, dim3(max_tasks), dim3(MSM_THREADS), CHUNK * sizeof(uint32_t), stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start,
-                           (const uint32_t *)task_start, partials, task_meta, p);
+        msm_accumulate_launch(FB, one_wave, max_tasks, stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start, (const uint32_t *)task_start, partials, task_meta, p);
         if (ctx->ev_on) (void)hipEventRecord(S.ev[1], stream);
         (void)hipEventRecord(S.acc_done, stream);
         hipLaunchKernelGGL(msm_fold_hot<FB>, dim3(rblocks), dim3(MSM_THREADS), 0, stream, partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);

@@ -201,3 +201,22 @@ def test_throughput_leg_of_the_bench(ctx):
     assert r["in_flight"] == 2 and r["proofs"] == 8 and r["byte_identical_to_sequential"] and r["proofs_per_s"] > 0
     r = prover_bench.throughput(ctx, 13, in_flight=3, proofs_each=3, lc_terms=7)
     assert r["in_flight"] == 3 and r["proofs"] == 9
+
+
+def test_two_provers_through_the_c_abi_alone(tmp_path):
+    """tests/host/two_provers.c: a C program (pthreads, include/plonkit_amd.h, no Python in the proving process) runs two
+    contexts on device 0 against one setup with two witnesses — every concurrent proof byte-identical to the sequential one,
+    and the lender refuses to replace its key while it is on loan"""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not on PATH")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "two_provers")
+    libdir = os.path.join(root, "plonkit_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-pthread", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "host", "two_provers.c"), "-o", exe, "-L", libdir, "-lplonkit_amd", "-Wl,-rpath," + libdir])
+    r = subprocess.run([exe, "14", "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert r.stdout.startswith("OK 12 "), r.stdout

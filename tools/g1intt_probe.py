@@ -1,5 +1,6 @@
 import sys, time
 import os; sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
+sys.path.append(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (the oracle always comes from the working tree)
 import numpy as np, torch
 import plonkit_amd as pa
 from oracle import oracle_lib as ol
