@@ -3,7 +3,7 @@
 
 This image has no Rust toolchain, so the transpilation of long linear combinations (bellman's IntoMultipleGates adaptor,
 /root/reference/src/transpile.rs:127-139) has only ever been compared between this package's C++ transpiler and its own
-Python oracle: two restatements of one recollection.  This tool writes, for five circuits, exactly the files the
+Python oracle: two restatements of one recollection.  This tool writes, for six circuits, exactly the files the
 reference's test flow produces (/root/reference/test/test_poseidon_plonk.sh:47-80):
 
     <case>/circuit.r1cs  witness.wtns  setup.key  vk.bin  proof.bin  proof.json  public.json  analyse.json
@@ -17,6 +17,8 @@ compare.sh pins or refutes the transpiler, the setup polynomials, the prover and
     poseidon_14      combinations of up to 24 / 60 signals, constant x LC outputs — domains 2^12, 2^14, 2^16
     poseidon_16
     long_lc        one 11-term LC x signal = 2-term LC, one LC x LC with constants (d / d_next chains, merges)
+    dense_14       the bench's DENSE synthetic circuit at the 2^14 domain (plk_circuit_synthetic_ex, lc_terms = 7: every constraint
+                   a 7-term linear combination folded through the d column) — the shape `prove.dense` of bench.py times
 
 usage (on a GPU box):  python tools/make_crosscheck_bundle.py <outdir>
 Every artefact here is labelled UNPINNED until such a run has happened."""
@@ -66,13 +68,18 @@ def run(*args):
     subprocess.run([CLI] + list(args), check=True, stderr=subprocess.DEVNULL)
 
 
+def circuits():
+    for name, js, wit, log_n in cases():
+        yield name, pa.Circuit(json.dumps(js).encode(), True, json.dumps([str(x) for x in wit]).encode(), True), log_n
+    yield "dense_14", pa.Circuit.synthetic_ex((1 << 14) - 2, lc_terms=7), 14
+
+
 def main(out):
     manifest = {}
-    for name, js, wit, log_n in cases():
+    for name, circ, log_n in circuits():
         d = os.path.join(out, name)
         os.makedirs(d, exist_ok=True)
         f = lambda x: os.path.join(d, x)                               # noqa: E731
-        circ = pa.Circuit(json.dumps(js).encode(), True, json.dumps([str(x) for x in wit]).encode(), True)
         open(f("circuit.r1cs"), "wb").write(circ.export("r1cs"))       # circom's binary formats (src/r1cs_file.rs, src/reader.rs)
         open(f("witness.wtns"), "wb").write(circ.export("wtns"))
         circ.close()

@@ -17,7 +17,7 @@ for r in rows:
 groups.append(cur)
 g = groups[-1]
 # proofs run back to back: keep the last one = from the last kernel whose name contains the marker (default: first kernel name of a proof)
-marker = sys.argv[2] if len(sys.argv) > 2 else "k_witness"
+marker = sys.argv[2] if len(sys.argv) > 2 else "k_eval_witness"
 idx = [i for i, r in enumerate(g) if marker in r[0]]
 if idx:
     g = g[idx[-1]:]
