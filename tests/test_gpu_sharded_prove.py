@@ -213,6 +213,8 @@ def test_bench_n2_control_flow_on_one_gpu():
     assert "error" not in st and st["terms_total"] == 1 << 18 and st["terms_per_gpu"] == 1 << 17 and st["scaling_vs_1gpu"] > 0
     assert "error" not in line["prove"] and line["prove"]["n_gpus"] == 2 and line["prove"]["proof_bytes"] == 1144
     assert line["strong_value"] == st["Mscalar_mul_s"] and line["strong_scaling_vs_1gpu"] == st["scaling_vs_1gpu"]
+    pt = line["prove_throughput"]                                     # every GPU proving on its own (replicas), two proofs in flight each
+    assert "error" not in pt and pt["n_gpus"] == 2 and pt["in_flight_per_gpu"] == 2 and pt["proofs_per_s"] > 0
 
 
 def _run_plain_bench(n_gpus, extra, timeout=900):
