@@ -680,17 +680,22 @@ def main():
             cb, ref, s_host = cpu_msm_baseline(ctx, min(args.cpu_log_n, args.log_n), 1234)
             got = ctx.msm(s_host)                         # same sample through the HIP path
             cb["matches_gpu"] = bool(np.array_equal(got, ref))
-            cb["msm_rows"] = cpu_msm_rows(ctx, device)
-            cb["g1_intt"] = cpu_g1_intt_row(ctx, device)
-            cb["ntt"] = cpu_ntt_baseline()
-            cb["prove"] = cpu_prove_baseline(ctx, min(args.cpu_log_n, args.log_n))
+            for key, fn in (("msm_rows", lambda: cpu_msm_rows(ctx, device)), ("g1_intt", lambda: cpu_g1_intt_row(ctx, device)),
+                            ("ntt", cpu_ntt_baseline), ("prove", lambda: cpu_prove_baseline(ctx, min(args.cpu_log_n, args.log_n)))):
+                try:
+                    cb[key] = fn()
+                except Exception as exc:                               # noqa: BLE001 — a secondary row must not cost the line
+                    cb[key] = {"error": repr(exc)}
             rb = reference_binary_baseline(min(args.cpu_log_n, args.log_n))
             if rb:
                 cb["reference_binary"] = rb
             line["cpu_baseline"] = cb
         if world == 1 and not force_dist and not args.msm_only:
             from plonkit_amd import prover_bench
-            line["prove"] = prover_bench.run(ctx, args.log_n)
+            try:
+                line["prove"] = prover_bench.run(ctx, args.log_n)
+            except Exception as exc:                                   # noqa: BLE001 — a failing leg must not cost the headline line
+                line["prove"] = {"error": repr(exc)}
             # the same circuit shape with a live d column (11 of 11 commitments), and prove THROUGHPUT: two proofs in flight on this GPU
             for key, fn in (("dense", lambda: prover_bench.run_dense(ctx, args.log_n)),
                             ("throughput", lambda: prover_bench.throughput(ctx, args.log_n, in_flight=2, proofs_each=10)),
@@ -699,7 +704,10 @@ def main():
                     line["prove"][key] = fn()
                 except Exception as exc:                               # noqa: BLE001 — must not cost the headline line
                     line["prove"][key] = {"error": repr(exc)}
-            line["kernels"] = prover_bench.kernel_table(ctx, device)
+            try:
+                line["kernels"] = prover_bench.kernel_table(ctx, device)
+            except Exception as exc:                                   # noqa: BLE001
+                line["kernels"] = {"error": repr(exc)}
     if world > 1 or force_dist:
         # (a) strong scaling of ONE 2^24-term commitment (configs[2]); (b) multi-GPU prove at the 2^log_n domain: the SRS
         # sliced across the ranks, commitments combined over RCCL, NTTs replicated.  Every rank takes part;

@@ -57,53 +57,57 @@ def throughput(ctx, log_n, in_flight=2, proofs_each=10, lc_terms=0, setup=None, 
     if own_setup:
         setup = _lib.SetupForProver(ctx, circs[0])
     ctxs = [ctx]
-    for _ in range(in_flight - 1):
-        c2 = _lib.Context(ctx.device)
-        c2.share_srs_from(ctx)
-        ctxs.append(c2)
-    # reference proofs, made one at a time on the first context (also the warm-up of that context)
-    want = [setup.prove(c) for c in circs]
-    assert len(set(want)) == len(want), "different witnesses must give different proofs"
-    for k in range(1, in_flight):                                   # warm-up of the other contexts (workspaces, twiddle tables)
-        assert setup.prove(circs[k], ctx=ctxs[k]) == want[k]
-    # sequential: the same number of proofs one after the other on one context
-    total = in_flight * proofs_each
-    t0 = time.perf_counter()
-    for i in range(total):
-        p = setup.prove(circs[i % in_flight])
-        assert p == want[i % in_flight]
-    seq_s = time.perf_counter() - t0
-    # concurrent
-    lat = [[] for _ in range(in_flight)]
-    bad = []
-    gate = threading.Barrier(in_flight + 1)
+    try:
+        for _ in range(in_flight - 1):
+            c2 = _lib.Context(ctx.device)
+            c2.share_srs_from(ctx)
+            ctxs.append(c2)
+        # reference proofs, made one at a time on the first context (also the warm-up of that context)
+        want = [setup.prove(c) for c in circs]
+        assert len(set(want)) == len(want), "different witnesses must give different proofs"
+        for k in range(1, in_flight):                               # warm-up of the other contexts (workspaces, twiddle tables)
+            assert setup.prove(circs[k], ctx=ctxs[k]) == want[k]
+        # sequential: the same number of proofs one after the other on one context
+        total = in_flight * proofs_each
+        t0 = time.perf_counter()
+        for i in range(total):
+            p = setup.prove(circs[i % in_flight])
+            assert p == want[i % in_flight]
+        seq_s = time.perf_counter() - t0
+        # concurrent
+        lat = [[] for _ in range(in_flight)]
+        bad = []
+        gate = threading.Barrier(in_flight + 1)
 
-    def worker(k):
+        def worker(k):
+            gate.wait()
+            for _ in range(proofs_each):
+                t = time.perf_counter()
+                try:
+                    p = setup.prove(circs[k], ctx=ctxs[k])
+                except Exception as exc:                             # noqa: BLE001
+                    bad.append(repr(exc)); return
+                lat[k].append(time.perf_counter() - t)
+                if p != want[k]:
+                    bad.append("thread %d: proof differs from the sequential one" % k)
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(in_flight)]
+        for t in th:
+            t.start()
         gate.wait()
-        for _ in range(proofs_each):
-            t = time.perf_counter()
-            try:
-                p = setup.prove(circs[k], ctx=ctxs[k])
-            except Exception as exc:                                 # noqa: BLE001
-                bad.append(repr(exc)); return
-            lat[k].append(time.perf_counter() - t)
-            if p != want[k]:
-                bad.append("thread %d: proof differs from the sequential one" % k)
-    th = [threading.Thread(target=worker, args=(k,)) for k in range(in_flight)]
-    for t in th:
-        t.start()
-    gate.wait()
-    t0 = time.perf_counter()
-    for t in th:
-        t.join()
-    par_s = time.perf_counter() - t0
-    for c2 in ctxs[1:]:
-        c2.close()
-    if own_setup:
-        setup.close()
-    if own_circs:
-        for c in circs:
-            c.close()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        par_s = time.perf_counter() - t0
+    finally:
+        # the borrowers go first, whatever happened: while one exists the lender refuses to replace its key, and the caller's
+        # next leg (bench.py: the kernel table regenerates the SRS) would fail with it
+        for c2 in ctxs[1:]:
+            c2.close()
+        if own_setup:
+            setup.close()
+        if own_circs:
+            for c in circs:
+                c.close()
     if bad:
         raise RuntimeError("concurrent proving failed: " + "; ".join(bad[:3]))
     all_lat = sorted(x for l in lat for x in l)
