@@ -61,6 +61,8 @@ struct EvalArgs {
 };
 
 int32_t gather(Fr *out, const Fr *values, const uint32_t *vars, uint32_t n, hipStream_t s);
+// out[j][i] = copy[j][i] = values[vars[j][i]] for the four wire columns, one launch
+int32_t gather4_dual(Fr *const out[4], Fr *const copy[4], const Fr *values, const uint32_t *const vars[4], uint32_t n, hipStream_t s);
 int32_t sigma_from_index(Fr *out, const uint32_t *packed, uint32_t n, uint32_t log_n, const PowTable &tw, const Fr k[4], hipStream_t s);
 int32_t check_gates(const CheckArgs &a, hipStream_t s);
 // perm.hip: 4 x n packed successors (idx[col * n + row] = col' << 30 | row') of the copy-constraint permutation
@@ -76,6 +78,9 @@ int32_t mul3(Fr *out, const Fr *a, const Fr *b, const Fr &sc, uint32_t n, hipStr
 // out may alias in.  mult: product scan, else sum; reverse: suffix; exclusive: shifted by one
 // totals: where the block totals live (default: the context's poly_tmp; two scans in flight on two streams need two)
 int32_t scan(plk_ctx *ctx, Fr *out, const Fr *in, uint32_t n, bool mult, bool reverse, bool exclusive, hipStream_t s, DevBuf *totals = nullptr);
+// two product scans of equal length in one launch per phase (the grand product's numerator prefix / denominator suffix)
+int32_t scan_pair_mult(plk_ctx *ctx, Fr *out0, const Fr *in0, bool reverse0, bool exclusive0, Fr *out1, const Fr *in1, bool reverse1, bool exclusive1,
+                       uint32_t n, hipStream_t s);
 int32_t quotient(const QuotientArgs &a, hipStream_t s);
 // data = the four per-coset coefficient vectors u_k of icoset4cm_dev (u_k at data + k*n) -> the 4n coefficients, natural order, in place;
 // constants in the W domain: i^-1 (i = omega_4) and s_c = 7^(-N c) / 4

@@ -558,10 +558,7 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     };
 
     // ---- round 1: wire polynomials, 4 x iNTT(N) in one launch per pass, 4 x MSM(N)
-    for (int j = 0; j < 4; j++) {
-        PLK_TRY(gather(w_vals[j], d_values, S->gate_vars[j], (uint32_t)N, st));
-        PLK_HIP(hipMemcpyAsync(w_coef[j], w_vals[j], N * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    }
+    PLK_TRY(gather4_dual(w_vals, w_coef, d_values, S->gate_vars, (uint32_t)N, st));
     if (log_n <= 22) PLK_TRY(ntt_batch_dev(ctx, w_coef, 4, log_n, true, nullptr, st, 0));
     else for (int j = 0; j < 4; j++) PLK_TRY(ntt_dev(ctx, w_coef[j], log_n, true, nullptr, st));
     // with a Lagrange-form key of the domain's size resident (`prove -l`, src/plonk.rs:138-146) the witness and
@@ -592,8 +589,7 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
         pa.beta = to_dev(beta * HFr::from_u64(32)); pa.gamma = to_dev(gamma); pa.fix = to_dev(HFr::from_u64(1u << 25));   // domains: poly.h
         pa.n = (uint32_t)N; pa.log_n = log_n; pa.tw = ctx->tw_fwd_w;
         PLK_TRY(perm_terms(pa, st));
-        PLK_TRY(scan(ctx, t1, t1, (uint32_t)N, true, false, true, st));
-        PLK_TRY(scan(ctx, t2, t2, (uint32_t)N, true, true, false, st));
+        PLK_TRY(scan_pair_mult(ctx, t1, t1, false, true, t2, t2, true, false, (uint32_t)N, st));
         HFr total;
         PLK_HIP(hipMemcpyAsync(total.l, t2, sizeof(Fr), hipMemcpyDeviceToHost, st));
         PLK_HIP(hipStreamSynchronize(st));
@@ -901,8 +897,7 @@ int32_t plk_permutation_grand_product_dev(plk_ctx *ctx, const void *const wires_
     pa.beta = to_dev(hb * HFr::from_u64(32)); pa.gamma = to_dev(hg); pa.fix = to_dev(HFr::from_u64(1u << 25));
     pa.n = (uint32_t)N; pa.log_n = log_n; pa.tw = ctx->tw_fwd_w;
     int32_t rc = perm_terms(pa, st);
-    if (rc == PLK_OK) rc = scan(ctx, pa.num, pa.num, (uint32_t)N, true, false, true, st);
-    if (rc == PLK_OK) rc = scan(ctx, pa.den, pa.den, (uint32_t)N, true, true, false, st);
+    if (rc == PLK_OK) rc = scan_pair_mult(ctx, pa.num, pa.num, false, true, pa.den, pa.den, true, false, (uint32_t)N, st);
     HFr total;
     if (rc == PLK_OK && hipMemcpyAsync(total.l, pa.den, sizeof(Fr), hipMemcpyDeviceToHost, st) != hipSuccess) rc = hip_fail(hipGetLastError(), "D2H", __FILE__, __LINE__);
     if (rc == PLK_OK && hipStreamSynchronize(st) != hipSuccess) rc = hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__);
