@@ -546,6 +546,7 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     // wire commitments took 2.1 ms instead of 0.35 behind it), so the start is placed by hand where the GPU has room — the
     // bucket reduction of that commitment, the point-wise kernels of the next round and the pre-phase of its commitment.
     static const int bg_gate_z = [] { const char *e = getenv("PLK_PROVE_BG_GATE_Z"); return e ? atoi(e) : 0; }();   // A/B knob
+    static const int bg_gate_w = [] { const char *e = getenv("PLK_PROVE_BG_GATE_W"); return e ? atoi(e) : 1; }();   // A/B knob: wire extensions behind the wires' accumulation
     auto bg_after_main = [&](bool behind_accumulation) -> int32_t {
         if (!use_bg) return PLK_OK;
         PLK_HIP(hipEventRecord(ctx->bg_go, st));
@@ -567,7 +568,7 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     if (use_lagrange && (ctx->combine ? ctx->lag.n != ctx->srs_n : ctx->lag.n != N)) { set_error("Lagrange-form key has a different size than the circuit's domain"); return PLK_ERR_SRS; }
     HAffine wire_c[4];
     PLK_TRY(commit_begin(ctx, use_lagrange ? w_vals : w_coef, 4, N, use_lagrange));
-    PLK_TRY(bg_after_main(true));
+    PLK_TRY(bg_after_main(bg_gate_w != 0));
     PLK_TRY(lde4cm_batch_dev(ctx, w_coef, 4, log_n, ext, bg, bg_lane));                       // round-3 work that needs no challenge
     PLK_HIP(hipEventSynchronize(ctx->flag_ready));
     if (*reinterpret_cast<volatile uint32_t *>(ctx->pinned)) { set_error("must satisfy: witness does not satisfy the circuit"); return PLK_ERR_UNSAT; }
