@@ -296,3 +296,26 @@ def test_header_is_plain_c_and_links(tmp_path):
                            "-L" + libdir, "-lplonkit_amd", "-Wl,-rpath," + libdir])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout.split()
     assert out[0] == "plonkit_amd" and out[-3] == "c5d2" and out[-2] == "1" and out[-1] == "128", out   # keccak256("") = c5d2..., ncclUniqueId is 128 bytes
+
+
+def test_synthetic_ex_generator_invariants():
+    """plk_circuit_synthetic_ex (bench / test input): exactly `target_gates` gates for every linear-combination width and
+    size, the product's and the oracle's transpilers agree gate for gate, the generated witness satisfies every gate,
+    witness_seed changes the witness and not the R1CS, lc_terms = 0 is plk_circuit_synthetic, bad arguments are refused"""
+    import json
+    for lc in (5, 6, 7, 8, 12, 33, 64):
+        for tg in (4, 5, 9, 30, 126):
+            c = pa.Circuit.synthetic_ex(tg, 1000 + lc, 7, lc)
+            raw, wt = c.export("r1cs"), c.export("wtns")
+            r1, w = po.load_r1cs_bin(raw), po.parse_wtns(wt)
+            assert json.loads(c.analyse())["num_gates"] == tg and c.analyse() == po.analyse(r1), (lc, tg)
+            T = po.transpile(r1, w)
+            assert po.is_satisfied(r1, T, po.setup(r1, T)), (lc, tg)
+            c2 = pa.Circuit.synthetic_ex(tg, 1000 + lc, 8, lc)
+            assert c2.export("r1cs") == raw and c2.export("wtns") != wt
+    a, b = pa.Circuit.synthetic(510), pa.Circuit.synthetic_ex(510)
+    assert a.export("r1cs") == b.export("r1cs") and a.export("wtns") == b.export("wtns")
+    for args in ((3, 1, 0, 0), (10, 1, 0, 4), (10, 1, 0, 65), (1 << 28, 1, 0, 0)):
+        with pytest.raises(pa.PlkError) as e:
+            pa.Circuit.synthetic_ex(*args)
+        assert e.value.code == 1
