@@ -245,3 +245,39 @@ def test_two_ranks_sliced_srs_2pow20():
     key each reproduce the single-GPU verification key and proof bytes"""
     from tests.test_gpu_sharded_prove import test_two_ranks_produce_the_single_gpu_proof as run
     run(20, False)
+
+
+def test_dense_circuit_at_the_2pow22_domain(ctx24):
+    """the dense synthetic circuit (12-term linear combinations: chains of up to four partial sums per constraint, 3.4 M
+    temporaries evaluated run by run on the device) at the 2^22 domain: all 11 commitments non-trivial, the host verifier
+    (real pairing) accepts, a tampered evaluation is rejected, and the host evaluation of the temporaries
+    (PLK_WITNESS_TMP_HOST is read once per process, so: the same proof at 2^16 in a subprocess) gives the same bytes.
+    PARITY UNPINNED (chaining rule)."""
+    import subprocess
+    import sys
+    import plonkit_amd as pa
+    from plonkit_amd.prover_bench import nonempty_commitments
+    log_n = 22
+    ctx = ctx24                                                          # (the 2^24-point key covers the 2^22 domain)
+    ctx.srs_lagrange_clear()
+    circ = pa.Circuit.synthetic_ex((1 << log_n) - 2, lc_terms=12)
+    setup = pa.SetupForProver(ctx, circ)
+    assert setup.domain_size == 1 << log_n
+    vk, proof = setup.verification_key_bytes(pa.crs42_g2_bytes()), setup.prove(circ)
+    assert nonempty_commitments(proof) == 11 and pa.verify(vk, proof)
+    bad = bytearray(proof); bad[-300] ^= 1
+    assert not pa.verify(vk, bytes(bad))
+    setup.close(); circ.close()
+    code = r"""
+import hashlib, plonkit_amd as pa
+ctx = pa.Context(0); ctx.srs_generate(1 << 16, 0, 42)
+circ = pa.Circuit.synthetic_ex((1 << 16) - 2, lc_terms=12)
+print("H", hashlib.sha256(pa.SetupForProver(ctx, circ).prove(circ)).hexdigest())
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"PLK_WITNESS_TMP_HOST": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("H ")][0])
+    assert outs[0] == outs[1]
