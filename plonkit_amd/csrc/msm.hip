@@ -32,6 +32,9 @@
 //     the digit / partition kernels of the one after next share the GPU with the accumulation in between.
 // No MFMA (256-bit modular integers), bound by v_mad_u64_u32 issue; HBM sees the algorithmic 96 B/term plus the
 // per-window gathers (64 B x W per term) from the table.
+// Files: the accumulation kernel ("kernel A" above, step (2) of the sort) lives in msm_accumulate.hip — a translation unit
+// of its own so that it can be compiled for ILP (plonkit_amd/build.py) —, the declarations both share in msm_shape.h;
+// everything else (recoding, partition, bucket reduction, drivers, the FIFO of three slots, plk_ctx_share_srs) is here.
 #include "msm_shape.h"
 #include "msm.h"
 #include "hostmath.h"
