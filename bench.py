@@ -703,6 +703,7 @@ def main():
             # the same circuit shape with a live d column (11 of 11 commitments), and prove THROUGHPUT: two proofs in flight on this GPU
             for key, fn in (("dense", lambda: prover_bench.run_dense(ctx, args.log_n)),
                             ("throughput", lambda: prover_bench.throughput(ctx, args.log_n, in_flight=2, proofs_each=10)),
+                            ("throughput_in_flight_3", lambda: prover_bench.throughput(ctx, args.log_n, in_flight=3, proofs_each=8)),
                             ("throughput_dense", lambda: prover_bench.throughput(ctx, args.log_n, in_flight=2, proofs_each=6, lc_terms=7))):
                 try:
                     line["prove"][key] = fn()
