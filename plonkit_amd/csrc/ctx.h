@@ -138,7 +138,7 @@ struct plk_ctx {
 namespace plk {
 // every entry point that replaces a resident key goes through these two: the MSM table of the old key is void, and a table
 // (or key) that was only borrowed must not be written to when the next one is built
-int32_t srs_replace_guard(plk_ctx *c, const char *who);           // runtime.hip: PLK_ERR_ARG while another context borrows this one's key
+int32_t srs_replace_guard(plk_ctx *c, const char *who, bool lagrange_only = false);   // runtime.hip: PLK_ERR_ARG while another context borrows this one's key
 inline void srs_table_invalidate(plk_ctx *c) { c->srs_w_valid = false; if (c->srs_w.borrowed) c->srs_w.release(); }
 inline void lag_table_invalidate(plk_ctx *c) { c->lag.w_valid = false; if (c->lag.w.borrowed) c->lag.w.release(); }
 void srs_return_loan(plk_ctx *c);                                 // runtime.hip

@@ -64,20 +64,21 @@ int32_t ensure_pinned2(plk_ctx *ctx, size_t bytes) {
 }
 
 // a context whose key is on loan must keep it: the borrowers' commitments read it (and its MSM table) at any time
-int32_t srs_replace_guard(plk_ctx *c, const char *who) {
+int32_t srs_replace_guard(plk_ctx *c, const char *who, bool lagrange_only) {
     if (c->srs_borrowers.load() > 0) {
         set_error(std::string(who) + ": this context's key is shared with another context (plk_ctx_share_srs) — destroy the borrowers first");
         return PLK_ERR_ARG;
     }
-    srs_return_loan(c);                                  // a borrower that gets a key of its own stops borrowing
-    return PLK_OK;
+    if (!lagrange_only) srs_return_loan(c);              // a borrower that gets a monomial key of its own stops borrowing altogether;
+    return PLK_OK;                                       // one that only replaces its Lagrange-form key keeps the borrowed monomial key
 }
 void srs_return_loan(plk_ctx *c) {
     if (!c->srs_lender) return;
+    const bool lag_on_loan = c->lag.pts && c->lag.pts == c->srs_lender->lag.pts;      // (a borrower may have uploaded a Lagrange key of its own since)
     c->srs_lender->srs_borrowers.fetch_sub(1);
     c->srs_lender = nullptr;
     c->srs = nullptr; c->srs_n = 0; c->srs_w.release(); c->srs_w_valid = false; c->srs_w_copies = 0;
-    c->lag.pts = nullptr; c->lag.n = 0; c->lag.w.release(); c->lag.w_valid = false; c->lag.w_copies = 0;
+    if (lag_on_loan) { c->lag.pts = nullptr; c->lag.n = 0; c->lag.w.release(); c->lag.w_valid = false; c->lag.w_copies = 0; }
 }
 
 }  // namespace plk
@@ -209,7 +210,7 @@ int32_t plk_set_commit_shard(plk_ctx *ctx, uint64_t first_index, plk_combine_fn 
 // Lagrange-form key (Crs<E, CrsForLagrangeForm>): second resident SRS, see include/plonkit_amd.h
 int32_t plk_srs_lagrange_upload(plk_ctx *ctx, const plk_g1_affine *bases, uint64_t n) {
     if (!ctx || !bases || n == 0) { set_error("plk_srs_lagrange_upload: bad argument"); return PLK_ERR_ARG; }
-    PLK_TRY(srs_replace_guard(ctx, "plk_srs_lagrange_upload"));
+    PLK_TRY(srs_replace_guard(ctx, "plk_srs_lagrange_upload", true));
     PLK_HIP(hipSetDevice(ctx->device));
     PLK_TRY(ctx->lag.own.reserve(n * sizeof(plk_g1_affine)));
     PLK_HIP(hipMemcpyAsync(ctx->lag.own.p, bases, n * sizeof(plk_g1_affine), hipMemcpyHostToDevice, ctx->stream));
@@ -219,13 +220,14 @@ int32_t plk_srs_lagrange_upload(plk_ctx *ctx, const plk_g1_affine *bases, uint64
 }
 int32_t plk_srs_lagrange_set_dev(plk_ctx *ctx, const void *bases_dev, uint64_t n) {
     if (!ctx || !bases_dev || n == 0) { set_error("plk_srs_lagrange_set_dev: bad argument"); return PLK_ERR_ARG; }
-    PLK_TRY(srs_replace_guard(ctx, "plk_srs_lagrange_set_dev"));
+    PLK_TRY(srs_replace_guard(ctx, "plk_srs_lagrange_set_dev", true));
     ctx->lag.pts = bases_dev; ctx->lag.n = n; lag_table_invalidate(ctx);
     return PLK_OK;
 }
 int32_t plk_srs_lagrange_clear(plk_ctx *ctx) {
     if (!ctx) { set_error("plk_srs_lagrange_clear: bad argument"); return PLK_ERR_ARG; }
-    PLK_TRY(srs_replace_guard(ctx, "plk_srs_lagrange_clear"));
+    if (!ctx->lag.pts) return PLK_OK;                                    // nothing resident: nothing to replace (also on a lender)
+    PLK_TRY(srs_replace_guard(ctx, "plk_srs_lagrange_clear", true));
     ctx->lag.pts = nullptr; ctx->lag.n = 0; lag_table_invalidate(ctx);
     return PLK_OK;
 }
