@@ -499,7 +499,11 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
     Fr *d_results = A.take<Fr>(16);
 
     uint32_t *d_flag = A.take<uint32_t>(64);
-    PLK_HIP(hipMemcpyAsync(d_values, wit, ncv * sizeof(Fr), hipMemcpyHostToDevice, st));
+    {   // (under the circuit's lock: another context proving the SAME circuit object may be about to page-lock this buffer —
+        //  not while a pageable copy of it is being staged)
+        std::lock_guard<std::mutex> upload_lock(c->reg_mu);
+        PLK_HIP(hipMemcpyAsync(d_values, wit, ncv * sizeof(Fr), hipMemcpyHostToDevice, st));
+    }
     PLK_HIP(hipMemsetAsync(d_values, 0, sizeof(Fr), st));
     if (n_tmp && tmp_on_device && S->ops_chained)
         PLK_TRY(eval_witness_runs(d_values, S->ops_dev.p, S->terms_dev.p, S->runs_dev.p, (uint32_t)S->run_start.size(), (uint32_t)S->ops.size(), (uint32_t)ncv, st));
