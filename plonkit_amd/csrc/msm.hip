@@ -434,7 +434,10 @@ static uint32_t meta_per_task(uint32_t fb) { return (1u << fb) + 2; }
 // Kernel B0 — folds a bucket that kernel A spread over more than HOT_SPAN lanes (repeated scalars: a witness
 // full of 0/1 values) into that bucket's otherwise unused PRIMARY slot, RL lanes per task working together.
 // Uniform scalars never take this path; the kernel then only reads the bucket offsets.
-constexpr uint32_t RL = 32, RL_LOG = 5, HOT_SPAN = 8;       // RL lanes per task, RB = FINE / RL buckets per lane
+#ifndef PLK_MSM_RL_LOG
+#define PLK_MSM_RL_LOG 5                                     // (A/B builds: tools/ab_flags.sh <tag> -DPLK_MSM_RL_LOG=4)
+#endif
+constexpr uint32_t RL_LOG = PLK_MSM_RL_LOG, RL = 1u << RL_LOG, HOT_SPAN = 8;   // RL lanes per task, RB = FINE / RL buckets per lane
 __device__ __forceinline__ uint32_t bucket_span(const uint32_t *meta, uint32_t b, uint32_t mu) {
     const uint32_t s0 = meta[b], e0 = meta[b + 1];
     return e0 > s0 ? (e0 - 1) / mu - s0 / mu : 0;
