@@ -7,12 +7,20 @@
 #include "ctx.h"
 #include "poly.h"
 #include "field29_dev.h"
+#include <utility>
+#include <type_traits>
 
 namespace plk {
 
 constexpr int PT = 256;                 // threads per block
 constexpr int EPT = 8;                  // elements per thread in scans / reductions
 constexpr int BLOCK_ELEMS = PT * EPT;
+
+// Compile-time loop: f(integral_constant<int, 0>) .. f(integral_constant<int, N - 1>).  `#pragma unroll` is only a request: the loops over
+// the four wire columns in k_perm_terms and k_quotient (two products of the 29-bit layer per trip) were left rolled, and a rolled loop that
+// indexes register arrays (w[j], bkx[j]) sends them to scratch memory — 304 B per lane in k_quotient until round 4.
+template <int... J, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, J...>, F &&f) { (f(std::integral_constant<int, J>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f)); }
 
 __device__ __forceinline__ Fr pow2l_(const PowTable &t, uint32_t e) {
     return mul(load_fp(t.lo + (e & (POW_TAB - 1))), load_fp(t.hi + (e >> POW_SPLIT)));
@@ -62,14 +70,14 @@ __global__ void __launch_bounds__(PT) k_perm_terms(PermArgs a) {
     const FrW9 wi = pow2l_w_(a.tw, i << (MAX_LOG_N - a.log_n));
     const FrW9 gamma = cw(a.gamma), beta = cw(a.beta), fix = cw(a.fix);
     FrW9 num, den;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
+    static_for<4>([&](auto J) {
+        constexpr int j = decltype(J)::value;
         const FrW9 wg = addw(ldw(a.w[j] + i), gamma);                                   // raw sums: limbs < 3 * 2^29 feed mulw's left side
         const FrW9 fn = addw(wg, mulw(wi, cw(a.beta_k[j])));
         const FrW9 fd = addw(wg, mulw(ldw(a.sigma[j] + i), beta));
         if (j == 0) { num = fn; den = fd; }
         else { num = mulw(num, normw(fn)); den = mulw(den, normw(fd)); }
-    }
+    });
     stw(a.num + i, csub_p(mulw(num, fix)));
     stw(a.den + i, csub_p(mulw(den, fix)));
 }
@@ -98,13 +106,13 @@ __device__ __forceinline__ void scan_local_body(Fr *out, const Fr *in, Fr *block
     const uint32_t tid = threadIdx.x, base = blockIdx.x * BLOCK_ELEMS + tid * EPT;
     Fr v[EPT];
     Fr run = ident<MULT>();
-#pragma unroll
-    for (int k = 0; k < EPT; k++) {
+    static_for<EPT>([&](auto K) {                               // (a rolled loop would keep v[] in scratch memory)
+        constexpr int k = decltype(K)::value;
         uint32_t i = base + k;
         Fr x = i < n ? load_fp(in + (reverse ? n - 1 - i : i)) : ident<MULT>();
         if (exclusive) { v[k] = run; run = op<MULT>(run, x); }
         else { run = op<MULT>(run, x); v[k] = run; }
-    }
+    });
     sh[tid] = run;
     __syncthreads();
     Fr incl = run;
@@ -116,11 +124,11 @@ __device__ __forceinline__ void scan_local_body(Fr *out, const Fr *in, Fr *block
     }
     Fr excl = tid ? sh[tid - 1] : ident<MULT>();
     if (tid == PT - 1) store_fp(block_tot + blockIdx.x, incl);
-#pragma unroll
-    for (int k = 0; k < EPT; k++) {
+    static_for<EPT>([&](auto K) {
+        constexpr int k = decltype(K)::value;
         uint32_t i = base + k;
         if (i < n) store_fp(out + (reverse ? n - 1 - i : i), fin<MULT>(op<MULT>(excl, v[k])));
-    }
+    });
 }
 
 template <bool MULT>
@@ -334,15 +342,18 @@ __global__ void __launch_bounds__(PT) k_quotient(QuotientArgs a) {
         for (int l = 0; l < 9; l++) t10.l[l] = bkx[1].l[l] << 1;
         bkx[3] = normw(t10);
     }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
+    static_for<4>([&](auto J) {
+        constexpr int j = decltype(J)::value;
         const FrW9 wg = addn(w[j], gamma);
         pa = mulw(pa, addn(wg, bkx[j]));
         pb = mulw(pb, addn(wg, mulw(ldw(a.sigma[j] + i), beta)));
-    }
+    });
     FrW9 t = addn(g, mulw(cw(a.alpha_pp), sub2(pa, pb)));
     t = addn(t, mulw(cw(a.alpha2_w), mulw(ldw(a.l0 + i), sub2(z, cw(Fr::one())))));
-    store_fp(a.out + i, pack<FrParams>(csub_p(mulw(t, cw(a.zh_inv_w[kc])))));
+    Fr zh_inv = a.zh_inv_w[0];
+#pragma unroll
+    for (uint32_t c = 1; c < 4; c++) if (kc == c) zh_inv = a.zh_inv_w[c];
+    store_fp(a.out + i, pack<FrParams>(csub_p(mulw(t, cw(zh_inv)))));
 }
 
 // Second half of the coset iNTT at 4N from the coset-major layout.  t(x) = sum_c x^(cN) T_c(x) with deg T_c < N; on the coset
