@@ -1,4 +1,5 @@
-"""one setup + N proves at the 2^log_n domain (for rocprofv3 --kernel-trace --stats): python tools/prove_probe.py [log_n] [proves]"""
+"""one setup + N proves at the 2^log_n domain (for rocprofv3 --kernel-trace --stats): python tools/prove_probe.py [log_n] [proves] [lc_terms]
+(lc_terms > 0: the dense synthetic circuit — long linear combinations folded through the d column, 11 of 11 commitments non-trivial)"""
 import os, sys, time
 sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
 import plonkit_amd as pa
@@ -6,7 +7,8 @@ log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 ctx = pa.Context(0)
 ctx.srs_generate(1 << log_n, 0, 42)
-circ = pa.Circuit.synthetic((1 << log_n) - 2)
+lc_terms = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+circ = pa.Circuit.synthetic_ex((1 << log_n) - 2, lc_terms=lc_terms) if lc_terms else pa.Circuit.synthetic((1 << log_n) - 2)
 setup = pa.SetupForProver(ctx, circ)
 setup.prove(circ)
 tot, rounds = [], {}
