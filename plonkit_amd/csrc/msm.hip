@@ -434,18 +434,19 @@ static uint32_t meta_per_task(uint32_t fb) { return (1u << fb) + 2; }
 // Kernel B0 — folds a bucket that kernel A spread over more than HOT_SPAN lanes (repeated scalars: a witness
 // full of 0/1 values) into that bucket's otherwise unused PRIMARY slot, RL lanes per task working together.
 // Uniform scalars never take this path; the kernel then only reads the bucket offsets.
-#ifndef PLK_MSM_RL_LOG
-#define PLK_MSM_RL_LOG 5                                     // (A/B builds: tools/ab_flags.sh <tag> -DPLK_MSM_RL_LOG=4)
-#endif
-constexpr uint32_t RL_LOG = PLK_MSM_RL_LOG, RL = 1u << RL_LOG, HOT_SPAN = 8;   // RL lanes per task, RB = FINE / RL buckets per lane
+// RL = 2^RL_LOG lanes per task, RB = FINE / RL buckets per lane — a template parameter of the two kernels since round 4: 32 lanes (a chain of 24
+// dependent additions) when the launch leaves SIMDs idle anyway (one or two commitments: latency is all that counts), 16 lanes (27 % fewer
+// lane-additions, a chain of 35) when a batch of three or more commitments puts two waves of these chains on every SIMD and the work decides
+// (profiles/r04_msm_reduce_rl_ab.txt: 16 lanes everywhere is +6 % on a single commitment and -1 % on a stream of them).
+constexpr uint32_t HOT_SPAN = 8;
 __device__ __forceinline__ uint32_t bucket_span(const uint32_t *meta, uint32_t b, uint32_t mu) {
     const uint32_t s0 = meta[b], e0 = meta[b + 1];
     return e0 > s0 ? (e0 - 1) / mu - s0 / mu : 0;
 }
-template <uint32_t FB>
+template <uint32_t FB, uint32_t RL_LOG>
 __global__ void __launch_bounds__(MSM_THREADS) msm_fold_hot(XyzzW *partials, const uint32_t *task_meta, const uint32_t *task_start, uint32_t total_bins) {
     constexpr uint32_t FINE = Shape<FB>::FINE, SLOT_PRIMARY = Shape<FB>::SLOT_PRIMARY, SLOT_HEAD = Shape<FB>::SLOT_HEAD,
-                       SLOTS_PER_TASK = Shape<FB>::SLOTS_PER_TASK, META_PER_TASK = Shape<FB>::META_PER_TASK, RB = FINE / RL;
+                       SLOTS_PER_TASK = Shape<FB>::SLOTS_PER_TASK, META_PER_TASK = Shape<FB>::META_PER_TASK, RL = 1u << RL_LOG, RB = FINE / RL;
     const uint32_t gt = blockIdx.x * MSM_THREADS + threadIdx.x;
     const uint32_t task = gt / RL, sub = gt % RL;
     const bool live = task < task_start[total_bins];
@@ -478,11 +479,11 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_fold_hot(XyzzW *partials, con
 // step loop — every step is "X += O" or "Y += X" with the operand selected beforehand — so the operands live
 // in registers: passing two 144-byte points to an out-of-line addition through scratch memory cost more
 // L2 write-through traffic than the arithmetic (measured 0.60 ms for this kernel against 0.3 ms of VALU work).
-template <uint32_t FB>
+template <uint32_t FB, uint32_t RL_LOG>
 __global__ void __launch_bounds__(MSM_THREADS, 2) msm_task_reduce(const XyzzW *partials, const uint32_t *task_meta,
                                                                    const uint32_t *task_start, XyzzW *task_out, uint32_t total_bins) {
     constexpr uint32_t FINE = Shape<FB>::FINE, SLOT_PRIMARY = Shape<FB>::SLOT_PRIMARY, SLOT_HEAD = Shape<FB>::SLOT_HEAD, SLOT_TAIL = Shape<FB>::SLOT_TAIL,
-                       SLOTS_PER_TASK = Shape<FB>::SLOTS_PER_TASK, META_PER_TASK = Shape<FB>::META_PER_TASK, RB = FINE / RL, RB_LOG = FB - RL_LOG;
+                       SLOTS_PER_TASK = Shape<FB>::SLOTS_PER_TASK, META_PER_TASK = Shape<FB>::META_PER_TASK, RL = 1u << RL_LOG, RB = FINE / RL, RB_LOG = FB - RL_LOG;
     static_assert(FB >= RL_LOG + 1, "at least two buckets per lane");
     const uint32_t gt = blockIdx.x * MSM_THREADS + threadIdx.x;
     const uint32_t task = gt / RL, sub = gt % RL;
@@ -792,7 +793,10 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
         hipLaunchKernelGGL(msm_partition<true>, dim3(pblocks, total_windows), dim3(PART_THREADS), plds_scatter, stream, (const int32_t *)digits, p, hist, (const uint32_t *)bin_start, entries);
     }
     if (ctx->ev_on) PLK_HIP(hipEventRecord(S.ev[0], stream));
-    const uint32_t rblocks = (max_tasks * RL + MSM_THREADS - 1) / MSM_THREADS;
+    // lanes per task of the bucket reduction (see msm_task_reduce): 16 for a batch of three or more commitments, 32 otherwise; PLK_MSM_RL_LOG=4|5 forces one (A/B runs)
+    static const int probe_rl = [] { const char *e = getenv("PLK_MSM_RL_LOG"); return e ? atoi(e) : 0; }();
+    const uint32_t rl_log = (probe_rl == 4 || probe_rl == 5) ? (uint32_t)probe_rl : (batch >= 3 ? 4u : 5u);
+    const uint32_t rblocks = ((max_tasks << rl_log) + MSM_THREADS - 1) / MSM_THREADS;
     auto launch_shape = [&](auto fb_tag) {
         constexpr uint32_t FB = decltype(fb_tag)::value;
         // PLK_MSM_ONE_WAVE=1 (measurement knob): the same kernel compiled for one wave per SIMD (512 registers, no spill)
@@ -800,9 +804,15 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
         msm_accumulate_launch(FB, one_wave, max_tasks, stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start, (const uint32_t *)task_start, partials, task_meta, p);
         if (ctx->ev_on) (void)hipEventRecord(S.ev[1], stream);
         (void)hipEventRecord(S.acc_done, stream);
-        hipLaunchKernelGGL(msm_fold_hot<FB>, dim3(rblocks), dim3(MSM_THREADS), 0, stream, partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
-        hipLaunchKernelGGL(msm_task_reduce<FB>, dim3(rblocks), dim3(MSM_THREADS), 0, stream,
-                           (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
+        if (rl_log == 4) {
+            hipLaunchKernelGGL((msm_fold_hot<FB, 4>), dim3(rblocks), dim3(MSM_THREADS), 0, stream, partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
+            hipLaunchKernelGGL((msm_task_reduce<FB, 4>), dim3(rblocks), dim3(MSM_THREADS), 0, stream,
+                               (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
+        } else {
+            hipLaunchKernelGGL((msm_fold_hot<FB, 5>), dim3(rblocks), dim3(MSM_THREADS), 0, stream, partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
+            hipLaunchKernelGGL((msm_task_reduce<FB, 5>), dim3(rblocks), dim3(MSM_THREADS), 0, stream,
+                               (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
+        }
     };
     if (p.fine_bits == 6) launch_shape(std::integral_constant<uint32_t, 6>{}); else launch_shape(std::integral_constant<uint32_t, 7>{});
     hipLaunchKernelGGL(msm_bin_fold, dim3((total_bins + MSM_THREADS / 64 - 1) / (MSM_THREADS / 64)), dim3(MSM_THREADS), 0, stream, task_out, (const uint32_t *)task_start, total_bins);

@@ -333,6 +333,14 @@ def test_msm_17bit_windows_scalar_distributions(srs19_ctx, kind):
     torch.cuda.synchronize()
     pair = srs19_ctx.msm_batch_dev([d, d], n)
     assert np.array_equal(np.asarray(pair[0]), want) and np.array_equal(np.asarray(pair[1]), want)
+    # a batch of three or more takes the 16-lanes-per-task shape of the bucket reduction (msm_fold_hot / msm_task_reduce,
+    # four buckets per lane): the same vector, the vector reversed and the same vector again
+    rev = ks[::-1]
+    d2 = torch.from_numpy(ol.fr_vec(rev).view(np.int64)).to("cuda:0")
+    torch.cuda.synchronize()
+    trio = srs19_ctx.msm_batch_dev([d, d2, d], n)
+    assert np.array_equal(np.asarray(trio[0]), want) and np.array_equal(np.asarray(trio[2]), want)
+    assert np.array_equal(np.asarray(trio[1]), _trapdoor(rev))
 
 
 def test_msm_differential_fuzz():
