@@ -79,8 +79,11 @@ int32_t mul3(Fr *out, const Fr *a, const Fr *b, const Fr &sc, uint32_t n, hipStr
 // totals: where the block totals live (default: the context's poly_tmp; two scans in flight on two streams need two)
 int32_t scan(plk_ctx *ctx, Fr *out, const Fr *in, uint32_t n, bool mult, bool reverse, bool exclusive, hipStream_t s, DevBuf *totals = nullptr);
 // two product scans of equal length in one launch per phase (the grand product's numerator prefix / denominator suffix)
+// pre0 / pre1 given: the third phase (block prefixes folded in) is left to mul3_blocks; see poly.hip
+constexpr uint32_t POLY_SCAN_BLOCK = 2048;   // elements per block of the scans: a scan of n elements has ceil(n / 2048) prefixes, then its grand total
 int32_t scan_pair_mult(plk_ctx *ctx, Fr *out0, const Fr *in0, bool reverse0, bool exclusive0, Fr *out1, const Fr *in1, bool reverse1, bool exclusive1,
-                       uint32_t n, hipStream_t s);
+                       uint32_t n, hipStream_t s, const Fr **pre0 = nullptr, const Fr **pre1 = nullptr);
+int32_t mul3_blocks(Fr *out, const Fr *a, const Fr *b, const Fr *pre_a, const Fr *pre_b, const Fr &sc, uint32_t n, hipStream_t s);
 int32_t quotient(const QuotientArgs &a, hipStream_t s);
 // data = the four per-coset coefficient vectors u_k of icoset4cm_dev (u_k at data + k*n) -> the 4n coefficients, natural order, in place;
 // constants in the W domain: i^-1 (i = omega_4) and s_c = 7^(-N c) / 4

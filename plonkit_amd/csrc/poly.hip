@@ -15,6 +15,7 @@ namespace plk {
 constexpr int PT = 256;                 // threads per block
 constexpr int EPT = 8;                  // elements per thread in scans / reductions
 constexpr int BLOCK_ELEMS = PT * EPT;
+static_assert(BLOCK_ELEMS == (int)POLY_SCAN_BLOCK, "poly.h: POLY_SCAN_BLOCK");
 
 // Compile-time loop: f(integral_constant<int, 0>) .. f(integral_constant<int, N - 1>).  `#pragma unroll` is only a request: the loops over
 // the four wire columns in k_perm_terms and k_quotient (two products of the 29-bit layer per trip) were left rolled, and a rolled loop that
@@ -86,6 +87,15 @@ __global__ void __launch_bounds__(PT) k_perm_terms(PermArgs a) {
 __global__ void __launch_bounds__(PT) k_mul3(Fr *out, const Fr *a, const Fr *b, Fr s, uint32_t n) {
     uint32_t i = blockIdx.x * PT + threadIdx.x;
     if (i < n) stw(out + i, csub_p(mulw(mulw(ldw(a + i), ldw(b + i)), cw(s))));
+}
+
+// the same with the third phase of the two product scans folded in (scan_pair_mult with pre0 / pre1): a = block-local PREFIX scan in memory order,
+// b = block-local scan of the REVERSED vector, pre_a / pre_b their block prefixes in scan order — one pass over memory and one launch less in round 2
+__global__ void __launch_bounds__(PT) k_mul3_blocks(Fr *out, const Fr *a, const Fr *b, const Fr *pre_a, const Fr *pre_b, Fr s, uint32_t n) {
+    uint32_t i = blockIdx.x * PT + threadIdx.x;
+    if (i >= n) return;
+    const FrW9 pa = ldw(pre_a + i / BLOCK_ELEMS), pb = ldw(pre_b + (n - 1 - i) / BLOCK_ELEMS);
+    stw(out + i, csub_p(mulw(mulw(mulw(ldw(a + i), pa), mulw(ldw(b + i), pb)), cw(s))));
 }
 
 // -------------------------------------------------------------------------------- scans
@@ -165,6 +175,7 @@ __device__ __forceinline__ void scan_totals_body(Fr *tot, uint32_t nb) {
     }
     Fr acc = tid ? sh[tid - 1] : ident<MULT>();
     for (uint32_t i = lo; i < hi; i++) { Fr x = load_fp(tot + i); store_fp(tot + i, acc); acc = op<MULT>(acc, x); }
+    if (lo < hi && hi == nb) store_fp(tot + nb, fin<MULT>(acc));         // the grand total, canonical, in the slot behind the nb prefixes
 }
 
 template <bool MULT> __global__ void __launch_bounds__(1024) k_scan_totals(Fr *tot, uint32_t nb) { scan_totals_body<MULT>(tot, nb); }
@@ -189,17 +200,22 @@ template <bool MULT> __global__ void __launch_bounds__(PT) k_scan_apply_pair(Sca
 }
 
 // two product scans of length n at once: (out0 <- scan of in0, reverse0, exclusive0) and the same for 1
+// pre0 / pre1 (optional): leave the third phase to the consumer (mul3_blocks) — on return *pre points at the scan's nb block prefixes (scan order)
+// followed by its grand total (canonical), valid until the context's next scan; nullptr when the scans fit one block (then they are complete).
 int32_t scan_pair_mult(plk_ctx *ctx, Fr *out0, const Fr *in0, bool reverse0, bool exclusive0, Fr *out1, const Fr *in1, bool reverse1, bool exclusive1,
-                       uint32_t n, hipStream_t s) {
+                       uint32_t n, hipStream_t s, const Fr **pre0, const Fr **pre1) {
     const uint32_t nb = (n + BLOCK_ELEMS - 1) / BLOCK_ELEMS;
-    PLK_TRY(ctx->poly_tmp.reserve((size_t)2 * nb * sizeof(Fr)));
+    PLK_TRY(ctx->poly_tmp.reserve((size_t)2 * (nb + 1) * sizeof(Fr)));
     ScanPair a;
     a.out[0] = out0; a.in[0] = in0; a.reverse[0] = reverse0 ? 1 : 0; a.exclusive[0] = exclusive0 ? 1 : 0; a.tot[0] = ctx->poly_tmp.as<Fr>();
-    a.out[1] = out1; a.in[1] = in1; a.reverse[1] = reverse1 ? 1 : 0; a.exclusive[1] = exclusive1 ? 1 : 0; a.tot[1] = ctx->poly_tmp.as<Fr>() + nb;
+    a.out[1] = out1; a.in[1] = in1; a.reverse[1] = reverse1 ? 1 : 0; a.exclusive[1] = exclusive1 ? 1 : 0; a.tot[1] = ctx->poly_tmp.as<Fr>() + nb + 1;
+    const bool defer = pre0 && pre1 && nb > 1;
+    if (pre0) *pre0 = defer ? a.tot[0] : nullptr;
+    if (pre1) *pre1 = defer ? a.tot[1] : nullptr;
     hipLaunchKernelGGL(k_scan_local_pair<true>, dim3(nb, 2), dim3(PT), 0, s, a, n);
     if (nb > 1) {
         hipLaunchKernelGGL(k_scan_totals_pair<true>, dim3(1, 2), dim3(1024), 0, s, a, nb);
-        hipLaunchKernelGGL(k_scan_apply_pair<true>, dim3(nb, 2), dim3(PT), 0, s, a, n);
+        if (!defer) hipLaunchKernelGGL(k_scan_apply_pair<true>, dim3(nb, 2), dim3(PT), 0, s, a, n);
     }
     PLK_HIP(hipGetLastError());
     return PLK_OK;
@@ -208,7 +224,7 @@ int32_t scan_pair_mult(plk_ctx *ctx, Fr *out0, const Fr *in0, bool reverse0, boo
 int32_t scan(plk_ctx *ctx, Fr *out, const Fr *in, uint32_t n, bool mult, bool reverse, bool exclusive, hipStream_t s, DevBuf *totals) {
     uint32_t nb = (n + BLOCK_ELEMS - 1) / BLOCK_ELEMS;
     DevBuf &tb = totals ? *totals : ctx->poly_tmp;
-    PLK_TRY(tb.reserve((size_t)nb * sizeof(Fr)));
+    PLK_TRY(tb.reserve((size_t)(nb + 1) * sizeof(Fr)));           // nb block totals + the grand total (scan_totals_body)
     Fr *tot = tb.as<Fr>();
     if (mult) {
         hipLaunchKernelGGL(k_scan_local<true>, dim3(nb), dim3(PT), 0, s, out, in, tot, n, reverse ? 1 : 0, exclusive ? 1 : 0);
@@ -504,6 +520,11 @@ int32_t check_gates(const CheckArgs &a, hipStream_t s) {
 }
 int32_t perm_terms(const PermArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_perm_terms, grid1(a.n), dim3(PT), 0, s, a);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+int32_t mul3_blocks(Fr *out, const Fr *a, const Fr *b, const Fr *pre_a, const Fr *pre_b, const Fr &sc, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_mul3_blocks, grid1(n), dim3(PT), 0, s, out, a, b, pre_a, pre_b, sc, n);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
 }

@@ -594,13 +594,20 @@ static int32_t prove_impl(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c
         pa.beta = to_dev(beta * HFr::from_u64(32)); pa.gamma = to_dev(gamma); pa.fix = to_dev(HFr::from_u64(1u << 25));   // domains: poly.h
         pa.n = (uint32_t)N; pa.log_n = log_n; pa.tw = ctx->tw_fwd_w;
         PLK_TRY(perm_terms(pa, st));
-        PLK_TRY(scan_pair_mult(ctx, t1, t1, false, true, t2, t2, true, false, (uint32_t)N, st));
+        // (the scans stop after their second phase when they span several blocks: the block prefixes are folded in by the product below,
+        //  and C_0 — the product of all denominators — is the suffix scan's grand total, which its second phase leaves behind the prefixes)
+        const Fr *pre_a = nullptr, *pre_c = nullptr;
+        static const bool fuse_scan_tail = [] { const char *e = getenv("PLK_PROVE_FUSE_SCAN_TAIL"); return !(e && e[0] == '0'); }();   // A/B knob, read once
+        PLK_TRY(scan_pair_mult(ctx, t1, t1, false, true, t2, t2, true, false, (uint32_t)N, st, fuse_scan_tail ? &pre_a : nullptr, fuse_scan_tail ? &pre_c : nullptr));
+        const uint32_t scan_blocks = pre_c ? (uint32_t)((N + POLY_SCAN_BLOCK - 1) / POLY_SCAN_BLOCK) : 0;
         HFr total;
-        PLK_HIP(hipMemcpyAsync(total.l, t2, sizeof(Fr), hipMemcpyDeviceToHost, st));
+        PLK_HIP(hipMemcpyAsync(total.l, pre_c ? pre_c + scan_blocks : t2, sizeof(Fr), hipMemcpyDeviceToHost, st));
         PLK_HIP(hipStreamSynchronize(st));
         if (total.is_zero()) { set_error("grand product denominator vanished (probability ~2^-230)"); return PLK_ERR_UNSAT; }
         // the scans live in the W domain: what was read is 32 * C_0, so E(1 / C_0) = 32 * E(1 / (32 C_0))
-        PLK_TRY(mul3(z_coef, t1, t2, to_dev(total.inv() * HFr::from_u64(32)), (uint32_t)N, st));
+        const Fr inv_c0 = to_dev(total.inv() * HFr::from_u64(32));
+        if (pre_c) PLK_TRY(mul3_blocks(z_coef, t1, t2, pre_a, pre_c, inv_c0, (uint32_t)N, st));
+        else PLK_TRY(mul3(z_coef, t1, t2, inv_c0, (uint32_t)N, st));
         if (use_lagrange) PLK_HIP(hipMemcpyAsync(t1, z_coef, N * sizeof(Fr), hipMemcpyDeviceToDevice, st));   // keep the values
         PLK_TRY(ntt_dev(ctx, z_coef, log_n, true, nullptr, st));
     }
