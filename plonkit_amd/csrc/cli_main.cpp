@@ -6,7 +6,7 @@
 //
 // Multi-GPU (an extension; the reference is one process): start one `plonkit prove` / `export-verification-key` per GPU
 // with PLONKIT_WORLD=<ranks> PLONKIT_RANK=<r> and PLONKIT_COMM=rccl:<id file> (rank 0 writes the RCCL unique id there, the
-// others wait for it; set PLONKIT_RUN_ID=<nonce> on all ranks when several runs may share the path) or PLONKIT_COMM=tcp:<port> (ranks sharing one device).  Rank r uses device PLONKIT_DEVICE or
+// others wait for it; PLONKIT_RUN_ID=<nonce of this run> on all ranks is mandatory with it) or PLONKIT_COMM=tcp:<port> (ranks sharing one device).  Rank r uses device PLONKIT_DEVICE or
 // r mod #devices, keeps only its 1/world slice of the key resident and computes its share of every commitment
 // (plk_comm_init, include/plonkit_amd.h); every rank derives the same bytes and rank 0 writes the files.
 #include "../../include/plonkit_amd.h"
