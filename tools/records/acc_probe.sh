@@ -1,6 +1,6 @@
 R=$PWD; cd /tmp; export TMPDIR=/tmp
 for c in 3 5; do for d in 0 1 3; do
-PLK_MSM_COPIES=$c PLK_MSM_DEBUG=$d rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_${c}_$d -o p -- python $R/tools/msm_c_probe.py 21 > /tmp/o.log 2>&1
+PLK_MSM_COPIES=$c PLK_MSM_DEBUG=$d rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_${c}_$d -o p -- python $R/tools/records/msm_c_probe.py 21 > /tmp/o.log 2>&1
 f=$(find /tmp/p_${c}_$d -name "*kernel_stats*")
 python3 - $f $c $d <<PY
 import csv,sys

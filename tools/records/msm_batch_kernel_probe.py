@@ -1,7 +1,7 @@
 """accumulate-kernel time per commitment for batches of 1..4 vectors of 2^log_n uniform scalars, one batch at a time
-(HIP events around msm_accumulate): python tools/msm_batch_kernel_probe.py [log_n]"""
+(HIP events around msm_accumulate): python tools/records/msm_batch_kernel_probe.py [log_n]"""
 import os, sys, time
-sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
+sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
 import numpy as np, torch
 import plonkit_amd as pa
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20

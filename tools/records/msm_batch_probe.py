@@ -1,6 +1,6 @@
-"""batched commitments vs single ones at 2^log_n: python tools/msm_batch_probe.py <log_n> <batch>"""
+"""batched commitments vs single ones at 2^log_n: python tools/records/msm_batch_probe.py <log_n> <batch>"""
 import os, sys, time
-sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
+sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
 import numpy as np, torch
 import plonkit_amd as pa
 log_n = int(sys.argv[1]); batch = int(sys.argv[2])

@@ -1,6 +1,6 @@
-"""commitment stream with B vectors per pass of the kernels, two passes in flight: python tools/msm_batch_stream_probe.py"""
+"""commitment stream with B vectors per pass of the kernels, two passes in flight: python tools/records/msm_batch_stream_probe.py"""
 import os, sys, time
-sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
+sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
 import numpy as np, torch
 import plonkit_amd as pa
 from plonkit_amd.sharded import ShardedMsm

@@ -1,6 +1,6 @@
-"""window-width probe: PLK_MSM_C=<c> python tools/msm_c_probe.py <log_n...> — time + result fingerprint"""
+"""window-width probe: PLK_MSM_C=<c> python tools/records/msm_c_probe.py <log_n...> — time + result fingerprint"""
 import sys, time, hashlib
-import os; sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
+import os; sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
 import numpy as np, torch
 import plonkit_amd as pa
 ctx = pa.Context(0); dev = torch.device("cuda:0")

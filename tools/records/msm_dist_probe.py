@@ -1,6 +1,6 @@
-"""MSM time at 2^20 for the scalar distributions of SURVEY.md §8(d): python tools/msm_dist_probe.py"""
+"""MSM time at 2^20 for the scalar distributions of SURVEY.md §8(d): python tools/records/msm_dist_probe.py"""
 import os, sys, time
-sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
+sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
 import numpy as np, torch
 import plonkit_amd as pa
 from oracle import oracle_lib as ol

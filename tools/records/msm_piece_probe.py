@@ -1,6 +1,6 @@
-"""one long commitment as pieces over successive SRS ranges, up to three pieces in flight: python tools/msm_piece_probe.py [log_n] [reps]"""
+"""one long commitment as pieces over successive SRS ranges, up to three pieces in flight: python tools/records/msm_piece_probe.py [log_n] [reps]"""
 import os, sys, time
-sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
+sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
 import numpy as np
 import torch
 import plonkit_amd as pa

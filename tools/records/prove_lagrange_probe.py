@@ -1,6 +1,6 @@
-"""prove with and without a resident Lagrange-form key (`prove -l`, src/plonk.rs:138-146) at the 2^log_n domain: python tools/prove_lagrange_probe.py [log_n] [reps]"""
+"""prove with and without a resident Lagrange-form key (`prove -l`, src/plonk.rs:138-146) at the 2^log_n domain: python tools/records/prove_lagrange_probe.py [log_n] [reps]"""
 import os, sys, time
-sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
+sys.path.insert(0, os.path.abspath(os.environ.get("PLK_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))   # PLK_AB_ROOT=ab_old: tools/ab_build.sh
 import torch
 import plonkit_amd as pa
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
