@@ -18,8 +18,14 @@
 // at the boundary.  No MFMA: these are 29x29->58-bit integer multiply-adds on the VALU.
 #pragma once
 #include "field_dev.h"
+#include <utility>
 
 namespace plk {
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{}) — `#pragma unroll` is only a
+// request, and a loop the compiler leaves rolled puts the register arrays it indexes into scratch memory
+template <int... J, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, J...>, F &&f) { (f(std::integral_constant<int, J>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f)); }
 
 constexpr uint32_t M29 = (1u << 29) - 1;
 constexpr uint32_t MULW_A_LIMB_MAX = 3280000000u;          // largest limb of mulw's LEFT operand (derivation at mulw)

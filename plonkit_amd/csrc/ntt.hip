@@ -34,6 +34,7 @@
 #include "ntt.h"
 #include "poly.h"
 #include "field29_dev.h"
+#include "ntt_plan.h"
 #include <cstdlib>
 #include <algorithm>
 #include <vector>
@@ -276,6 +277,181 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------- wave-owned tile passes (round 5)
+// The same passes as ntt_pass_cols / ntt_pass_rows for full 2048-element tiles of 7..10 row bits, restructured so that the
+// waves of a workgroup run apart (ntt_plan.h has the index plan and its host-side proof):
+//   * round 0 takes its four rows straight from HBM, the last round multiplies by the inter-pass twiddle (or canonicalises)
+//     and stores straight to HBM: NR - 1 LDS exchanges per pass instead of NR + 1;
+//   * an exchange inside a phase is private to ONE wave (the LDS executes a wave's instructions in order, so a compiler
+//     fence is all it needs); the only workgroup barriers of a pass are the two around the phase A -> phase B hand-over,
+//     against one barrier per round (six per pass at 2^20) before.  Measured with rocprofv3 counters on the old kernels
+//     (profiles/r05_ntt_pmc_before.txt): a wave was parked at s_waitcnt / s_barrier 38 % of its life, the VALU about 70 %
+//     busy — the barriers made all eight waves of a tile (and usually both tiles of a CU) do their LDS traffic at the same time;
+//   * LDS is laid out the way the reader reads it: 64 consecutive 16-byte words per instruction, no bank conflicts on either
+//     side (pads per round from the plan), one address register with immediate offsets.
+// The butterfly arithmetic is r4_finish's, bit for bit (same lazy bounds); `nonzero` / `quarter` inputs (zero-padded natural-
+// order LDE) stay on the old kernels.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// stages S .. S+NST-1 on a lane's four rows row0 + {0, h, 2h, 3h} (h = 2^S); outputs normalised
+template <int LR, int S, int NST>
+__device__ __forceinline__ void wave_round(FrW9 &x0, FrW9 &x1, FrW9 &x2, FrW9 &x3, const PowTable &tw, uint32_t row0) {
+    constexpr uint32_t h = 1u << S;
+    if constexpr (NST == 1) {                                   // one twiddle-free stage (S = 0): pairs (0,1) and (2,3)
+        static_assert(S == 0, "a single stage is only ever the first");
+        const FrW9 v1 = normw(x1), v3 = normw(x3);
+        const FrW9 u0 = x0, u2 = x2;
+        x0 = addn(u0, v1); x1 = sub2(u0, v1);              // inputs < 1.1p
+        x2 = addn(u2, v3); x3 = sub2(u2, v3);
+    } else {
+        const uint32_t jl = row0 & (h - 1);
+        FrW9 y1 = x1, y3 = x3;
+        if constexpr (S > 0) {
+            const FrW9 t1 = small_tw(tw, jl << (LR - S - 1), LR);
+            mulw2(x1, t1, x3, t1, y1, y3);
+        }
+        FrW9 u, v;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { u.l[i] = x2.l[i] + y3.l[i]; v.l[i] = x2.l[i] + FrW::PAD2[i] - y3.l[i]; }
+        FrW9 b2 = u, b3;
+        const FrW9 t3 = small_tw(tw, (jl + h) << (LR - S - 2), LR);
+        if constexpr (S > 0) {
+            const FrW9 t2 = small_tw(tw, jl << (LR - S - 2), LR);
+            mulw2(u, t2, v, t3, b2, b3);
+        } else b3 = mulw(v, t3);
+        FrW9 o0, o1, o2, o3;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {                           // bounds: r4_finish
+            const uint32_t b0 = x0.l[i] + y1.l[i];
+            o0.l[i] = b0 + b2.l[i];
+            o2.l[i] = b0 + FrW::PAD4[i] - b2.l[i];
+            o1.l[i] = x0.l[i] + FrW::PAD2[i] - y1.l[i] + b3.l[i];
+            o3.l[i] = x0.l[i] + FrW::PAD4[i] - y1.l[i] - b3.l[i];
+        }
+        x0 = normw(o0); x1 = normw(o1); x2 = normw(o2); x3 = normw(o3);
+    }
+}
+
+template <int LR, bool ROWS>
+__global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_w(NttPassArgs a) {
+    using P = TilePlan<LR>;
+    constexpr uint32_t LC = P::LC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LdsTile L{reinterpret_cast<u32x4 *>(smem), reinterpret_cast<u32x4 *>(smem) + NTT_W_SLOTS,
+                    reinterpret_cast<uint32_t *>(reinterpret_cast<u32x4 *>(smem) + 2 * NTT_W_SLOTS)};
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, t = blockIdx.x;
+    const Fr *const in = a.in_b[blockIdx.y];
+    Fr *const out = a.out_b[blockIdx.y];
+    // where the tile lives: cols — R rows of stride 2^log_inner, C adjacent columns from c0; rows — C contiguous rows of R
+    // elements, row c = sub-transform (k1_0 + c, mu) (ntt_pass_cols / ntt_pass_rows have the same arithmetic)
+    uint32_t c0 = 0, k1_0 = 0, mu = 0, log_m = 0;
+    size_t base = 0;
+    if constexpr (!ROWS) {
+        const uint32_t tiles_log = a.log_inner - LC;
+        c0 = (t & ((1u << tiles_log) - 1)) << LC;
+        base = ((size_t)(t >> tiles_log) << (LR + a.log_inner)) + c0;
+    } else {
+        const uint32_t kb_log = a.log_r1 - LC;
+        log_m = a.log_m1 + a.log_m2;
+        k1_0 = (t & ((1u << kb_log) - 1)) << LC; mu = t >> kb_log;
+    }
+
+    FrW9 x0, x1, x2, x3;                                        // (named registers, compile-time loops: nothing of this may land in scratch)
+    auto X = [&](auto K) -> FrW9 & { constexpr int k = decltype(K)::value; if constexpr (k == 0) return x0; else if constexpr (k == 1) return x1; else if constexpr (k == 2) return x2; else return x3; };
+    {                                                           // round 0 reads HBM: LDS row i is input row bitrev(i)
+        uint32_t row0, col;
+        P::template locate<0>(wave, lane, 0, row0, col);
+        auto addr = [&](uint32_t k) __attribute__((always_inline)) -> size_t {
+            const uint32_t n = brev(row0 + k, LR);              // (round 0 starts at stage 0: the four rows are row0 + k)
+            if constexpr (!ROWS) return base + ((size_t)n << a.log_inner) + col;
+            else return (((((size_t)(k1_0 + col)) << log_m) + mu) << LR) + n;
+        };
+        const size_t g0 = addr(0), g1 = addr(1), g2 = addr(2), g3 = addr(3);
+        x0 = ldw(in + g0); x1 = ldw(in + g1); x2 = ldw(in + g2); x3 = ldw(in + g3);
+        const Fr *const pre_direct = a.pre_direct_b[blockIdx.y];
+        const PowTable pre = a.pre_b[blockIdx.y];
+        if (pre_direct) {
+            FrW9 y0, y1;
+            mulw2(x0, ldw(pre_direct + g0), x1, ldw(pre_direct + g1), y0, y1); x0 = y0; x1 = y1;
+            mulw2(x2, ldw(pre_direct + g2), x3, ldw(pre_direct + g3), y0, y1); x2 = y0; x3 = y1;
+        } else if (pre.lo) {
+            auto pair = [&](FrW9 &u, FrW9 &v, uint32_t e0, uint32_t e1) __attribute__((always_inline)) {
+                FrW9 p0, p1, y0, y1;
+                mulw2(ldw(pre.lo + (e0 & (POW_TAB - 1))), ldw(pre.hi + (e0 >> POW_SPLIT)), ldw(pre.lo + (e1 & (POW_TAB - 1))), ldw(pre.hi + (e1 >> POW_SPLIT)), p0, p1);
+                mulw2(u, p0, v, p1, y0, y1); u = y0; v = y1;
+            };
+            pair(x0, x1, (uint32_t)g0, (uint32_t)g1);
+            pair(x2, x3, (uint32_t)g2, (uint32_t)g3);
+        }
+    }
+    static_for<P::NR>([&](auto RR) {
+        constexpr int r = decltype(RR)::value;
+        if constexpr (r > 0) {                                  // exchange: what round r-1 left in registers -> the layout round r reads
+            constexpr bool handover = P::pb(r - 1) != P::pb(r);
+            uint32_t prow, pcol;
+            P::template locate<r - 1>(wave, lane, 0, prow, pcol);
+            static_for<4>([&](auto K) { constexpr uint32_t k = decltype(K)::value; L.put(P::template slot<r>(prow + (k << P::rs(r - 1)), pcol), X(K)); });
+            if constexpr (handover) __syncthreads(); else wave_lds_fence();
+            static_for<4>([&](auto K) { constexpr uint32_t k = decltype(K)::value; X(K) = L.get(P::template own_slot<r>(wave, lane, k)); });
+        }
+        // the round after this one hands over to phase B, i.e. writes into the other waves' regions: they must all have
+        // finished reading theirs (their gets of THIS round) first
+        if constexpr (r > 0 && r + 1 < P::NR && P::pb(r) != P::pb(r + 1)) __syncthreads();
+        uint32_t row0, col;
+        P::template locate<r>(wave, lane, 0, row0, col);
+        wave_round<LR, P::rs(r), P::rn(r)>(x0, x1, x2, x3, a.tw, row0);
+    });
+    {                                                           // the last round's rows row0 + k * R/4 go straight out
+        uint32_t row0, col;
+        P::template locate<P::NR - 1>(wave, lane, 0, row0, col);
+        if constexpr (!ROWS) {
+            const uint32_t eshift = MAX_LOG_N - (LR + a.log_inner);
+            auto off = [&](uint32_t k) __attribute__((always_inline)) -> size_t { return ((size_t)(row0 + (k << (LR - 2))) << a.log_inner) + c0 + col; };
+            auto twd = [&](uint32_t k, size_t o) __attribute__((always_inline)) -> FrW9 {
+                const uint32_t e = ((row0 + (k << (LR - 2))) * (c0 + col)) << eshift;
+                return a.tw_direct ? ldw(a.tw_direct + o) : eshift >= POW_SPLIT ? ldw(a.tw.hi + (e >> POW_SPLIT)) : pow2l_w(a.tw, e);
+            };
+            Fr *const ob = out + (base - c0);
+            auto finish = [&](const FrW9 &u, const FrW9 &v, uint32_t k) __attribute__((always_inline)) {      // (two twiddles at a time: four would not fit 128 registers)
+                const size_t o0 = off(k), o1 = off(k + 1);
+                const FrW9 t0 = twd(k, o0), t1 = twd(k + 1, o1);
+                FrW9 y0, y1;
+                mulw2(u, t0, v, t1, y0, y1);                    // < 1.1p: fits 256 bits, stays lazy
+                store_fp(ob + o0, pack<FrParams>(y0)); store_fp(ob + o1, pack<FrParams>(y1));
+            };
+            finish(x0, x1, 0);
+            finish(x2, x3, 2);
+        } else {
+            const uint32_t k2 = mu >> a.log_m2, k3 = mu & ((1u << a.log_m2) - 1);
+            const size_t drev = (size_t)k2 + ((size_t)k3 << a.log_m1);
+            const Fr *const post_direct = a.post_direct_b[blockIdx.y];
+            const PowTable post = a.post_b[blockIdx.y];
+            const FrW9 last = unpack<FrW>(a.scale);             // 1/n on inverse transforms
+            auto finish = [&](FrW9 v0, FrW9 v1, uint32_t k) __attribute__((always_inline)) {
+                const size_t o0 = (size_t)(k1_0 + col) + (drev << a.log_r1) + ((size_t)(row0 + (k << (LR - 2))) << (a.log_n - LR));
+                const size_t o1 = (size_t)(k1_0 + col) + (drev << a.log_r1) + ((size_t)(row0 + ((k + 1) << (LR - 2))) << (a.log_n - LR));
+                FrW9 y0, y1;
+                if (post_direct) { mulw2(v0, ldw(post_direct + o0), v1, ldw(post_direct + o1), y0, y1); v0 = y0; v1 = y1; }
+                else if (post.lo) {
+                    const uint32_t e0 = (uint32_t)o0, e1 = (uint32_t)o1;
+                    FrW9 p0, p1;
+                    mulw2(ldw(post.lo + (e0 & (POW_TAB - 1))), ldw(post.hi + (e0 >> POW_SPLIT)), ldw(post.lo + (e1 & (POW_TAB - 1))), ldw(post.hi + (e1 >> POW_SPLIT)), p0, p1);
+                    mulw2(v0, p0, v1, p1, y0, y1); v0 = y0; v1 = y1;
+                }
+                if (a.has_scale) { mulw2(v0, last, v1, last, y0, y1); v0 = csub_p(y0); v1 = csub_p(y1); }
+                else { v0 = reduce_small(v0); v1 = reduce_small(v1); }       // canonical output (values here are < 24p)
+                store_fp(out + o0, pack<FrParams>(v0)); store_fp(out + o1, pack<FrParams>(v1));
+            };
+            finish(x0, x1, 0);
+            finish(x2, x3, 2);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- tables
 // w_domain: entries 32 * base^e, i.e. base^e * 2^261 — what the 29-bit layer's products take as a constant (poly.hip)
 __global__ void fill_pow_table(Fr *lo, Fr *hi, Fr base, int w_domain = 0) {
@@ -479,6 +655,31 @@ static int32_t ntt_direct_table(plk_ctx *ctx, bool inverse, uint32_t log_r, uint
 // ------------------------------------------------------------------------------- driver
 static std::atomic<bool> g_attr_set{false};                    // (several contexts may transform from several host threads)
 
+// the wave-owned passes (ntt_pass_w) take every full 2048-element tile of 7..10 row bits; PLK_NTT_WAVE=0 keeps the
+// barrier-per-round kernels for everything (A/B knob)
+constexpr size_t NTT_W_LDS = (size_t)36 * NTT_W_SLOTS;
+static bool ntt_wave_enabled() {
+    static const int on = [] { const char *e = getenv("PLK_NTT_WAVE"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+static bool ntt_wave_shape(const NttPassArgs &a) {
+    return ntt_wave_enabled() && a.log_r >= 7 && a.log_r <= 10 && a.log_r + a.log_c == LOG_TILE && a.nonzero == 0 && a.quarter == 0;
+}
+template <bool ROWS>
+static void ntt_launch_w(const NttPassArgs &a, dim3 grid, hipStream_t stream) {
+    switch (a.log_r) {
+        case 7: hipLaunchKernelGGL((ntt_pass_w<7, ROWS>), grid, dim3(NTT_THREADS), NTT_W_LDS, stream, a); break;
+        case 8: hipLaunchKernelGGL((ntt_pass_w<8, ROWS>), grid, dim3(NTT_THREADS), NTT_W_LDS, stream, a); break;
+        case 9: hipLaunchKernelGGL((ntt_pass_w<9, ROWS>), grid, dim3(NTT_THREADS), NTT_W_LDS, stream, a); break;
+        default: hipLaunchKernelGGL((ntt_pass_w<10, ROWS>), grid, dim3(NTT_THREADS), NTT_W_LDS, stream, a); break;
+    }
+}
+template <int LR> static hipError_t ntt_w_attr() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_w<LR, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_W_LDS);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_w<LR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_W_LDS);
+}
+
 // digits of the mixed-radix plan: up to 10 bits per pass
 static void digit_plan(uint32_t log_n, uint32_t d[4], uint32_t *passes) {
     d[0] = d[1] = d[2] = d[3] = 0;
@@ -533,6 +734,7 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
     if (!g_attr_set) {
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_cols), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        PLK_HIP(ntt_w_attr<7>()); PLK_HIP(ntt_w_attr<8>()); PLK_HIP(ntt_w_attr<9>()); PLK_HIP(ntt_w_attr<10>());
         g_attr_set = true;
     }
     PowTable pre{}, post{};
@@ -567,7 +769,8 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
         a.quarter = (i == 0 && nonzero && nonzero == (n >> 2) && !(d[0] & 1) && d[0] >= 2) ? 1 : 0;
         uint32_t tiles = (uint32_t)(n >> (a.log_r + a.log_c));
         size_t lds = (size_t)36 << (a.log_r + a.log_c);
-        hipLaunchKernelGGL(ntt_pass_cols, dim3(tiles, count), dim3(NTT_THREADS), lds, stream, a);
+        if (ntt_wave_shape(a)) ntt_launch_w<false>(a, dim3(tiles, count), stream);
+        else hipLaunchKernelGGL(ntt_pass_cols, dim3(tiles, count), dim3(NTT_THREADS), lds, stream, a);
     }
     {
         for (uint32_t b = 0; b < count; b++) { a.in_b[b] = (p == 1) ? src[b] : scratch + (size_t)b * n; a.out_b[b] = (p == 1) ? scratch + (size_t)b * n : data[b]; }
@@ -588,7 +791,8 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
         if (a.has_scale) a.scale = ctx->n_inv_w[log_n];
         uint32_t tiles = (uint32_t)(n >> (a.log_r + a.log_c));
         size_t lds = (size_t)36 << (a.log_r + a.log_c);
-        hipLaunchKernelGGL(ntt_pass_rows, dim3(tiles, count), dim3(NTT_THREADS), lds, stream, a);
+        if (p > 1 && ntt_wave_shape(a)) ntt_launch_w<true>(a, dim3(tiles, count), stream);
+        else hipLaunchKernelGGL(ntt_pass_rows, dim3(tiles, count), dim3(NTT_THREADS), lds, stream, a);
     }
     PLK_HIP(hipGetLastError());
     if (p == 1) for (uint32_t b = 0; b < count; b++) PLK_HIP(hipMemcpyAsync(data[b], scratch + (size_t)b * n, n * sizeof(Fr), hipMemcpyDeviceToDevice, stream));

@@ -20,8 +20,6 @@ static_assert(BLOCK_ELEMS == (int)POLY_SCAN_BLOCK, "poly.h: POLY_SCAN_BLOCK");
 // Compile-time loop: f(integral_constant<int, 0>) .. f(integral_constant<int, N - 1>).  `#pragma unroll` is only a request: the loops over
 // the four wire columns in k_perm_terms and k_quotient (two products of the 29-bit layer per trip) were left rolled, and a rolled loop that
 // indexes register arrays (w[j], bkx[j]) sends them to scratch memory — 304 B per lane in k_quotient until round 4.
-template <int... J, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, J...>, F &&f) { (f(std::integral_constant<int, J>{}), ...); }
-template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f)); }
 
 __device__ __forceinline__ Fr pow2l_(const PowTable &t, uint32_t e) {
     return mul(load_fp(t.lo + (e & (POW_TAB - 1))), load_fp(t.hi + (e >> POW_SPLIT)));
