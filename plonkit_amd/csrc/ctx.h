@@ -38,6 +38,7 @@ struct PowTable {
     const Fr *lo = nullptr;
     const Fr *hi = nullptr;
     const uint32_t *hi_sliced = nullptr;     // optional: the hi table as 9 x 29-bit limbs, 48 B per entry (NTT stage twiddles)
+    const uint32_t *hi_tw3 = nullptr;        // optional: the hi table as three shifted copies per entry (field29_dev.h mul_tw3), 112 B per entry
 };
 
 // grows-only device buffer.  `borrowed`: a view of another context's allocation (plk_ctx_share_srs) — never freed here,

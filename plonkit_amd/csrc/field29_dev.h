@@ -286,6 +286,87 @@ PLK_HD W9<WP> mul2addw(const W9<WP> &a, const W9<WP> &b, const W9<WP> &c, const 
     return r;
 }
 
+// ---- product by a CONSTANT that is held as three shifted copies ("tw3"): 108 multiply-adds instead of 162.
+// For a constant w keep  W_q = w * 2^(87 (q+1)) mod p  (q = 0, 1, 2; canonical, 9 limbs each).  Split the variable operand into
+// three chunks of three limbs, x = X_0 + X_1 2^87 + X_2 2^174: then  X_0 W_0 + X_1 W_1 + X_2 W_2 = x * w * 2^87 (mod p)  and all
+// three partial products start at column 0, so only THREE Montgomery steps (one per limb of 2^87) are needed to divide the 2^87
+// out again:
+//     mul_tw3(x, W) = (X_0 W_0 + X_1 W_1 + X_2 W_2 + m p) / 2^87  =  x * w  (mod p),      81 + 27 multiply-adds, 12 columns.
+// The constant costs 27 words instead of 9 — this is for constants that are read from a table many times (the NTT's stage
+// twiddles); no domain change: the result is in whatever domain x is in, w is the PLAIN value of the constant.
+// Bounds: a column holds at most 9 products x_j * W (x_j <= A, W < 2^29), 3 products m * p and a carry:
+// 9 A (2^29 - 1) + 3 (2^29 - 1)^2 + 2^35 < 2^64 for A <= 3.6e9 (MULTW3_X_LIMB_MAX).  The result depends on the chunk values, not on
+// the value of x: r < (X_0 + X_1 + X_2 + 2^87) p / 2^87, i.e. r < 4p for NORMALISED x (limbs < 2^29, so X_q < 2^87) — un-normalised
+// limbs are allowed but buy a bound of up to 19p (limbs of 3.2e9), so callers normalise first.  Output limbs are normalised.
+constexpr uint32_t MULTW3_X_LIMB_MAX = 3600000000u;
+template <class WP> struct Tw3 { uint32_t w[3][9]; };
+template <class WP>
+PLK_HD W9<WP> mul_tw3(const W9<WP> &x, const Tw3<WP> &t) {
+    uint32_t m[3];
+    W9<WP> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (k - i < 0 || k - i > 8) continue;
+#pragma unroll
+            for (int q = 0; q < 3; q++) { acc += (uint64_t)x.l[3 * q + i] * t.w[q][k - i]; PLK_CHAIN(acc); }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (i >= k || k - i > 8) continue;
+            acc += (uint64_t)m[i] * WP::P29[k - i]; PLK_CHAIN(acc);
+        }
+        if (k < 3) { m[k] = ((uint32_t)acc * WP::INV29) & M29; acc += (uint64_t)m[k] * WP::P29[0]; }
+        else r.l[k - 3] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+// two of them in lockstep with the SAME constant (the two products of a butterfly stage that share a twiddle)
+template <class WP>
+PLK_HD void mul_tw3_2(const W9<WP> &x0, const W9<WP> &x1, const Tw3<WP> &t, W9<WP> &r0, W9<WP> &r1) {
+    uint32_t m0[3], m1[3];
+    uint64_t acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (k - i < 0 || k - i > 8) continue;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                acc0 += (uint64_t)x0.l[3 * q + i] * t.w[q][k - i]; PLK_CHAIN(acc0);
+                acc1 += (uint64_t)x1.l[3 * q + i] * t.w[q][k - i]; PLK_CHAIN(acc1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (i >= k || k - i > 8) continue;
+            acc0 += (uint64_t)m0[i] * WP::P29[k - i]; PLK_CHAIN(acc0);
+            acc1 += (uint64_t)m1[i] * WP::P29[k - i]; PLK_CHAIN(acc1);
+        }
+        if (k < 3) {
+            m0[k] = ((uint32_t)acc0 * WP::INV29) & M29; m1[k] = ((uint32_t)acc1 * WP::INV29) & M29;
+            acc0 += (uint64_t)m0[k] * WP::P29[0]; acc1 += (uint64_t)m1[k] * WP::P29[0];
+        } else { r0.l[k - 3] = (uint32_t)acc0 & M29; r1.l[k - 3] = (uint32_t)acc1 & M29; }
+        acc0 >>= 29; acc1 >>= 29;
+    }
+    r0.l[8] = (uint32_t)acc0; r1.l[8] = (uint32_t)acc1;
+}
+// the three copies of a constant given in the W domain (w * 2^261, canonical): W_2 is the value itself, W_1 and W_0 are it times
+// 2^-87 and 2^-174 — products by the limb-unit vectors 2^174 and 2^87 (mulw divides by 2^261)
+template <class WP>
+PLK_HD Tw3<WP> make_tw3(const W9<WP> &w_dom_w) {
+    W9<WP> e87 = w_zero<WP>(), e174 = w_zero<WP>();
+    e87.l[3] = 1; e174.l[6] = 1;
+    const W9<WP> w0 = csub_p(mulw(w_dom_w, e87)), w1 = csub_p(mulw(w_dom_w, e174));
+    Tw3<WP> t;
+    for (int i = 0; i < 9; i++) { t.w[0][i] = w0.l[i]; t.w[1][i] = w1.l[i]; t.w[2][i] = w_dom_w.l[i]; }
+    return t;
+}
+
 // ---- OPERAND-SCANNING forms of the same three products (identical results, bit for bit): ten independent 64-bit
 // column accumulators per row instead of one chain.  They issue 16 more instructions per product (the carries join their
 // columns through v_lshl_add_u64), but a wave that has its SIMD to itself — the bucket-reduction kernels of the MSM are

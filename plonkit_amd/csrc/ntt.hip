@@ -297,7 +297,28 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// stages S .. S+NST-1 on a lane's four rows row0 + {0, h, 2h, 3h} (h = 2^S); outputs normalised
+// omega_R^i (i < R/2) as a mul_tw3 constant: 7 x 16 bytes out of the hi table's tw3 copy
+__device__ __forceinline__ Tw3<FrW> small_tw3(const PowTable &t, uint32_t i, uint32_t log_r) {
+    const u32x4 *p = reinterpret_cast<const u32x4 *>(t.hi_tw3) + 7 * (size_t)(i << (POW_SPLIT - log_r));
+    uint32_t w[28];
+#pragma unroll
+    for (int k = 0; k < 7; k++) { const u32x4 v = p[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+    Tw3<FrW> r;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int k = 0; k < 9; k++) r.w[q][k] = w[9 * q + k];
+    return r;
+}
+
+// stages S .. S+NST-1 on a lane's four rows row0 + {0, h, 2h, 3h} (h = 2^S); outputs normalised.
+// The stage twiddles are mul_tw3 constants (108 multiply-adds per product instead of 162).  A mul_tw3 result is < 4p whatever the
+// value of its (normalised) operand, so with inputs < V the outputs of a two-stage round are < V + 8p:
+//     y1, y3 < 4p;   u = x2 + y3,  v = x2 + 4p - y3  (normalised before the second product);   b2, b3 < 4p;
+//     o0 = x0 + y1 + b2,  o2 = x0 + y1 + 4p - b2,  o1 = x0 + 4p - y1 + b3,  o3 = x0 + 8p - y1 - b3        (all < V + 8p)
+// and the first round (stage 0: y1 = x1, y3 = x3 < 2p, b2 = x2 + x3 un-multiplied) leaves < 7.3p from inputs < 1.3p.  Five rounds end
+// below 40p: inside the 2^261 capacity (170p) and reduce_small's 64p.  Limbs: every sum below stays under 2^32 (x < 2^29, PADk limbs
+// < 2.7e9, mul_tw3 outputs < 2^29), and the un-normalised operand of a product never occurs (u and v are normalised first).
 template <int LR, int S, int NST>
 __device__ __forceinline__ void wave_round(FrW9 &x0, FrW9 &x1, FrW9 &x2, FrW9 &x3, const PowTable &tw, uint32_t row0) {
     constexpr uint32_t h = 1u << S;
@@ -305,32 +326,29 @@ __device__ __forceinline__ void wave_round(FrW9 &x0, FrW9 &x1, FrW9 &x2, FrW9 &x
         static_assert(S == 0, "a single stage is only ever the first");
         const FrW9 v1 = normw(x1), v3 = normw(x3);
         const FrW9 u0 = x0, u2 = x2;
-        x0 = addn(u0, v1); x1 = sub2(u0, v1);              // inputs < 1.1p
+        x0 = addn(u0, v1); x1 = sub2(u0, v1);                  // inputs < 1.3p -> < 3.3p
         x2 = addn(u2, v3); x3 = sub2(u2, v3);
     } else {
         const uint32_t jl = row0 & (h - 1);
         FrW9 y1 = x1, y3 = x3;
-        if constexpr (S > 0) {
-            const FrW9 t1 = small_tw(tw, jl << (LR - S - 1), LR);
-            mulw2(x1, t1, x3, t1, y1, y3);
-        }
+        if constexpr (S > 0) mul_tw3_2(x1, x3, small_tw3(tw, jl << (LR - S - 1), LR), y1, y3);
         FrW9 u, v;
 #pragma unroll
-        for (int i = 0; i < 9; i++) { u.l[i] = x2.l[i] + y3.l[i]; v.l[i] = x2.l[i] + FrW::PAD2[i] - y3.l[i]; }
-        FrW9 b2 = u, b3;
-        const FrW9 t3 = small_tw(tw, (jl + h) << (LR - S - 2), LR);
-        if constexpr (S > 0) {
-            const FrW9 t2 = small_tw(tw, jl << (LR - S - 2), LR);
-            mulw2(u, t2, v, t3, b2, b3);
-        } else b3 = mulw(v, t3);
+        for (int i = 0; i < 9; i++) {
+            u.l[i] = x2.l[i] + y3.l[i];
+            v.l[i] = x2.l[i] + (S > 0 ? FrW::PAD4[i] : FrW::PAD2[i]) - y3.l[i];
+        }
+        FrW9 b2 = u;                                            // stage 1 of the first pair: omega_4^0 = 1
+        if constexpr (S > 0) b2 = mul_tw3(normw(u), small_tw3(tw, jl << (LR - S - 2), LR));
+        const FrW9 b3 = mul_tw3(normw(v), small_tw3(tw, (jl + h) << (LR - S - 2), LR));
         FrW9 o0, o1, o2, o3;
 #pragma unroll
-        for (int i = 0; i < 9; i++) {                           // bounds: r4_finish
+        for (int i = 0; i < 9; i++) {
             const uint32_t b0 = x0.l[i] + y1.l[i];
             o0.l[i] = b0 + b2.l[i];
-            o2.l[i] = b0 + FrW::PAD4[i] - b2.l[i];
-            o1.l[i] = x0.l[i] + FrW::PAD2[i] - y1.l[i] + b3.l[i];
-            o3.l[i] = x0.l[i] + FrW::PAD4[i] - y1.l[i] - b3.l[i];
+            o2.l[i] = b0 + FrW::PAD4[i] - b2.l[i];             // (S = 0: b2 is the raw x2 + x3 < 2.6p)
+            o1.l[i] = x0.l[i] + (S > 0 ? FrW::PAD4[i] : FrW::PAD2[i]) - y1.l[i] + b3.l[i];
+            o3.l[i] = x0.l[i] + (S > 0 ? FrW::PAD8[i] : FrW::PAD6[i]) - y1.l[i] - b3.l[i];
         }
         x0 = normw(o0); x1 = normw(o1); x2 = normw(o2); x3 = normw(o3);
     }
@@ -491,10 +509,21 @@ __global__ void table_slice(uint32_t *out, const Fr *in_w, uint32_t n) {
     for (int k = 9; k < 12; k++) out[12 * (size_t)i + k] = 0;
 }
 
-// allocates [lo | hi] in the external domain followed by [lo | hi] in the W domain and the sliced W-domain hi table
-static int32_t make_pow_table(plk_ctx *ctx, const Fr &base, PowTable *out, PowTable *out_w, void **alloc_out) {
+// the W-domain hi table as mul_tw3 constants: three shifted copies of 9 limbs, padded to 112 bytes (7 x 16) per entry
+constexpr uint32_t TW3_WORDS = 28;
+__global__ void table_tw3(uint32_t *out, const Fr *in_w, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Tw3<FrW> t = make_tw3(unpack<FrW>(load_fp(in_w + i)));             // (table_to_w leaves canonical values)
+    for (int q = 0; q < 3; q++) for (int k = 0; k < 9; k++) out[TW3_WORDS * (size_t)i + 9 * q + k] = t.w[q][k];
+    out[TW3_WORDS * (size_t)i + 27] = 0;
+}
+
+// allocates [lo | hi] in the external domain followed by [lo | hi] in the W domain, the sliced W-domain hi table and (tw3: the
+// transform's own twiddle tables only) the same hi table as mul_tw3 constants
+static int32_t make_pow_table(plk_ctx *ctx, const Fr &base, PowTable *out, PowTable *out_w, void **alloc_out, bool tw3 = false) {
     Fr *buf = nullptr;
-    PLK_HIP(hipMalloc(&buf, sizeof(Fr) * 4 * POW_TAB + (size_t)48 * POW_TAB));
+    PLK_HIP(hipMalloc(&buf, sizeof(Fr) * 4 * POW_TAB + (size_t)48 * POW_TAB + (tw3 ? (size_t)4 * TW3_WORDS * POW_TAB : 0)));
     hipLaunchKernelGGL(fill_pow_table, dim3(2 * POW_TAB / 256), dim3(256), 0, ctx->stream, buf, buf + POW_TAB, base, 0);
     hipLaunchKernelGGL(table_to_w, dim3(2 * POW_TAB / 256), dim3(256), 0, ctx->stream, buf + 2 * POW_TAB, (const Fr *)buf, 2 * POW_TAB);
     PLK_HIP(hipGetLastError());
@@ -506,6 +535,12 @@ static int32_t make_pow_table(plk_ctx *ctx, const Fr &base, PowTable *out, PowTa
     hipLaunchKernelGGL(table_slice, dim3(POW_TAB / 256), dim3(256), 0, ctx->stream, sliced, (const Fr *)(buf + 3 * POW_TAB), POW_TAB);
     PLK_HIP(hipGetLastError());
     out_w->hi_sliced = sliced;
+    if (tw3) {
+        uint32_t *t3 = sliced + (size_t)12 * POW_TAB;
+        hipLaunchKernelGGL(table_tw3, dim3(POW_TAB / 256), dim3(256), 0, ctx->stream, t3, (const Fr *)(buf + 3 * POW_TAB), POW_TAB);
+        PLK_HIP(hipGetLastError());
+        out_w->hi_tw3 = t3;
+    }
     if (alloc_out) *alloc_out = buf;
     return PLK_OK;
 }
@@ -553,8 +588,8 @@ int32_t ntt_init_tables(plk_ctx *ctx) {
     for (uint32_t i = 1; i <= MAX_LOG_N; i++) ctx->n_inv[i] = mul(ctx->n_inv[i - 1], half);
     Fr w = root28();
     void *a = nullptr, *b = nullptr;
-    PLK_TRY(make_pow_table(ctx, w, &ctx->tw_fwd, &ctx->tw_fwd_w, &a));
-    PLK_TRY(make_pow_table(ctx, inv(w), &ctx->tw_inv, &ctx->tw_inv_w, &b));
+    PLK_TRY(make_pow_table(ctx, w, &ctx->tw_fwd, &ctx->tw_fwd_w, &a, true));
+    PLK_TRY(make_pow_table(ctx, inv(w), &ctx->tw_inv, &ctx->tw_inv_w, &b, true));
     for (uint32_t i = 0; i <= MAX_LOG_N; i++) ctx->n_inv_w[i] = mul(ctx->n_inv[i], from_u64<FrParams>(32));   // x*2^256 -> x*2^261
     ctx->coset_allocs.push_back(a);
     ctx->coset_allocs.push_back(b);

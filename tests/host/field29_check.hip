@@ -64,6 +64,33 @@ int main() {
             if (m1.l[k] != m2.l[k] || s1.l[k] != s2.l[k] || f1.l[k] != f2.l[k] || p0.l[k] != m1.l[k] || p1.l[k] != p1s.l[k] || q0.l[k] != s1.l[k] || q1.l[k] != q1s.l[k]) {
                 bad++; if (bad < 5) printf("product forms disagree %d\n", it); break; }
     }
+    // product by a constant held as three shifted copies (mul_tw3: 108 multiply-adds, the NTT's stage twiddles): equals the plain
+    // product for normalised and for un-normalised operands up to the limb bound, result < 4p for normalised ones, and the lockstep
+    // pair is the same function
+    {
+        FrW9 four_p = w_zero<FrW>();
+        { uint64_t c = 0; for (int i = 0; i < 9; i++) { c += 4ull * FrW::P29[i]; four_p.l[i] = (uint32_t)c & M29; c >>= 29; } }
+        auto less = [](const FrW9 &a, const FrW9 &b) { for (int i = 8; i >= 0; i--) if (a.l[i] != b.l[i]) return a.l[i] < b.l[i]; return false; };
+        for (int it = 0; it < 20000; it++) {
+            Fr a = rnd_fp<FrParams>(), b = rnd_fp<FrParams>(), t = rnd_fp<FrParams>();
+            const Tw3<FrW> tw = make_tw3(csub_p(w_from_s(unpack<FrW>(t))));
+            FrW9 x = unpack<FrW>(a), y = unpack<FrW>(b);
+            if ((it & 3) == 1) { for (int k = 0; k < 9; k++) x.l[k] = M29; }                  // largest normalised operand (2^261 - 1)
+            if ((it & 3) == 2) { for (int k = 0; k < 8; k++) x.l[k] += FrW::PAD4[k]; }        // un-normalised, like a padded difference
+            if ((it & 3) == 3) { for (int k = 0; k < 8; k++) x.l[k] = MULTW3_X_LIMB_MAX; x.l[8] = 0x003fffffu; }
+            const FrW9 r = mul_tw3(x, tw);
+            if ((it & 3) < 2 && !less(r, four_p)) { bad++; if (bad < 5) printf("mul_tw3 result not below 4p at %d\n", it); }
+            for (int k = 0; k < 8; k++) if (r.l[k] > M29) { bad++; if (bad < 5) printf("mul_tw3 output limb not normalised %d\n", it); break; }
+            // reference: the ordinary product of the normalised operand by the same constant in the W domain
+            const FrW9 want = reduce_small(mulw(normw(x), csub_p(w_from_s(unpack<FrW>(t))))), got = reduce_small(r);
+            for (int k = 0; k < 9; k++) if (want.l[k] != got.l[k]) { bad++; if (bad < 5) printf("mul_tw3 mismatch %d (case %d)\n", it, it & 3); break; }
+            if ((it & 3) == 0 && pack<FrParams>(got) != mul(a, t)) { bad++; if (bad < 5) printf("mul_tw3 vs Fr mul mismatch %d\n", it); }
+            FrW9 r0, r1;
+            mul_tw3_2(x, y, tw, r0, r1);
+            const FrW9 r1s = mul_tw3(y, tw);
+            for (int k = 0; k < 9; k++) if (r0.l[k] != r.l[k] || r1.l[k] != r1s.l[k]) { bad++; if (bad < 5) printf("mul_tw3_2 disagrees %d\n", it); break; }
+        }
+    }
     // mulw with an un-normalised left operand (ntt.hip r4_finish): limbs at MULW_A_LIMB_MAX against a right operand with
     // every limb at 2^29 - 1, raw padded differences against their normalised forms, and one lazy radix-4 butterfly
     // against the strictly normalised formulas
