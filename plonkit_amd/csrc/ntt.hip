@@ -319,8 +319,18 @@ __device__ __forceinline__ Tw3<FrW> small_tw3(const PowTable &t, uint32_t i, uin
 // and the first round (stage 0: y1 = x1, y3 = x3 < 2p, b2 = x2 + x3 un-multiplied) leaves < 7.3p from inputs < 1.3p.  Five rounds end
 // below 40p: inside the 2^261 capacity (170p) and reduce_small's 64p.  Limbs: every sum below stays under 2^32 (x < 2^29, PADk limbs
 // < 2.7e9, mul_tw3 outputs < 2^29), and the un-normalised operand of a product never occurs (u and v are normalised first).
+// Where the twiddle loads sit is pinned (sched_barrier): left alone, the scheduler sinks every load down to just before its first use
+// to save registers, and the wave then sits out one L2 latency (~750 cycles) per twiddle, three times per round.  t1 is requested
+// BEFORE the LDS exchange that precedes the round (wave_round_t1), t2 before the first product, t3 right after it (when t1 is dead:
+// four data elements + three 27-word twiddles would not fit 128 registers).
 template <int LR, int S, int NST>
-__device__ __forceinline__ void wave_round(FrW9 &x0, FrW9 &x1, FrW9 &x2, FrW9 &x3, const PowTable &tw, uint32_t row0) {
+__device__ __forceinline__ Tw3<FrW> wave_round_t1(const PowTable &tw, uint32_t row0) {
+    Tw3<FrW> t{};
+    if constexpr (NST == 2 && S > 0) t = small_tw3(tw, (row0 & ((1u << S) - 1)) << (LR - S - 1), LR);
+    return t;
+}
+template <int LR, int S, int NST>
+__device__ __forceinline__ void wave_round(FrW9 &x0, FrW9 &x1, FrW9 &x2, FrW9 &x3, const PowTable &tw, uint32_t row0, const Tw3<FrW> &t1) {
     constexpr uint32_t h = 1u << S;
     if constexpr (NST == 1) {                                   // one twiddle-free stage (S = 0): pairs (0,1) and (2,3)
         static_assert(S == 0, "a single stage is only ever the first");
@@ -331,7 +341,14 @@ __device__ __forceinline__ void wave_round(FrW9 &x0, FrW9 &x1, FrW9 &x2, FrW9 &x
     } else {
         const uint32_t jl = row0 & (h - 1);
         FrW9 y1 = x1, y3 = x3;
-        if constexpr (S > 0) mul_tw3_2(x1, x3, small_tw3(tw, jl << (LR - S - 1), LR), y1, y3);
+        Tw3<FrW> t2{};
+        if constexpr (S > 0) {
+            t2 = small_tw3(tw, jl << (LR - S - 2), LR);
+            __builtin_amdgcn_sched_barrier(0);
+            mul_tw3_2(x1, x3, t1, y1, y3);
+        }
+        const Tw3<FrW> t3 = small_tw3(tw, (jl + h) << (LR - S - 2), LR);
+        __builtin_amdgcn_sched_barrier(0);
         FrW9 u, v;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
@@ -339,8 +356,8 @@ __device__ __forceinline__ void wave_round(FrW9 &x0, FrW9 &x1, FrW9 &x2, FrW9 &x
             v.l[i] = x2.l[i] + (S > 0 ? FrW::PAD4[i] : FrW::PAD2[i]) - y3.l[i];
         }
         FrW9 b2 = u;                                            // stage 1 of the first pair: omega_4^0 = 1
-        if constexpr (S > 0) b2 = mul_tw3(normw(u), small_tw3(tw, jl << (LR - S - 2), LR));
-        const FrW9 b3 = mul_tw3(normw(v), small_tw3(tw, (jl + h) << (LR - S - 2), LR));
+        if constexpr (S > 0) b2 = mul_tw3(normw(u), t2);
+        const FrW9 b3 = mul_tw3(normw(v), t3);
         FrW9 o0, o1, o2, o3;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
@@ -408,6 +425,10 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_w(NttPassArgs a) {
     }
     static_for<P::NR>([&](auto RR) {
         constexpr int r = decltype(RR)::value;
+        uint32_t row0, col;
+        P::template locate<r>(wave, lane, 0, row0, col);
+        const Tw3<FrW> t1 = wave_round_t1<LR, P::rs(r), P::rn(r)>(a.tw, row0);       // in flight across the exchange
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (r > 0) {                                  // exchange: what round r-1 left in registers -> the layout round r reads
             constexpr bool handover = P::pb(r - 1) != P::pb(r);
             uint32_t prow, pcol;
@@ -419,9 +440,7 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_w(NttPassArgs a) {
         // the round after this one hands over to phase B, i.e. writes into the other waves' regions: they must all have
         // finished reading theirs (their gets of THIS round) first
         if constexpr (r > 0 && r + 1 < P::NR && P::pb(r) != P::pb(r + 1)) __syncthreads();
-        uint32_t row0, col;
-        P::template locate<r>(wave, lane, 0, row0, col);
-        wave_round<LR, P::rs(r), P::rn(r)>(x0, x1, x2, x3, a.tw, row0);
+        wave_round<LR, P::rs(r), P::rn(r)>(x0, x1, x2, x3, a.tw, row0, t1);
     });
     {                                                           // the last round's rows row0 + k * R/4 go straight out
         uint32_t row0, col;

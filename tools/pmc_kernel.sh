@@ -4,7 +4,7 @@
 pat=$1; set_=$2; shift 3
 R=$PWD; export TMPDIR=/tmp; d=/tmp/pmc_$$; rm -rf $d
 args=(); for a in "$@"; do if [ -f "$R/$a" ]; then args+=("$R/$a"); else args+=("$a"); fi; done; set -- "${args[@]}"   # (the profiler runs from /tmp)
-(cd /tmp && rocprofv3 --pmc $set_ --kernel-trace --output-format csv -d $d -o p -- "$@" > $d.log 2>&1)
+(cd /tmp && timeout 150 rocprofv3 --pmc $set_ --kernel-trace --output-format csv -d $d -o p -- "$@" > $d.log 2>&1)
 f=$(find $d -name "*counter_collection.csv" 2>/dev/null | head -1)
 if [ -z "$f" ]; then echo "no counter file; log tail:"; tail -5 $d.log; exit 1; fi
 python3 - "$f" "$pat" <<PY
