@@ -74,6 +74,26 @@ VALU_PEAK_GMADD = MAD_RATE_TLANE_S * 1e3 / MADS_PER_MIXED_ADD
 LOOP_ISOLATED_GMADD = 16.3
 
 
+FAILED_LEGS = []                 # (leg, repr(exception), is_correctness) of every secondary leg that raised: the line keeps going, the exit status does not lie
+
+
+def leg(name, fn):
+    """run a secondary leg of the line: an exception becomes {"error": ...} in its place AND an entry of the top-level `failed_legs`;
+    an AssertionError / a failed byte-identity or verification check also makes the process exit non-zero after the line is printed"""
+    try:
+        return fn()
+    except Exception as exc:                                       # noqa: BLE001
+        FAILED_LEGS.append((name, repr(exc), isinstance(exc, AssertionError) or "differs" in repr(exc) or "mismatch" in repr(exc)))
+        return {"error": repr(exc)}
+
+
+def all_ok(dist, device, ok):
+    """collective AND of a per-rank flag: every rank calls it, so a rank that failed locally does not leave the others in a barrier"""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
 def red_device(device):
     """where the timing reductions live: the GPU over RCCL, the host when torch.distributed runs over gloo (shared-device test)"""
     return torch.device("cpu") if os.environ.get("PLK_BENCH_SHARE_DEVICE") else device
@@ -181,6 +201,9 @@ def cpu_msm_rows(ctx, device, log_n=20, big_log_n=24):
         gpu_ms = (time.perf_counter() - t0) / 3 * 1e3
         out["2^%d_%s" % (log_n, name)] = {"cpu_ms": round(cpu_ms, 1), "gpu_ms": round(gpu_ms, 3), "cores": cores, "same_point": bool(np.array_equal(got, ref))}
     del bases
+    # 2^24 terms (MSM at 2^20 / 2^24 with the four distributions).  The CPU port is timed on the uniform case only (6 s;
+    # the bounded-sample rule); the other three are checked against the tau = 42 trapdoor instead: sum s_i tau^i G = (sum s_i 42^i) G
+    # is ONE fixed-base multiplication on the host, so every GPU result is still compared with an independent value.
     m = 1 << big_log_n
     ctx.srs_generate(m, 0, 42)
     bases = ctx.srs_download(0, m)
@@ -189,14 +212,35 @@ def cpu_msm_rows(ctx, device, log_n=20, big_log_n=24):
     t0 = time.perf_counter()
     ref = ol.msm(bases, big, threads=cores)
     cpu_ms = (time.perf_counter() - t0) * 1e3
-    d = torch.from_numpy(big.view(np.int64)).to(device)
-    torch.cuda.synchronize()
-    got = ctx.msm_dev(d, m)
-    t0 = time.perf_counter()
-    ctx.msm_dev(d, m)
-    gpu_ms = (time.perf_counter() - t0) * 1e3
-    out["2^%d_uniform" % big_log_n] = {"cpu_ms": round(cpu_ms, 1), "gpu_ms": round(gpu_ms, 3), "cores": cores, "same_point": bool(np.array_equal(got, ref))}
-    del bases, big, d
+    del bases
+    wl = big.copy()
+    pick = rng.random(m)
+    wl[pick < 0.5] = 0
+    idx = np.nonzero((pick >= 0.5) & (pick < 0.75))[0]
+    wl[idx] = small[rng.integers(0, 1 << 16, size=idx.shape[0])]
+    for name, sc in (("uniform", big), ("witness_like", wl), ("all_ones", None), ("all_r_minus_1", None)):
+        if sc is None:
+            d = torch.from_numpy(np.ascontiguousarray(one if name == "all_ones" else minus_one).view(np.int64)).to(device).repeat(m, 1).contiguous()
+        else:
+            d = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).to(device)
+        torch.cuda.synchronize()
+        got = ctx.msm_dev(d, m)
+        t0 = time.perf_counter()
+        ctx.msm_dev(d, m)
+        gpu_ms = (time.perf_counter() - t0) * 1e3
+        row = {"gpu_ms": round(gpu_ms, 3), "Mscalar_mul_s": round(m / gpu_ms / 1e3, 1)}
+        if name == "uniform":
+            row.update({"cpu_ms": round(cpu_ms, 1), "cores": cores, "same_point": bool(np.array_equal(got, ref))})
+        else:
+            if name == "witness_like":
+                k = ol.poly_eval(sc, 42)                    # sum s_i 42^i (Horner, C)
+            else:                                            # sum_{i<m} 42^i = (42^m - 1) / 41, times 1 or (r - 1)
+                geo = (pow(42, m, ol.R_MOD) - 1) * pow(41, ol.R_MOD - 2, ol.R_MOD) % ol.R_MOD
+                k = geo if name == "all_ones" else (ol.R_MOD - 1) * geo % ol.R_MOD
+            row.update({"same_point": bool(np.array_equal(got, ol.g1_mul(ol.g1_generator(), k))), "checked_against": "tau = 42 trapdoor (one host scalar multiplication)"})
+        out["2^%d_%s" % (big_log_n, name)] = row
+        del d
+    del big, wl
     if keep:
         ctx.srs_generate(keep, 0, 42)
     return out
@@ -384,24 +428,45 @@ def replica_prove_throughput(dist, device, log_n, rank, world, in_flight=2, proo
     synchronize, every rank proves its share, barrier + synchronize, MAX over ranks; value = all proofs / that time."""
     import plonkit_amd as pa
     from plonkit_amd import prover_bench
-    ctx2 = pa.Context(device.index if device.index is not None else 0)          # a context of its own: no communicator installed
-    ctx2.srs_generate(1 << log_n, 0, 42)
-    n_gates = (1 << log_n) - 2
-    circs = [pa.Circuit.synthetic_ex(n_gates, witness_seed=(0 if k == 0 else 1000 * (rank + 1) + k)) for k in range(in_flight)]
-    setup = pa.SetupForProver(ctx2, circs[0])
-    prover_bench.throughput(ctx2, log_n, in_flight=in_flight, proofs_each=1, setup=setup, circs=circs)      # warm-up of every context path
+    # Every rank executes every collective of this leg whatever happens to it locally (a rank that raised before a barrier would leave
+    # the others waiting for the process-group timeout): local work runs under try, the verdicts are AND-ed across the ranks.
+    ctx2 = setup = None
+    circs = []
+    err = None
+    try:
+        ctx2 = pa.Context(device.index if device.index is not None else 0)      # a context of its own: no communicator installed
+        ctx2.srs_generate(1 << log_n, 0, 42)
+        n_gates = (1 << log_n) - 2
+        circs = [pa.Circuit.synthetic_ex(n_gates, witness_seed=(0 if k == 0 else 1000 * (rank + 1) + k)) for k in range(in_flight)]
+        setup = pa.SetupForProver(ctx2, circs[0])
+        prover_bench.throughput(ctx2, log_n, in_flight=in_flight, proofs_each=1, setup=setup, circs=circs)  # warm-up of every context path
+    except Exception as exc:                                       # noqa: BLE001
+        err = exc
+    r = {"proofs_per_s": 0.0}
+    ready = all_ok(dist, device, err is None)
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    r = prover_bench.throughput(ctx2, log_n, in_flight=in_flight, proofs_each=proofs_each, setup=setup, circs=circs)
+    if ready:
+        try:
+            r = prover_bench.throughput(ctx2, log_n, in_flight=in_flight, proofs_each=proofs_each, setup=setup, circs=circs)
+        except Exception as exc:                                   # noqa: BLE001
+            err = exc
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     per_gpu = torch.tensor([r["proofs_per_s"]], dtype=torch.float64, device=red_device(device))
     dist.all_reduce(per_gpu, op=dist.ReduceOp.SUM)
-    setup.close()
+    good = all_ok(dist, device, err is None)
+    if setup:
+        setup.close()
     for c in circs:
         c.close()
-    ctx2.close()
+    if ctx2:
+        ctx2.close()
+    if err is not None:
+        raise err
+    if not good:
+        raise RuntimeError("another rank failed in this leg (its own line names the error)")
     return {"n_gpus": world, "in_flight_per_gpu": in_flight, "proofs_per_gpu": in_flight * proofs_each, "domain": 1 << log_n,
             "proofs_per_s": round(float(per_gpu.item()), 2), "ms_per_proof_node": round(1e3 / float(per_gpu.item()), 3),
             "region_wall_s": round(float(t.item()), 3), "scaling": "replicas only (independent proofs, one full key per GPU, no exchange)",
@@ -686,49 +751,37 @@ def main():
             cb["matches_gpu"] = bool(np.array_equal(got, ref))
             for key, fn in (("msm_rows", lambda: cpu_msm_rows(ctx, device)), ("g1_intt", lambda: cpu_g1_intt_row(ctx, device)),
                             ("ntt", cpu_ntt_baseline), ("prove", lambda: cpu_prove_baseline(ctx, min(args.cpu_log_n, args.log_n)))):
-                try:
-                    cb[key] = fn()
-                except Exception as exc:                               # noqa: BLE001 — a secondary row must not cost the line
-                    cb[key] = {"error": repr(exc)}
+                cb[key] = leg("cpu_baseline." + key, fn)               # a secondary row must not cost the line
+            for key in ("msm_rows",):                                  # a result that is not the same group element is a failure, not a field
+                if isinstance(cb[key], dict) and any(isinstance(r, dict) and r.get("same_point") is False for r in cb[key].values()):
+                    FAILED_LEGS.append(("cpu_baseline." + key, "a GPU commitment differs from its reference value", True))
+            if isinstance(cb.get("prove"), dict) and cb["prove"].get("proof_bytes_identical") is False:
+                FAILED_LEGS.append(("cpu_baseline.prove", "GPU proof differs from the CPU port's", True))
             rb = reference_binary_baseline(min(args.cpu_log_n, args.log_n))
             if rb:
                 cb["reference_binary"] = rb
             line["cpu_baseline"] = cb
         if world == 1 and not force_dist and not args.msm_only:
             from plonkit_amd import prover_bench
-            try:
-                line["prove"] = prover_bench.run(ctx, args.log_n)
-            except Exception as exc:                                   # noqa: BLE001 — a failing leg must not cost the headline line
-                line["prove"] = {"error": repr(exc)}
-            # the same circuit shape with a live d column (11 of 11 commitments), and prove THROUGHPUT: two proofs in flight on this GPU
+            line["prove"] = leg("prove", lambda: prover_bench.run(ctx, args.log_n))      # a failing leg must not cost the headline line
+            # the same circuit shape with a live d column (11 of 11 commitments), prove THROUGHPUT (two / three proofs in flight on this GPU),
+            # and the whole `plonkit prove` process (SURVEY.md 8(d)'s third timed region)
             for key, fn in (("dense", lambda: prover_bench.run_dense(ctx, args.log_n)),
                             ("throughput", lambda: prover_bench.throughput(ctx, args.log_n, in_flight=2, proofs_each=10)),
                             ("throughput_in_flight_3", lambda: prover_bench.throughput(ctx, args.log_n, in_flight=3, proofs_each=8)),
-                            ("throughput_dense", lambda: prover_bench.throughput(ctx, args.log_n, in_flight=2, proofs_each=6, lc_terms=7))):
-                try:
-                    line["prove"][key] = fn()
-                except Exception as exc:                               # noqa: BLE001 — must not cost the headline line
-                    line["prove"][key] = {"error": repr(exc)}
-            try:
-                line["kernels"] = prover_bench.kernel_table(ctx, device)
-            except Exception as exc:                                   # noqa: BLE001
-                line["kernels"] = {"error": repr(exc)}
+                            ("throughput_dense", lambda: prover_bench.throughput(ctx, args.log_n, in_flight=2, proofs_each=6, lc_terms=7)),
+                            ("cli", lambda: prover_bench.cli_whole(args.log_n))):
+                line["prove"][key] = leg("prove." + key, fn)
+            if isinstance(line["prove"].get("dense"), dict) and line["prove"]["dense"].get("verified") is False:
+                FAILED_LEGS.append(("prove.dense", "the host verifier rejects the dense proof", True))
+            line["kernels"] = leg("kernels", lambda: prover_bench.kernel_table(ctx, device))
     if world > 1 or force_dist:
         # (a) strong scaling of ONE 2^24-term commitment (configs[2]); (b) multi-GPU prove at the 2^log_n domain: the SRS
         # sliced across the ranks, commitments combined over RCCL, NTTs replicated.  Every rank takes part;
         # a failure here must not cost the headline line.
-        try:
-            strong = strong_scaling_msm(ctx, dist, device, rank, world, log_total=args.strong_log_n)
-        except Exception as exc:                                   # noqa: BLE001
-            strong = {"error": repr(exc)}
-        try:
-            sharded = sharded_prove(ctx, dist, device, args.log_n, rank, world)
-        except Exception as exc:                                   # noqa: BLE001
-            sharded = {"error": repr(exc)}
-        try:
-            replicas = replica_prove_throughput(dist, device, args.log_n, rank, world)
-        except Exception as exc:                                   # noqa: BLE001
-            replicas = {"error": repr(exc)}
+        strong = leg("strong", lambda: strong_scaling_msm(ctx, dist, device, rank, world, log_total=args.strong_log_n))
+        sharded = leg("prove(sharded)", lambda: sharded_prove(ctx, dist, device, args.log_n, rank, world))
+        replicas = leg("prove_throughput", lambda: replica_prove_throughput(dist, device, args.log_n, rank, world))
         if rank == 0:
             line["strong"] = strong
             line["prove"] = sharded
@@ -739,10 +792,13 @@ def main():
             line["strong_unit"] = "Mscalar·mul/s (one 2^%d-term commitment, SRS split over %d GPUs)" % (args.strong_log_n, world)
             line["strong_scaling_vs_1gpu"] = strong.get("scaling_vs_1gpu")
     if rank == 0:
+        line["failed_legs"] = [{"leg": a, "error": b, "correctness": c} for a, b, c in FAILED_LEGS]
         print(json.dumps(line, ensure_ascii=False), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if any(c for _, _, c in FAILED_LEGS):
+        raise SystemExit("bench.py: a correctness check failed in: " + ", ".join(a for a, _, c in FAILED_LEGS if c))
 
 
 if __name__ == "__main__":

@@ -74,7 +74,9 @@ int32_t plk_srs_precompute(plk_ctx *ctx);
  * thread-safe), any number of contexts per device, ONE plk_setup shared by all of them (its lazily cached extensions are
  * filled under a lock), one plk_circuit per witness.  plk_ctx_share_srs makes `dst` borrow `src`'s resident key(s) and MSM
  * fixed-base table(s) instead of building its own (0.94 GiB and ~40 ms per key at 2^20 points): `src` builds what is missing,
- * keeps ownership, refuses to replace its key while a borrower exists (PLK_ERR_ARG) and must be destroyed after its borrowers.
+ * keeps ownership and refuses to replace a key that a borrower holds (PLK_ERR_ARG; a Lagrange-form key it did not have when the
+ * loans were made may still be installed — the borrowers do not see it, share again for that).  Destroying `src` before its
+ * borrowers is safe: the key and the tables outlive it until the last borrower returns its loan (plk_destroy / a key of its own).
  * A borrower that is given a key of its own (upload / generate / set_dev) simply stops borrowing.                              */
 int32_t plk_ctx_share_srs(plk_ctx *dst, plk_ctx *src);
 

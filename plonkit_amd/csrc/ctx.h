@@ -134,6 +134,10 @@ struct plk_ctx {
     // while one exists; a borrower drops the loan when it is given a key of its own or destroyed.
     plk_ctx *srs_lender = nullptr;
     std::atomic<int> srs_borrowers{0};
+    bool lag_borrowed = false;               // borrower: the Lagrange-form key in `lag` is the lender's (recorded when the loan was made:
+                                             // the lender swaps its own key slots during a proof, so comparing pointers later is a race)
+    std::atomic<int> lag_borrowers{0};       // lender: how many borrowers hold its Lagrange-form key (it may install one while none does)
+    bool zombie = false;                     // lender destroyed while borrowers exist: only the lent key and tables are left, freed with the last loan
 };
 
 namespace plk {
@@ -143,6 +147,8 @@ int32_t srs_replace_guard(plk_ctx *c, const char *who, bool lagrange_only = fals
 inline void srs_table_invalidate(plk_ctx *c) { c->srs_w_valid = false; if (c->srs_w.borrowed) c->srs_w.release(); }
 inline void lag_table_invalidate(plk_ctx *c) { c->lag.w_valid = false; if (c->lag.w.borrowed) c->lag.w.release(); }
 void srs_return_loan(plk_ctx *c);                                 // runtime.hip
+void srs_make_loan(plk_ctx *dst, plk_ctx *src);                   // runtime.hip
+bool srs_orphan_lender(plk_ctx *c);                               // runtime.hip
 
 // makes the Lagrange key the context's active SRS for the lifetime of the guard (host-side pointer swap only;
 // kernels already enqueued keep the addresses they were launched with)

@@ -1050,15 +1050,13 @@ int32_t plk_ctx_share_srs(plk_ctx *dst, plk_ctx *src) {
     if (src->srs_lender) { set_error("plk_ctx_share_srs: the source context itself borrows its key (share from the owner)"); return PLK_ERR_ARG; }
     if (!src->srs) { set_error("plk_ctx_share_srs: the source context has no key resident"); return PLK_ERR_SRS; }
     if (dst->msm_enq != dst->msm_fin) { set_error("plk_ctx_share_srs: a commitment is still in flight on the destination context"); return PLK_ERR_ARG; }
-    PLK_TRY(srs_replace_guard(dst, "plk_ctx_share_srs"));
-    PLK_TRY(plk_srs_precompute(src));                        // (synchronises src->stream: the tables are complete before anyone reads them)
+    if (dst->srs_borrowers.load() > 0) { set_error("plk_ctx_share_srs: the destination context lends its own key to other contexts"); return PLK_ERR_ARG; }
+    PLK_TRY(plk_srs_precompute(src));                        // the fallible step first (synchronises src->stream: the tables are complete before anyone
+                                                             // reads them) — dst keeps what it has if this fails
+    PLK_TRY(srs_replace_guard(dst, "plk_ctx_share_srs"));    // drops a loan dst may hold
     dst->srs_own.release(); dst->lag.own.release();
-    dst->srs = src->srs; dst->srs_n = src->srs_n;
-    dst->srs_w.borrow(src->srs_w); dst->srs_w_valid = src->srs_w_valid; dst->srs_w_copies = src->srs_w_copies;
-    dst->lag.pts = src->lag.pts; dst->lag.n = src->lag.n;
-    dst->lag.w.borrow(src->lag.w); dst->lag.w_valid = src->lag.pts ? src->lag.w_valid : false; dst->lag.w_copies = src->lag.w_copies;
-    dst->srs_lender = src;
-    src->srs_borrowers.fetch_add(1);
+    dst->lag.w.release();
+    srs_make_loan(dst, src);
     return PLK_OK;
 }
 

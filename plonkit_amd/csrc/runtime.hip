@@ -10,6 +10,7 @@
 #include "comm.h"
 #include <cstring>
 #include <cstdio>
+#include <mutex>
 
 namespace plk {
 
@@ -63,22 +64,62 @@ int32_t ensure_pinned2(plk_ctx *ctx, size_t bytes) {
     return PLK_OK;
 }
 
-// a context whose key is on loan must keep it: the borrowers' commitments read it (and its MSM table) at any time
+// a context whose key is on loan must keep it: the borrowers' commitments read it (and its MSM table) at any time.  The Lagrange-form
+// key of a lender is only frozen while a borrower actually holds it (a lender that had none when the loans were made may install one;
+// its borrowers do not see it — share again for that).
+static std::mutex g_share_mu;                          // loans are made, returned and orphaned under one lock (rare operations)
 int32_t srs_replace_guard(plk_ctx *c, const char *who, bool lagrange_only) {
-    if (c->srs_borrowers.load() > 0) {
+    if (lagrange_only ? c->lag_borrowers.load() > 0 : c->srs_borrowers.load() > 0) {
         set_error(std::string(who) + ": this context's key is shared with another context (plk_ctx_share_srs) — destroy the borrowers first");
         return PLK_ERR_ARG;
     }
     if (!lagrange_only) srs_return_loan(c);              // a borrower that gets a monomial key of its own stops borrowing altogether;
-    return PLK_OK;                                       // one that only replaces its Lagrange-form key keeps the borrowed monomial key
+    else if (c->lag_borrowed) {                          // one that replaces its Lagrange-form key keeps the borrowed monomial key
+        std::lock_guard<std::mutex> g(g_share_mu);
+        c->srs_lender->lag_borrowers.fetch_sub(1);
+        c->lag_borrowed = false;
+        c->lag.pts = nullptr; c->lag.n = 0; c->lag.w.release(); c->lag.w_valid = false; c->lag.w_copies = 0;
+    }
+    return PLK_OK;
+}
+static void free_lent(plk_ctx *c) {                      // what a destroyed lender had to keep for its borrowers
+    (void)hipSetDevice(c->device);
+    c->srs_own.release(); c->srs_w.release(); c->lag.own.release(); c->lag.w.release();
+    delete c;
 }
 void srs_return_loan(plk_ctx *c) {
     if (!c->srs_lender) return;
-    const bool lag_on_loan = c->lag.pts && c->lag.pts == c->srs_lender->lag.pts;      // (a borrower may have uploaded a Lagrange key of its own since)
-    c->srs_lender->srs_borrowers.fetch_sub(1);
-    c->srs_lender = nullptr;
-    c->srs = nullptr; c->srs_n = 0; c->srs_w.release(); c->srs_w_valid = false; c->srs_w_copies = 0;
-    if (lag_on_loan) { c->lag.pts = nullptr; c->lag.n = 0; c->lag.w.release(); c->lag.w_valid = false; c->lag.w_copies = 0; }
+    plk_ctx *orphan = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_share_mu);
+        plk_ctx *const lender = c->srs_lender;
+        if (c->lag_borrowed) lender->lag_borrowers.fetch_sub(1);
+        if (lender->srs_borrowers.fetch_sub(1) == 1 && lender->zombie) orphan = lender;
+        c->srs_lender = nullptr;
+        c->srs = nullptr; c->srs_n = 0; c->srs_w.release(); c->srs_w_valid = false; c->srs_w_copies = 0;
+        if (c->lag_borrowed) { c->lag.pts = nullptr; c->lag.n = 0; c->lag.w.release(); c->lag.w_valid = false; c->lag.w_copies = 0; }
+        c->lag_borrowed = false;
+    }
+    if (orphan) free_lent(orphan);                       // the lender was destroyed before this, its last, borrower
+}
+void srs_make_loan(plk_ctx *dst, plk_ctx *src) {         // (msm.hip plk_ctx_share_srs: the checks and the fallible steps come first)
+    std::lock_guard<std::mutex> g(g_share_mu);
+    dst->srs = src->srs; dst->srs_n = src->srs_n;
+    dst->srs_w.borrow(src->srs_w); dst->srs_w_valid = src->srs_w_valid; dst->srs_w_copies = src->srs_w_copies;
+    dst->lag.pts = src->lag.pts; dst->lag.n = src->lag.n;
+    dst->lag.w.borrow(src->lag.w); dst->lag.w_valid = src->lag.pts ? src->lag.w_valid : false; dst->lag.w_copies = src->lag.w_copies;
+    dst->lag_borrowed = src->lag.pts != nullptr;
+    dst->srs_lender = src;
+    src->srs_borrowers.fetch_add(1);
+    if (dst->lag_borrowed) src->lag_borrowers.fetch_add(1);
+}
+// true: the context lends its key to contexts that are still alive — plk_destroy keeps the key and the tables (and the shell of the
+// context) until the last of them returns its loan
+bool srs_orphan_lender(plk_ctx *c) {
+    std::lock_guard<std::mutex> g(g_share_mu);
+    if (c->srs_borrowers.load() == 0) return false;
+    c->zombie = true;
+    return true;
 }
 
 }  // namespace plk
@@ -90,12 +131,15 @@ extern "C" {
 const char *plk_last_error(void) { return g_last_error.c_str(); }
 const char *plk_version(void) { return "plonkit_amd 0.1 (gfx950)"; }
 
-// read by the runtimes when they initialise, i.e. at the first HIP call of the process: more hardware queues than HIP's default of 4
-// (a proof keeps 4-5 streams busy, several proofs may be in flight), and dmabuf device-memory IPC — RCCL between the per-GPU processes
-// of plk_comm_init fails with `hipIpcGetMemHandle: invalid argument` on this driver without it.  Never overrides the caller's setting.
+// read by the runtime when it initialises, i.e. at the first HIP call of the process: more hardware queues than HIP's default of 4
+// (a proof keeps 4-5 streams busy, several proofs may be in flight).  Never overrides the caller's setting.
 static void runtime_env_defaults() {
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
-    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+    // once per process and only what a single-GPU user needs: the dmabuf IPC mode the multi-rank path needs
+    // (HSA_ENABLE_IPC_MODE_LEGACY=0) changes the behaviour of every other HIP / RCCL user of the embedding process, so it is the
+    // launcher's to set before the first HIP call — this package's binary (PLONKIT_WORLD > 1), bench.py and plonkit_amd.sharded do;
+    // INTEGRATION.md names it.  (call_once: contexts are created from several host threads, setenv is not thread-safe.)
+    static std::once_flag once;
+    std::call_once(once, [] { setenv("GPU_MAX_HW_QUEUES", "8", 0); });
 }
 
 int32_t plk_device_count(void) {
@@ -144,10 +188,12 @@ void plk_destroy(plk_ctx *ctx) {
     if (ctx->bg_stream) (void)hipStreamSynchronize(ctx->bg_stream);
     comm_release(ctx);
     srs_return_loan(ctx);
+    const bool lent = srs_orphan_lender(ctx);            // borrowers alive: their commitments read this context's key and tables at any time
     for (void *p : ctx->coset_allocs) (void)hipFree(p);
     for (auto &kv : ctx->ntt_direct) (void)hipFree(kv.second);
     ctx->coset_direct[0].buf.release(); ctx->coset_direct[1].buf.release();
-    ctx->tables.release(); ctx->ntt_scratch[0].release(); ctx->ntt_scratch[1].release(); ctx->srs_own.release(); ctx->srs_w.release(); ctx->lag.own.release(); ctx->lag.w.release();
+    ctx->tables.release(); ctx->ntt_scratch[0].release(); ctx->ntt_scratch[1].release();
+    if (!lent) { ctx->srs_own.release(); ctx->srs_w.release(); ctx->lag.own.release(); ctx->lag.w.release(); }
     for (auto &S : ctx->slot) {
         S.a.release(); S.b.release(); S.c.release(); S.d.release(); S.e.release(); S.f.release();
         if (S.pinned) (void)hipHostFree(S.pinned);
@@ -164,7 +210,8 @@ void plk_destroy(plk_ctx *ctx) {
     if (ctx->bg_done) (void)hipEventDestroy(ctx->bg_done);
     if (ctx->bg_stream) (void)hipStreamDestroy(ctx->bg_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    delete ctx;
+    ctx->stream = nullptr; ctx->bg_stream = nullptr;
+    if (!lent) delete ctx;                               // else: srs_return_loan of the last borrower frees the key, the tables and the shell
 }
 
 int32_t plk_synchronize(plk_ctx *ctx) {

@@ -6,6 +6,87 @@ import time
 from . import _lib
 
 
+HBM_PEAK_BS = 8.0e12            # MI355X_MICROARCH.md: 8 TB/s
+
+
+def prove_bytes(n, commitments_nonempty=11):
+    """ALGORITHMIC bytes of one proof at domain n (one compulsory read + one compulsory write of each operand, independent of
+    pass count).  `survey` = SURVEY.md 8(d)'s itemisation of the REFERENCE's prove_by_steps (11 MSM + 6 NTT(N) + 18 LDE(4N) + one
+    coset iNTT(4N) + point-wise passes = 8416 B per domain point); `this_prover` = the same itemisation for what THIS prover does per
+    proof: the twelve constant extensions (7 selectors, 4 permutations, ...) are cached in HBM across proofs, so 6 extensions are
+    left (four wires, z, public inputs); the quotient kernel reads 22 vectors of 4N and writes one; empty commitments cost nothing."""
+    survey = {"11 MSM x 96N": 11 * 96 * n, "6 NTT(N) x 64N": 6 * 64 * n, "18 LDE x 160N": 18 * 160 * n, "coset iNTT(4N) 64 x 4N": 64 * 4 * n,
+              "20 point-wise arrays of 4N x 32 B": 20 * 128 * n, "40 point-wise arrays of N x 32 B": 40 * 32 * n}
+    this = {"%d MSM x 96N" % commitments_nonempty: commitments_nonempty * 96 * n, "6 NTT(N) x 64N": 6 * 64 * n, "6 LDE x 160N (12 constant ones cached)": 6 * 160 * n,
+            "coset iNTT(4N) 64 x 4N": 64 * 4 * n, "quotient: 23 arrays of 4N x 32 B": 23 * 128 * n, "40 point-wise arrays of N x 32 B": 40 * 32 * n}
+    return {"survey": sum(survey.values()), "survey_items": survey, "this_prover": sum(this.values()), "this_prover_items": this}
+
+
+def with_roofline(row, n, seconds_per_proof, commitments_nonempty):
+    """adds algorithmic_bytes / hbm_frac (north_star: prove-time throughput "as fraction of the HBM roofline") to a prove row"""
+    b = prove_bytes(n, commitments_nonempty)
+    row["algorithmic_bytes"] = b["survey"]
+    row["algorithmic_GBs"] = round(b["survey"] / seconds_per_proof / 1e9, 1)
+    row["hbm_frac"] = round(b["survey"] / seconds_per_proof / HBM_PEAK_BS, 4)
+    row["algorithmic_bytes_this_prover"] = b["this_prover"]
+    row["hbm_frac_this_prover"] = round(b["this_prover"] / seconds_per_proof / HBM_PEAK_BS, 4)
+    row["algorithmic_bytes_what"] = ("algorithmic_bytes = SURVEY.md 8(d): 8416 B per domain point for the reference's 11 MSM + 6 NTT(N) + 18 LDE + coset iNTT + point-wise "
+                                     "passes; _this_prover = the same itemisation for this prover (12 constant extensions cached, %d non-empty commitments, "
+                                     "quotient kernel 23 arrays of 4N); hbm_frac = bytes / seconds per proof / 8 TB/s.  A proof is VALU-bound (the commitments), "
+                                     "so this fraction is small by construction" % commitments_nonempty)
+    return row
+
+
+def cli_whole(log_n, runs=3):
+    """SURVEY.md 8(d)'s third timed region: the whole `plonkit prove` process of this package (parse .r1cs/.wtns, HIP init, key read +
+    upload, MSM table, setup, prove, files written) on the 2^log_n synthetic circuit, files in /dev/shm, median of `runs`; the phases are
+    the binary's own PLK_CLI_TIMING=1 report of the median run.  The reference's counterpart is src/bin/main.rs:384-410."""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    cli = os.path.join(os.path.dirname(_lib.lib_path()), "plonkit")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="plonkit_cli_", dir=base)
+    f = lambda name: os.path.join(d, name)
+    try:
+        circ = _lib.Circuit.synthetic((1 << log_n) - 2)
+        r1cs, wtns = circ.export("r1cs"), circ.export("wtns")
+        open(f("circuit.r1cs"), "wb").write(r1cs); open(f("witness.wtns"), "wb").write(wtns)
+        circ.close()
+        env = dict(os.environ, PLK_CLI_TIMING="1")
+        subprocess.check_call([cli, "setup", "-p", str(log_n), "-m", f("key.bin"), "--overwrite"], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+        subprocess.check_call([cli, "export-verification-key", "-m", f("key.bin"), "-c", f("circuit.r1cs"), "-v", f("vk.bin"), "--overwrite"],
+                              stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+        res = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            p = subprocess.run([cli, "prove", "-m", f("key.bin"), "-c", f("circuit.r1cs"), "-w", f("witness.wtns"), "-p", f("proof.bin"),
+                                "-j", f("proof.json"), "-i", f("public.json"), "--overwrite"], env=env, capture_output=True, text=True, timeout=600)
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                raise RuntimeError("plonkit prove exited %d: %s" % (p.returncode, p.stderr[-300:]))
+            res.append((dt, p.stderr))
+        res.sort(key=lambda r: r[0])
+        whole, log = res[len(res) // 2]
+        phases = {}
+        import re
+        for ln in log.splitlines():
+            m = re.match(r"\[timing\]\s+(.*?)\s+\+([0-9.]+) s", ln)            # "[timing] <phase, may contain '+'>   +0.123 s (total)"
+            if m:
+                phases[m.group(1).strip()] = float(m.group(2))
+        t0 = time.perf_counter()
+        ok = subprocess.call([cli, "verify", "-p", f("proof.bin"), "-v", f("vk.bin")], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 0
+        verify_s = time.perf_counter() - t0
+        return {"whole_s": round(whole, 3), "whole_s_min": round(res[0][0], 3), "whole_s_max": round(res[-1][0], 3), "runs": runs, "phases_s": phases,
+                "verify_whole_s": round(verify_s, 3), "verified": bool(ok), "domain": 1 << log_n,
+                "files_MB": {"r1cs": round(len(r1cs) / 1e6, 1), "wtns": round(len(wtns) / 1e6, 1), "key": round(os.path.getsize(f("key.bin")) / 1e6, 1)},
+                "what": "wall clock of the whole `plonkit prove` process of this package (C ABI only), files in %s, median of %d; phases = its own "
+                        "PLK_CLI_TIMING report (main thread; the GPU thread's lines are indented), beside cpu_baseline.prove.cpu_whole_s" % (base or "the temp dir", runs)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def cold(device, log_n, circ):
     """first proof of a process as a `plonkit prove` user meets it (the reference is always in this state: it passes
     `None` precomputations, src/plonk.rs:152-159): a fresh context with only the key resident — the fixed-base table of
@@ -111,13 +192,13 @@ def throughput(ctx, log_n, in_flight=2, proofs_each=10, lc_terms=0, setup=None, 
     if bad:
         raise RuntimeError("concurrent proving failed: " + "; ".join(bad[:3]))
     all_lat = sorted(x for l in lat for x in l)
-    return {"in_flight": in_flight, "proofs": total, "proofs_per_s": round(total / par_s, 2), "ms_per_proof": round(par_s / total * 1e3, 3),
+    return with_roofline({"in_flight": in_flight, "proofs": total, "proofs_per_s": round(total / par_s, 2), "ms_per_proof": round(par_s / total * 1e3, 3),
             "latency_ms_median": round(all_lat[len(all_lat) // 2] * 1e3, 3), "latency_ms_max": round(all_lat[-1] * 1e3, 3),
             "sequential": {"proofs_per_s": round(total / seq_s, 2), "ms_per_proof": round(seq_s / total * 1e3, 3)},
             "speedup_vs_sequential": round(seq_s / par_s, 3), "byte_identical_to_sequential": True, "domain": 1 << log_n,
             "what": "%d host threads x %d proofs, one context per thread on one GPU (key and MSM table shared: plk_ctx_share_srs), one shared setup, "
                     "a different witness per thread; sequential = the same %d proofs one after the other on one context in the same run"
-                    % (in_flight, proofs_each, total)}
+                    % (in_flight, proofs_each, total)}, 1 << log_n, par_s / total, nonempty_commitments(want[0]))
 
 
 def run_dense(ctx, log_n, lc_terms=7, reps=6):
@@ -142,11 +223,12 @@ def run_dense(ctx, log_n, lc_terms=7, reps=6):
     bad = bytearray(proof); bad[-200] ^= 1                             # an evaluation
     rejected = not _lib.verify(vk, bytes(bad))
     setup.close(); circ.close()
-    return {"wall_s": round(best, 4), "wall_s_min": round(runs[0][0], 4), "proves_timed": reps, "domain": 1 << log_n, "lc_terms": lc_terms,
+    return with_roofline({"wall_s": round(best, 4), "wall_s_min": round(runs[0][0], 4), "proves_timed": reps, "domain": 1 << log_n, "lc_terms": lc_terms,
             "commitments_nonempty": nonempty_commitments(proof), "rounds_ms": {k: round(v, 2) for k, v in phases.items()},
             "verified": bool(ok), "tampered_rejected": bool(rejected), "parity": "unpinned",
             "what": "synthetic circuit whose constraints carry %d-term linear combinations (Poseidon-round shape): folded through the d column, "
-                    "so the d wire, q_d_next and t_3 are live; verified by the host verifier (real pairing) in the same run" % lc_terms}
+                    "so the d wire, q_d_next and t_3 are live; verified by the host verifier (real pairing) in the same run" % lc_terms},
+                         1 << log_n, best, nonempty_commitments(proof))
 
 
 def run(ctx, log_n, reps=10):
@@ -171,7 +253,7 @@ def run(ctx, log_n, reps=10):
     best, phases = runs[len(runs) // 2]            # the MEDIAN proof of `reps` back-to-back ones (round 2 reported the best of two)
     gpu_ms = sum(v for k, v in phases.items() if k.startswith("round"))
     assert cold_proof == proof
-    return {"wall_s": round(best, 4), "wall_s_min": round(runs[0][0], 4), "wall_s_max": round(runs[-1][0], 4), "proves_timed": reps,
+    return with_roofline({"wall_s": round(best, 4), "wall_s_min": round(runs[0][0], 4), "wall_s_max": round(runs[-1][0], 4), "proves_timed": reps,
             "commitments_nonempty": nonempty_commitments(proof),
             "cold": cold_info, "domain": 1 << log_n, "proof_bytes": len(proof),
             "rounds_ms": {k: round(v, 2) for k, v in phases.items()},
@@ -179,7 +261,8 @@ def run(ctx, log_n, reps=10):
             "setup_prepare_s": round(t_setup, 3), "circuit_generation_s": round(t_synth, 3),
             "what": "SetupForProver::prove (witness synthesis + satisfiability check on the host, rounds 1-5 on the GPU, "
                     "Proof::write); setup_prepare = transpile + 11 iNTT, timed separately as in the reference's CLI; "
-                    "wall_s = median of `proves_timed` warm proofs (tables, cached constant extensions and allocations in place), cold = first proof of a fresh context"}
+                    "wall_s = median of `proves_timed` warm proofs (tables, cached constant extensions and allocations in place), cold = first proof of a fresh context"},
+                         1 << log_n, best, nonempty_commitments(proof))
 
 
 def kernel_table(ctx, device):

@@ -8,6 +8,10 @@ the sharded commitment is mathematically the same sum commit_using_monomials com
 """
 import os
 
+# dmabuf IPC: RCCL between the per-GPU processes fails with `hipIpcGetMemHandle: invalid argument` on this driver unless this is set
+# before the first HIP call of the process; this module is the multi-rank entry of the package, so it is the one to ask
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import collections
 
 import numpy as np

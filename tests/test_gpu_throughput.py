@@ -139,6 +139,55 @@ def test_share_srs_ownership_rules(ctx):
     b.close()
 
 
+def test_lender_destroyed_before_its_borrowers():
+    """plk_destroy of a lender while borrowers are alive must not pull the key from under them (round-4 advisor finding): the key
+    and the MSM tables outlive the lender until the last borrower returns its loan"""
+    import plonkit_amd as pa
+    n = 1 << 12
+    owner = pa.Context(0)
+    owner.srs_generate(n, 0, 42)
+    rng = np.random.default_rng(11)
+    s = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    s[:, 3] &= np.uint64((1 << 60) - 1)
+    want = owner.msm(s)
+    b1, b2 = pa.Context(0), pa.Context(0)
+    b1.share_srs_from(owner); b2.share_srs_from(owner)
+    owner.close()                                                      # the lender goes first
+    assert np.array_equal(b1.msm(s), want) and np.array_equal(b2.msm(s), want)
+    b1.close()
+    assert np.array_equal(b2.msm(s), want)                             # one loan left: the key is still there
+    b2.srs_generate(n, 0, 42)                                          # the last loan ends (a key of its own): the orphaned key is freed
+    assert np.array_equal(b2.msm(s), want)
+    b2.close()
+
+
+def test_lender_may_install_a_lagrange_key_nobody_borrowed(ctx):
+    """the Lagrange-form key of a lender is only frozen while a borrower holds it (round-4 advisor finding): `prove -l` can be
+    started on the owner after its throughput contexts were created; a borrowed Lagrange key stays frozen"""
+    import plonkit_amd as pa
+    from oracle import oracle_lib as ol
+    n = 1 << 10
+    ctx.srs_generate(n, 0, 42)
+    ctx.srs_lagrange_clear()
+    b = pa.Context(0)
+    b.share_srs_from(ctx)                                              # no Lagrange key on loan
+    lag = ol.g1_intt(ol.crs42(n), 10)
+    ctx.srs_lagrange_upload(lag)                                       # allowed: nobody holds the (absent) Lagrange key
+    ctx.srs_lagrange_clear()
+    ctx.srs_lagrange_upload(lag)
+    b.close()
+    b = pa.Context(0)
+    b.share_srs_from(ctx)                                              # now the Lagrange key is on loan too
+    with pytest.raises(pa.PlkError):
+        ctx.srs_lagrange_clear()
+    b.srs_lagrange_clear()                                             # the borrower drops only its Lagrange loan ...
+    ctx.srs_lagrange_clear()                                           # ... which frees the owner's Lagrange slot, not its monomial key
+    with pytest.raises(pa.PlkError):
+        ctx.srs_generate(n, 0, 42)
+    b.close()
+    ctx.srs_generate(n, 0, 42)
+
+
 def test_dense_circuit_proves_all_eleven_commitments_at_2pow20(ctx):
     """the dense synthetic circuit at the headline domain (2^20): d, q_d_next and t_3 live — 11 of 11 commitments are
     non-trivial (the pinned-subset circuit: 9) —, the host verifier (real pairing) accepts, tampering with an evaluation
