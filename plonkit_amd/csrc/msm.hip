@@ -211,6 +211,15 @@ __device__ __forceinline__ void recode17(const Fr &k, int32_t (&d)[RC_WINDOWS]) 
     }
 }
 
+// true for every lane of the wave iff all its live lanes hold the same scalar (then every window's digit is the same in all of them)
+__device__ __forceinline__ bool wave_same_scalar(const Fr &k, bool live, uint64_t live_mask) {
+    const int leader = __ffsll((unsigned long long)live_mask) - 1;
+    uint32_t diff = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) diff |= k.l[i] ^ (uint32_t)__shfl((int)k.l[i], leader);
+    return __ballot(live && diff != 0) == 0;
+}
+
 // pass 1: coarse-bin histogram of the commitment's bucket set; RC_COUNT_PER scalars per thread keep the global atomics at
 // one per (workgroup, bin) for 4096 scalars
 constexpr int RC_COUNT_PER = 4;
@@ -229,9 +238,22 @@ __global__ void __launch_bounds__(RC_THREADS) msm_recode_count(ScalarSet set, Ms
     }
 #pragma unroll
     for (int r = 0; r < RC_COUNT_PER; r++) {
+        // (a wave of 64 equal scalars — all-ones, all-(r-1), a constant column — would hit ONE word with every LDS atomic below, 64-way
+        //  serialised; such a wave counts once per window instead: wave_same_scalar, ~20 instructions per scalar)
+        const uint64_t lv = __ballot(live[r]);
+        if (!lv) continue;
+        const bool same = wave_same_scalar(k[r], live[r], lv);
         if (!live[r]) continue;
         int32_t d[RC_WINDOWS];
         recode17(to_canonical(k[r]), d);
+        if (same) {
+            if ((tid & 63) == (uint32_t)(__ffsll((unsigned long long)lv) - 1)) {
+#pragma unroll
+                for (uint32_t w = 0; w < RC_WINDOWS; w++)
+                    if (d[w]) { const uint32_t mg = (uint32_t)(d[w] < 0 ? -d[w] : d[w]) - 1; atomicAdd(&lcnt[mg >> p.fine_bits], (uint32_t)__popcll(lv)); }
+            }
+            continue;
+        }
 #pragma unroll
         for (uint32_t w = 0; w < RC_WINDOWS; w++)
             if (d[w]) { const uint32_t mg = (uint32_t)(d[w] < 0 ? -d[w] : d[w]) - 1; atomicAdd(&lcnt[mg >> p.fine_bits], 1u); }
@@ -252,8 +274,16 @@ __global__ void __launch_bounds__(RC_THREADS) msm_recode_scatter(ScalarSet set, 
     const uint32_t i = blockIdx.x * RC_SCALARS + tid;
     cursor += m * p.nbins; bin_start += m * p.nbins;
     int32_t d[RC_WINDOWS];
-    if (i < p.n) recode17(to_canonical(load_fp(set.v[m] + i)), d);
-    else {
+    const bool live = i < p.n;
+    const uint64_t lv = __ballot(live);
+    bool same = false;                                                 // every live lane of this wave holds the same scalar (see msm_recode_count)
+    uint32_t lane_rank = 0, wave_live = 0;
+    if (live) {
+        const Fr k = load_fp(set.v[m] + i);
+        same = wave_same_scalar(k, true, lv);
+        recode17(to_canonical(k), d);
+        lane_rank = (uint32_t)__popcll(lv & ((1ull << (tid & 63)) - 1)); wave_live = (uint32_t)__popcll(lv);
+    } else {
 #pragma unroll
         for (uint32_t w = 0; w < RC_WINDOWS; w++) d[w] = 0;
     }
@@ -261,7 +291,11 @@ __global__ void __launch_bounds__(RC_THREADS) msm_recode_scatter(ScalarSet set, 
     __syncthreads();
 #pragma unroll
     for (uint32_t w = 0; w < RC_WINDOWS; w++)
-        if (d[w]) { const uint32_t mg = (uint32_t)(d[w] < 0 ? -d[w] : d[w]) - 1; atomicAdd(&lcnt[mg >> p.fine_bits], 1u); }
+        if (d[w]) {
+            const uint32_t mg = (uint32_t)(d[w] < 0 ? -d[w] : d[w]) - 1;
+            if (!same) atomicAdd(&lcnt[mg >> p.fine_bits], 1u);
+            else if (lane_rank == 0) atomicAdd(&lcnt[mg >> p.fine_bits], wave_live);
+        }
     __syncthreads();
     // exclusive scan of the <= 1024 counts by the whole workgroup (one bin per thread: wave scan + the 16 wave totals), and the
     // global reservation of every bin's run issued right away: its round trip to L2 overlaps the staging pass below, which only
@@ -288,7 +322,14 @@ __global__ void __launch_bounds__(RC_THREADS) msm_recode_scatter(ScalarSet set, 
         if (!d[w]) continue;
         const uint32_t mg = (uint32_t)(d[w] < 0 ? -d[w] : d[w]) - 1, bin = mg >> p.fine_bits;
         // window w takes its point from copy w of the table (groups == 1): copy_tag = w << nbits
-        staged[lstart[bin] + atomicAdd(&lcnt[bin], 1u)] = ((((uint32_t)w << p.nbits) | i) << 8) | (d[w] < 0 ? 0x80u : 0u) | (mg & fmask);
+        uint32_t at;
+        if (!same) at = atomicAdd(&lcnt[bin], 1u);
+        else {                                                         // one reservation for the wave's run, positions by rank
+            uint32_t base = 0;
+            if (lane_rank == 0) base = atomicAdd(&lcnt[bin], wave_live);
+            at = (uint32_t)__shfl((int)base, __ffsll((unsigned long long)lv) - 1) + lane_rank;
+        }
+        staged[lstart[bin] + at] = ((((uint32_t)w << p.nbits) | i) << 8) | (d[w] < 0 ? 0x80u : 0u) | (mg & fmask);
     }
     __syncthreads();
     copy_out_runs<RC_THREADS>(lstart, gbase, staged, entries, p.nbins);

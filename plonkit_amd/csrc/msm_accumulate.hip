@@ -56,8 +56,32 @@ __global__ void __launch_bounds__(MSM_THREADS, MINW) msm_accumulate(const G1Affi
     uint32_t ent[PER_LANE];
 #pragma unroll
     for (uint32_t k = 0; k < PER_LANE; k++) { const uint32_t idx = tid + k * MSM_THREADS; ent[k] = idx < nc ? entries[s + idx] : 0u; }
+    // A slice of ONE hot bucket (repeated scalars: all-(r-1), or a witness that is one value) makes all 64 lanes of every LDS atomic below
+    // hit the same word — a 64-way serialised read-modify-write, twice per entry: +10 % on the whole kernel, measured
+    // (profiles/r05_msm_all_r_minus_1_kernels.txt).  A wave whose entries all carry the same fine bucket counts them in one atomic
+    // and numbers them by position instead; the test is ~2 cheap instructions per entry in registers and one ballot.
+    const uint32_t wave_first = (tid & ~63u);                              // index of this wave's first entry of round k = 0
+    uint32_t f0, diff = 0;
+    {
+        const uint32_t e0 = __builtin_amdgcn_readfirstlane(ent[0]);       // (lane 0 of the wave: valid whenever the wave has any entry)
+        f0 = e0 & (FINE - 1);
 #pragma unroll
-    for (uint32_t k = 0; k < PER_LANE; k++) if (tid + k * MSM_THREADS < nc) atomicAdd(&cnt[ent[k] & (FINE - 1)], 1u);
+        for (uint32_t k = 0; k < PER_LANE; k++) if (tid + k * MSM_THREADS < nc) diff |= (ent[k] ^ e0) & (FINE - 1);
+    }
+    const bool wave_hot = wave_first < nc && __ballot(diff != 0) == 0;     // wave-uniform
+    // valid entries of this wave: (k, lane) with wave_first + lane + k * MSM_THREADS < nc — a prefix in (k, lane) order
+    uint32_t wave_n = 0;
+    if (wave_hot) {
+#pragma unroll
+        for (uint32_t k = 0; k < PER_LANE; k++) {
+            const uint32_t b0 = wave_first + k * MSM_THREADS;
+            wave_n += b0 >= nc ? 0u : (nc - b0 < 64u ? nc - b0 : 64u);
+        }
+        if ((tid & 63) == 0) atomicAdd(&cnt[f0], wave_n);
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < PER_LANE; k++) if (tid + k * MSM_THREADS < nc) atomicAdd(&cnt[ent[k] & (FINE - 1)], 1u);
+    }
     __syncthreads();
     if (tid < 64) {                                           // exclusive scan of the FINE counts by one wave
         constexpr uint32_t PER = FINE / 64;                   // 1 or 2 buckets per lane
@@ -75,9 +99,18 @@ __global__ void __launch_bounds__(MSM_THREADS, MINW) msm_accumulate(const G1Affi
     uint32_t *meta = task_meta + (size_t)task * META_PER_TASK;
     if (tid <= FINE) meta[tid] = start[tid];
     if (tid == 0) meta[FINE + 1] = nc;
+    if (wave_hot) {
+        uint32_t base = 0;
+        if ((tid & 63) == 0) base = atomicAdd(&cursor[f0], wave_n);
+        base = start[f0] + __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
-    for (uint32_t k = 0; k < PER_LANE; k++)
-        if (tid + k * MSM_THREADS < nc) { const uint32_t f = ent[k] & (FINE - 1); sorted[start[f] + atomicAdd(&cursor[f], 1u)] = ent[k]; }
+        for (uint32_t k = 0; k < PER_LANE; k++)
+            if (tid + k * MSM_THREADS < nc) sorted[base + k * 64 + (tid & 63)] = ent[k];          // (valid entries are a prefix in (k, lane) order)
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < PER_LANE; k++)
+            if (tid + k * MSM_THREADS < nc) { const uint32_t f = ent[k] & (FINE - 1); sorted[start[f] + atomicAdd(&cursor[f], 1u)] = ent[k]; }
+    }
     __syncthreads();
     if (nc == 0 || p.debug == 3) return;                      // (debug 3: time the sort alone)
     const uint32_t mu = (nc + MSM_THREADS - 1) / MSM_THREADS;
