@@ -216,6 +216,13 @@ void plk_keccak256(const uint8_t *in, uint64_t len, uint8_t out[32]);
  *      return PLK_ERR_ARG — the reference panics in its readers at that point.  The final check
  *      e(A, g2[0]) * e(B, g2[1]) == 1 is a real BN254 optimal-ate pairing (pairing.cpp), no trapdoor.          */
 int32_t plk_verify(const uint8_t *vk, uint64_t vk_len, const uint8_t *proof, uint64_t proof_len, int32_t *valid);
+/* plonk::verify with options.  PLK_VERIFY_STRICT_INPUTS: refuse keys with num_inputs = 0, as the Solidity verifier the reference
+ * generates does (contrib/template.sol:697 `require(vk.num_inputs >= 1)`).  bellman's Rust verifier behind `plonkit verify`
+ * (src/plonk.rs:189-210) has no such requirement as far as this package can tell (UNPINNED: the reference holds no zero-input
+ * fixture), so plk_verify accepts them by default; it applies the strict rule when the environment variable
+ * PLK_VERIFY_STRICT_INPUTS is set (to anything but 0).  Unknown flag bits: PLK_ERR_ARG.                                          */
+#define PLK_VERIFY_STRICT_INPUTS 1u
+int32_t plk_verify_ex(const uint8_t *vk, uint64_t vk_len, const uint8_t *proof, uint64_t proof_len, uint32_t flags, int32_t *valid);
 /* e(a, g2_a) * e(b, g2_b) == 1 ?   G2 as 128 bytes x.c1|x.c0|y.c1|y.c0 big-endian (the key/vk file encoding) */
 int32_t plk_pairing_check(const plk_g1_affine *a, const uint8_t *g2_a, const plk_g1_affine *b, const uint8_t *g2_b, int32_t *is_one);
 

@@ -503,10 +503,16 @@ def fr_from_bytes(b):
     return out
 
 
-def verify(vk_bytes, proof_bytes):
-    """plonk::verify(&vk, &proof, "keccak") (src/plonk.rs:189-210) on the bytes of vk.bin / proof.bin; pure CPU."""
+def verify(vk_bytes, proof_bytes, strict_inputs=None):
+    """plonk::verify(&vk, &proof, "keccak") (src/plonk.rs:189-210) on the bytes of vk.bin / proof.bin; pure CPU.
+    strict_inputs: None = plk_verify (accepts num_inputs = 0 unless PLK_VERIFY_STRICT_INPUTS is set); True / False = plk_verify_ex with /
+    without PLK_VERIFY_STRICT_INPUTS (the Solidity verifier's `num_inputs >= 1`, contrib/template.sol:697)."""
     valid = ctypes.c_int32(0)
-    _check(lib().plk_verify(bytes(vk_bytes), ctypes.c_uint64(len(vk_bytes)), bytes(proof_bytes), ctypes.c_uint64(len(proof_bytes)), ctypes.byref(valid)))
+    if strict_inputs is None:
+        _check(lib().plk_verify(bytes(vk_bytes), ctypes.c_uint64(len(vk_bytes)), bytes(proof_bytes), ctypes.c_uint64(len(proof_bytes)), ctypes.byref(valid)))
+    else:
+        _check(lib().plk_verify_ex(bytes(vk_bytes), ctypes.c_uint64(len(vk_bytes)), bytes(proof_bytes), ctypes.c_uint64(len(proof_bytes)),
+                                   ctypes.c_uint32(1 if strict_inputs else 0), ctypes.byref(valid)))
     return bool(valid.value)
 
 

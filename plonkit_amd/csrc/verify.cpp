@@ -3,6 +3,7 @@
 // reference's Solidity template spells out (contrib/template.sol:445-494 verify_initial, 496-586
 // verify_at_z, 588-689 reconstruct_d, 691-758 verify_commitments) over the file formats of SURVEY.md A.1.
 // Keccak transcript only (`-t keccak`); CPU code in the reference too.
+#include <cstdlib>
 #include "../../include/plonkit_amd.h"
 #include "keccak.h"
 #include "pairing.h"
@@ -101,10 +102,13 @@ HFr omega_of(uint32_t log_n) {                                // omega_{2^28} = 
 HJac smul(const HAffine &p, const HFr &k) { uint64_t c[4]; k.to_canonical(c); return jac_mul(jac_from_affine(p), c); }
 HJac smulj(const HJac &p, const HFr &k) { uint64_t c[4]; k.to_canonical(c); return jac_mul(p, c); }
 
-bool verify_keccak(const Vk &vk, const ProofData &P) {
+bool verify_keccak(const Vk &vk, const ProofData &P, bool strict_inputs) {
     const uint64_t N = vk.n + 1;
     if (N < 2 || (N & (N - 1)) || N > (1ull << 28)) return false;
     uint32_t log_n = 0; while ((1ull << log_n) < N) log_n++;
+    // PLK_VERIFY_STRICT_INPUTS: the Solidity verifier's `require(vk.num_inputs >= 1)` (contrib/template.sol:697) for deployments
+    // whose proofs end up on chain; off by default, see below
+    if (strict_inputs && vk.num_inputs < 1) return false;
     // contrib/template.sol:697 additionally requires num_inputs >= 1 — a restriction of the SOLIDITY verifier only.  `plonkit
     // verify` calls bellman's Rust verifier::verify (src/plonk.rs:196), which walks proof.input_values with no such
     // requirement [recollection; unpinned: no fixture has zero inputs], and a circom circuit without public signals is
@@ -189,13 +193,19 @@ bool verify_keccak(const Vk &vk, const ProofData &P) {
 
 }  // namespace
 
-PLK_API int32_t plk_verify(const uint8_t *vk_bytes, uint64_t vk_len, const uint8_t *proof_bytes, uint64_t proof_len, int32_t *valid) {
+PLK_API int32_t plk_verify_ex(const uint8_t *vk_bytes, uint64_t vk_len, const uint8_t *proof_bytes, uint64_t proof_len, uint32_t flags, int32_t *valid) {
     if (!vk_bytes || !proof_bytes || !valid) { set_error("plk_verify: null argument"); return PLK_ERR_ARG; }
+    if (flags & ~(uint32_t)PLK_VERIFY_STRICT_INPUTS) { set_error("plk_verify_ex: unknown flag"); return PLK_ERR_ARG; }
     Vk vk; ProofData pr;
     if (!parse_vk(vk_bytes, vk_len, &vk)) { set_error("plk_verify: malformed verification key"); return PLK_ERR_ARG; }
     if (!parse_proof(proof_bytes, proof_len, &pr)) { set_error("plk_verify: malformed proof"); return PLK_ERR_ARG; }
-    *valid = verify_keccak(vk, pr) ? 1 : 0;
+    *valid = verify_keccak(vk, pr, (flags & PLK_VERIFY_STRICT_INPUTS) != 0) ? 1 : 0;
     return PLK_OK;
+}
+
+PLK_API int32_t plk_verify(const uint8_t *vk_bytes, uint64_t vk_len, const uint8_t *proof_bytes, uint64_t proof_len, int32_t *valid) {
+    const char *e = getenv("PLK_VERIFY_STRICT_INPUTS");               // read per call: a test (or a service) may flip it
+    return plk_verify_ex(vk_bytes, vk_len, proof_bytes, proof_len, (e && e[0] && e[0] != '0') ? PLK_VERIFY_STRICT_INPUTS : 0u, valid);
 }
 
 PLK_API int32_t plk_pairing_check(const plk_g1_affine *a, const uint8_t *g2_a, const plk_g1_affine *b, const uint8_t *g2_b, int32_t *is_one) {

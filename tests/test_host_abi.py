@@ -319,3 +319,40 @@ def test_synthetic_ex_generator_invariants():
         with pytest.raises(pa.PlkError) as e:
             pa.Circuit.synthetic_ex(*args)
         assert e.value.code == 1
+
+
+def test_verify_strict_inputs_flag(golden_dir, golden_crs, monkeypatch):
+    """a key with num_inputs = 0 (legal circom, src/reader.rs:197): plk_verify accepts it by default, refuses it under
+    PLK_VERIFY_STRICT_INPUTS=1 / plk_verify_ex(PLK_VERIFY_STRICT_INPUTS) — the Solidity verifier's rule (contrib/template.sol:697).
+    The golden one-input proof is untouched by the flag.  Key and proof of the zero-input circuit come from the oracle (CPU)."""
+    import json
+    import plonkit_amd as pa
+    from oracle import plonk_oracle as po
+    from oracle.oracle_lib import R_MOD
+    u, v = 3, 5
+    wit = [1, u, v, u * v % R_MOD]
+    cons = [({"1": "1"}, {"2": "1"}, {"3": "1"})]
+    for _ in range(4):
+        wit.append(wit[-1] * v % R_MOD)
+        cons.append(({str(len(wit) - 2): "1"}, {"2": "1"}, {str(len(wit) - 1): "1"}))
+    js = {"n8": 32, "prime": str(R_MOD), "nVars": len(wit), "nOutputs": 0, "nPubInputs": 0, "nPrvInputs": 2,
+          "nLabels": len(wit), "nConstraints": len(cons), "constraints": [list(c) for c in cons]}
+    r1cs = po.load_r1cs_json(js)
+    S = po.setup(r1cs)
+    proof = po.write_proof(po.prove(r1cs, wit, golden_crs, S))
+    vk = po.write_vk(po.make_verification_key(S, golden_crs))
+    assert len(po.read_proof(proof).inputs) == 0
+    monkeypatch.delenv("PLK_VERIFY_STRICT_INPUTS", raising=False)
+    assert pa.verify(vk, proof) and pa.verify(vk, proof, strict_inputs=False)
+    assert not pa.verify(vk, proof, strict_inputs=True)
+    monkeypatch.setenv("PLK_VERIFY_STRICT_INPUTS", "1")
+    assert not pa.verify(vk, proof)                                     # plk_verify reads the switch per call
+    assert pa.verify(vk, proof, strict_inputs=False)                    # the explicit flag wins over the environment
+    monkeypatch.setenv("PLK_VERIFY_STRICT_INPUTS", "0")
+    assert pa.verify(vk, proof)
+    gvk, gproof = open(golden_dir + "/vk.bin", "rb").read(), open(golden_dir + "/proof.bin", "rb").read()
+    assert pa.verify(gvk, gproof, strict_inputs=True) and pa.verify(gvk, gproof, strict_inputs=False)
+    import ctypes
+    valid = ctypes.c_int32(0)
+    rc = pa.lib().plk_verify_ex(gvk, ctypes.c_uint64(len(gvk)), gproof, ctypes.c_uint64(len(gproof)), ctypes.c_uint32(2), ctypes.byref(valid))
+    assert rc == 1                                                      # PLK_ERR_ARG: unknown flag bit

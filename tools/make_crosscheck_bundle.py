@@ -3,7 +3,7 @@
 
 This image has no Rust toolchain, so the transpilation of long linear combinations (bellman's IntoMultipleGates adaptor,
 /root/reference/src/transpile.rs:127-139) has only ever been compared between this package's C++ transpiler and its own
-Python oracle: two restatements of one recollection.  This tool writes, for six circuits, exactly the files the
+Python oracle: two restatements of one recollection.  This tool writes, for seven circuits, exactly the files the
 reference's test flow produces (/root/reference/test/test_poseidon_plonk.sh:47-80):
 
     <case>/circuit.r1cs  witness.wtns  setup.key  vk.bin  proof.bin  proof.json  public.json  analyse.json
@@ -17,6 +17,8 @@ compare.sh pins or refutes the transpiler, the setup polynomials, the prover and
     poseidon_14      combinations of up to 24 / 60 signals, constant x LC outputs — domains 2^12, 2^14, 2^16
     poseidon_16
     long_lc        one 11-term LC x signal = 2-term LC, one LC x LC with constants (d / d_next chains, merges)
+    zero_inputs    a circuit without public signals: vk.num_inputs = 0 — does the reference's verifier accept it? (this package: yes by default,
+                   no under PLK_VERIFY_STRICT_INPUTS=1, the Solidity template's rule)
     dense_14       the bench's DENSE synthetic circuit at the 2^14 domain (plk_circuit_synthetic_ex, lc_terms = 7: every constraint
                    a 7-term linear combination folded through the d column) — the shape `prove.dense` of bench.py times
 
@@ -55,6 +57,21 @@ def long_lc_case():
     return js, wit
 
 
+def zero_inputs_case():
+    """no public signal at all (nPubInputs = 0, legal circom: src/reader.rs:197): vk.num_inputs = 0 and a proof with an empty input
+    list.  This package's verifier accepts it (PLK_VERIFY_STRICT_INPUTS=1 refuses, like contrib/template.sol:697); whether the
+    reference's `plonkit verify` does is UNPINNED — compare.sh's last line for this case answers it."""
+    u, v = 3, 5
+    wit = [1, u, v, u * v % R_MOD]
+    cons = [({"1": "1"}, {"2": "1"}, {"3": "1"})]
+    for _ in range(4):
+        wit.append(wit[-1] * v % R_MOD)
+        cons.append(({str(len(wit) - 2): "1"}, {"2": "1"}, {str(len(wit) - 1): "1"}))
+    js = {"n8": 32, "prime": str(R_MOD), "nVars": len(wit), "nOutputs": 0, "nPubInputs": 0, "nPrvInputs": 2,
+          "nLabels": len(wit), "nConstraints": len(cons), "constraints": [list(c) for c in cons]}
+    return js, wit
+
+
 def cases():
     yield "simple", json.load(open(os.path.join(GOLD, "circuit.r1cs.json"))), [int(x) for x in json.load(open(os.path.join(GOLD, "witness.json")))], 10
     for perms, rp, log_n in ((7, 20, 12), (6, 56, 14), (120, 20, 16)):
@@ -62,6 +79,8 @@ def cases():
         yield "poseidon_%d" % log_n, pl.as_circom_json(ni, nv, cons), wit, log_n
     js, wit = long_lc_case()
     yield "long_lc", js, wit, 10
+    js, wit = zero_inputs_case()
+    yield "zero_inputs", js, wit, 10
 
 
 def run(*args):
