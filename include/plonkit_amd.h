@@ -165,6 +165,23 @@ int32_t plk_comm_unique_id(plk_comm_id *out);
 int32_t plk_comm_init(plk_ctx *ctx, int32_t rank, int32_t world, const plk_comm_id *id, uint64_t first_index);
 int32_t plk_comm_init_tcp(plk_ctx *ctx, int32_t rank, int32_t world, uint16_t port, uint64_t first_index);
 int32_t plk_comm_set_shard(plk_ctx *ctx, uint64_t first_index);         /* same communicator, another slice of the key */
+/* Two ways to use the ranks of a communicator (bellman's Worker, src/plonk.rs:41,47,183, has one: threads of one address space):
+ *   PLK_SHARD_REPLICATE (default)  every rank runs the same plk_prove on the same circuit; only the commitments are split.  The
+ *                                  transforms, the quotient and the openings are done G times over (Amdahl: <= 2.5x at 2^20).
+ *   PLK_SHARD_SCATTER              OWNER COMPUTES: rank 0 alone runs plk_prove / plk_setup_write_vk.  For every batch of commitments
+ *                                  it sends each other rank that rank's slice of the scalar vectors (N/G x 32 B per vector: 4 MiB per
+ *                                  xGMI link at 2^20, 64 MiB at 2^24; grouped ncclSend / ncclRecv) and gets 96 bytes back; the other
+ *                                  ranks only hold their slice of the key and sit in plk_comm_serve.  Same proof bytes.  Rank r must
+ *                                  hold the key points [r * L, (r + 1) * L), L = the owner's key size (plk_comm_init's first_index).
+ * Every rank of a communicator must be in the same mode: PLK_SHARD_MODE=scatter in the environment of all of them, or
+ * plk_comm_set_mode on all of them right after plk_comm_init.                                                                        */
+#define PLK_SHARD_REPLICATE 0
+#define PLK_SHARD_SCATTER 1
+int32_t plk_comm_set_mode(plk_ctx *ctx, int32_t mode);
+/* worker ranks (rank > 0) of a scatter-mode communicator: commit whatever the owner sends against this context's key slice until the
+ * owner calls plk_comm_stop_workers (returns PLK_OK) or goes away (PLK_ERR_HIP / PLK_ERR_IO).  *batches = batches served.            */
+int32_t plk_comm_serve(plk_ctx *ctx, uint64_t *batches);
+int32_t plk_comm_stop_workers(plk_ctx *ctx);                            /* owner: ends every worker's plk_comm_serve */
 int32_t plk_comm_destroy(plk_ctx *ctx);                                 /* back to single-GPU commitments */
 /* plk_msm_g1_finish + the combiner: the commitment over all ranks' shards (each rank enqueued its own slice), affine */
 int32_t plk_msm_g1_finish_sharded(plk_ctx *ctx, plk_g1_affine *out);

@@ -144,6 +144,20 @@ class Context:
     def comm_init_tcp(self, rank, world, port, first_index):
         _check(lib().plk_comm_init_tcp(self._h, ctypes.c_int32(rank), ctypes.c_int32(world), ctypes.c_uint16(port), ctypes.c_uint64(first_index)))
 
+    def comm_set_mode(self, mode):
+        """"replicate" (every rank proves, commitments split) or "scatter" (owner computes: rank 0 proves, the others comm_serve); every
+        rank of the communicator must choose the same"""
+        _check(lib().plk_comm_set_mode(self._h, ctypes.c_int32({"replicate": 0, "scatter": 1}[mode])))
+
+    def comm_serve(self):
+        """worker ranks of a scatter-mode communicator: commit what the owner sends until it calls comm_stop_workers; returns the batches served"""
+        n = ctypes.c_uint64(0)
+        _check(lib().plk_comm_serve(self._h, ctypes.byref(n)))
+        return int(n.value)
+
+    def comm_stop_workers(self):
+        _check(lib().plk_comm_stop_workers(self._h))
+
     def comm_set_shard(self, first_index):
         _check(lib().plk_comm_set_shard(self._h, ctypes.c_uint64(first_index)))
 

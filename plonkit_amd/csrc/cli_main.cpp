@@ -237,6 +237,15 @@ static void join_ranks(plk_ctx *ctx, const Ranks &rk, uint64_t N) {
     CK("plk_comm_init", plk_comm_init(ctx, rk.rank, rk.world, &id, first));
     if (rk.rank == 0) (void)unlink(path.c_str());
 }
+// PLK_SHARD_MODE=scatter with several ranks (owner computes, include/plonkit_amd.h): rank 0 runs the command, the others serve its
+// commitments from their slice of the key and never touch the witness
+static bool scatter_mode(const Ranks &rk) { const char *e = getenv("PLK_SHARD_MODE"); return rk.world > 1 && e && !strcmp(e, "scatter"); }
+static int serve_owner(plk_ctx *ctx) {
+    uint64_t batches = 0;
+    CK("serve (owner-computes mode)", plk_comm_serve(ctx, &batches));
+    fprintf(stderr, "served %llu batches of commitments\n", (unsigned long long)batches);
+    return 0;
+}
 // uploads the key; with several ranks only this rank's slice [rank * N/world, (rank + 1) * N/world) of its first N points
 static void load_key(plk_ctx *ctx, const std::string &path, uint8_t g2[256], bool lagrange = false, const Ranks &rk = Ranks(), uint64_t N = 0) {
     const char *what = lagrange ? "read key_lagrange_form err" : "read key_monomial_form err";
@@ -335,12 +344,15 @@ static int run(int argc, char **argv) {
         } else {
             c = load_circuit(resolve_circuit(a), nullptr);
             ctx = open_ctx(rk);
-            CK("prepare err", plk_setup_prepare(ctx, c, &s));
+            if (scatter_mode(rk) && rk.rank != 0) CK("prepare err", plk_setup_prepare_host(c, &s));       // a worker only needs the domain size
+            else CK("prepare err", plk_setup_prepare(ctx, c, &s));
             join_ranks(ctx, rk, plk_setup_domain_size(s));
             load_key(ctx, a.get("srs_monomial_form"), g2, false, rk, plk_setup_domain_size(s));
+            if (scatter_mode(rk) && rk.rank != 0) return serve_owner(ctx);
         }
         std::vector<uint8_t> buf(4096); uint64_t len = 0;
         CK("make_verification_key", plk_setup_write_vk(ctx, s, g2, buf.data(), buf.size(), &len));
+        if (scatter_mode(rk)) CK("stop workers", plk_comm_stop_workers(ctx));
         std::string out = a.get("vk", "vk.bin");
         if (rk.rank == 0) {
             refuse_duplicate(a, out, "vk");
@@ -399,13 +411,16 @@ static int run(int argc, char **argv) {
             phase("load circuit + witness");
             ctx = open_ctx(rk);
             phase("plk_create (HIP init)");
-            CK("prepare err", plk_setup_prepare(ctx, c, &s));             // the slice of the key depends on the domain size
+            const bool worker = scatter_mode(rk) && rk.rank != 0;
+            if (worker) CK("prepare err", plk_setup_prepare_host(c, &s));  // a worker only needs the domain size
+            else CK("prepare err", plk_setup_prepare(ctx, c, &s));         // the slice of the key depends on the domain size
             phase("setup_prepare");
             join_ranks(ctx, rk, plk_setup_domain_size(s));
             const uint64_t N = plk_setup_domain_size(s);
             load_key(ctx, a.get("srs_monomial_form"), g2, false, rk, N);
             if (!lag.empty()) { uint8_t g2l[256]; load_key(ctx, lag, g2l, true, rk, N); }
             phase("load key (parse + upload)");
+            if (worker) return serve_owner(ctx);
         }
         if (!s) {
             CK("prepare err", plk_setup_prepare(ctx, c, &s));
@@ -418,6 +433,7 @@ static int run(int argc, char **argv) {
             buf.resize(len);
             rc = plk_prove(ctx, s, c, buf.data(), buf.size(), &len);
         }
+        if (scatter_mode(rk)) { const int32_t rs = plk_comm_stop_workers(ctx); if (rc == PLK_OK && rs != PLK_OK) die("stop workers", rs); }
         if (rc == PLK_ERR_UNSAT) { fprintf(stderr, "must satisfy: %s\n", plk_last_error()); return 101; }
         if (rc != PLK_OK) die("prove", rc);
         phase("prove");

@@ -38,6 +38,12 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    // scatter mode only (optional: a librccl without them keeps the replicate mode)
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                       // optional: the watchdog's way out
     ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr; // optional
@@ -60,6 +66,11 @@ Rccl *rccl() {
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.so, "ncclGetErrorString"));
         r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.so, "ncclCommAbort"));
         r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(r.so, "ncclCommGetAsyncError"));
+        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(r.so, "ncclBroadcast"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(r.so, "ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(r.so, "ncclRecv"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.so, "ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.so, "ncclGroupEnd"));
         if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { dlclose(r.so); r.so = nullptr; }
     });
     return r.so ? &r : nullptr;
@@ -91,6 +102,8 @@ __global__ void comm_test_stall_kernel(unsigned long long ticks) {           // 
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
+// PLK_SHARD_MODE=scatter: communicators start in owner-computes mode (every rank must agree); plk_comm_set_mode overrides
+bool shard_mode_default() { const char *e = getenv("PLK_SHARD_MODE"); return e && !strcmp(e, "scatter"); }
 void set_timeouts(int fd) {
     timeval tv{COMM_TIMEOUT_S, 0};
     ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
@@ -126,6 +139,11 @@ struct Comm {
     std::vector<plk_g1_jacobian> host_all;
     plk_ctx *ctx = nullptr;
     uint64_t gathers = 0;                    // number of exchanges performed (tracing / tests)
+    bool scatter = false;                    // owner-computes mode (PLK_SHARD_MODE=scatter / plk_comm_set_mode): see comm.h
+    DevBuf d_hdr, d_work;                    // scatter mode: the 64-byte header, a worker's received slices
+    hipEvent_t ev = nullptr;                 // orders the exchange stream against the producer / consumer stream of the scalars
+    std::vector<char> h_stage;               // TCP transport of the slices (test tier)
+    uint64_t seq = 0;                        // batches sent / received (both sides count: a header out of step is a protocol error)
     bool dead = false;                       // the watchdog aborted the communicator: every later exchange fails at once
     bool leak = false;                       // ... and could not abort the collective: stream and buffers are abandoned, not freed
 };
@@ -134,11 +152,13 @@ struct Comm {
 // completes and a plain synchronise would hang this rank (and with it the node) for ever.  Spins for the common case
 // (the exchange takes tens of microseconds), then yields, then sleeps.  On expiry or an asynchronous RCCL error the
 // communicator is aborted (ncclCommAbort tears the collective's kernel down so that the stream drains) and marked dead.
-static int32_t watch_exchange(Comm *C, hipStream_t st) {
+static int32_t watch_exchange(Comm *C, hipStream_t st, bool no_deadline = false) {
     using clk = std::chrono::steady_clock;
     Rccl *R = rccl();
     const auto t0 = clk::now();
-    const auto deadline = t0 + std::chrono::milliseconds(comm_timeout_ms());
+    // (no_deadline: a worker waiting for the owner's next batch — the owner may be inside its transforms, or between two proofs, for
+    //  any length of time; a peer that DIED still ends the wait through ncclCommGetAsyncError)
+    const auto deadline = no_deadline ? clk::time_point::max() : t0 + std::chrono::milliseconds(comm_timeout_ms());
     for (unsigned it = 0;; it++) {
         hipError_t q = hipStreamQuery(st);
         if (q == hipSuccess) return PLK_OK;
@@ -227,14 +247,166 @@ static int32_t builtin_combine(void *user, plk_g1_jacobian *sums, uint32_t count
 
 static void comm_free(Comm *C) {
     if (!C) return;
-    if (C->leak) { C->stream = nullptr; C->d_send.p = nullptr; C->d_recv.p = nullptr; C->nccl = nullptr; C->h_pin = nullptr; }      // see watch_exchange
+    if (C->leak) { C->stream = nullptr; C->d_send.p = nullptr; C->d_recv.p = nullptr; C->d_hdr.p = nullptr; C->d_work.p = nullptr; C->nccl = nullptr; C->h_pin = nullptr; }      // see watch_exchange
     if (C->nccl) { Rccl *R = rccl(); if (R) (void)R->CommDestroy(C->nccl); }
     if (C->stream) (void)hipStreamDestroy(C->stream);
-    C->d_send.release(); C->d_recv.release();
+    C->d_send.release(); C->d_recv.release(); C->d_hdr.release(); C->d_work.release();
+    if (C->ev) (void)hipEventDestroy(C->ev);
     if (C->h_pin) (void)hipHostFree(C->h_pin);
     for (int fd : C->fds) if (fd >= 0) ::close(fd);
     if (C->listen_fd >= 0) ::close(C->listen_fd);
     delete C;
+}
+
+// ------------------------------------------------------------------------------- owner-computes mode: the transport
+// One batch = a 64-byte header from rank 0 to everyone, then rank 0 -> rank r: count x (r's share of the vector) x 32 bytes, grouped
+// ncclSend / ncclRecv on the exchange stream (xGMI is point to point: the seven slices leave on seven links at once — 4 MiB per link
+// and vector at the 2^20 domain, 64 MiB at 2^24), then the all-gather of the 96-byte partial sums every mode ends a batch with.
+struct ShardHeader { uint32_t magic, op, count, lagrange; uint64_t n, slice, seq; uint8_t pad[24]; };
+static_assert(sizeof(ShardHeader) == 64, "64-byte header");
+constexpr uint32_t SHARD_MAGIC = 0x706c6b53u;          // "plkS"
+
+static bool scatter_rank(const plk_ctx *ctx, bool owner) {
+    const Comm *C = ctx ? static_cast<const Comm *>(ctx->comm) : nullptr;
+    return C && C->scatter && C->world > 1 && (owner ? C->rank == 0 : C->rank > 0);
+}
+bool comm_scatter_owner(const plk_ctx *ctx) { return scatter_rank(ctx, true); }
+bool comm_scatter_worker(const plk_ctx *ctx) { return scatter_rank(ctx, false); }
+
+static int32_t scatter_ready(Comm *C) {
+    if (C->tcp) return PLK_OK;
+    Rccl *R = rccl();
+    if (!R || !R->Broadcast || !R->Send || !R->Recv || !R->GroupStart || !R->GroupEnd) { set_error("scatter mode: this librccl lacks ncclBroadcast / ncclSend / ncclRecv / ncclGroupStart"); return PLK_ERR_HIP; }
+    if (C->dead || !C->nccl) { set_error("RCCL exchange: the communicator was aborted earlier (plk_comm_destroy + plk_comm_init to start over)"); return PLK_ERR_HIP; }
+    PLK_HIP(hipSetDevice(C->ctx->device));
+    PLK_TRY(C->d_hdr.reserve(sizeof(ShardHeader)));
+    if (!C->ev) PLK_HIP(hipEventCreateWithFlags(&C->ev, hipEventDisableTiming));
+    if (C->h_pin_cap < 2 * sizeof(ShardHeader)) {
+        if (C->h_pin) (void)hipHostFree(C->h_pin);
+        C->h_pin = nullptr; C->h_pin_cap = 0;
+        PLK_HIP(hipHostMalloc(&C->h_pin, (size_t)8 * sizeof(plk_g1_jacobian) * ((size_t)C->world + 1), hipHostMallocDefault));
+        C->h_pin_cap = (size_t)8 * sizeof(plk_g1_jacobian) * ((size_t)C->world + 1);
+    }
+    return PLK_OK;
+}
+
+// rank 0 -> everyone
+static int32_t send_header(Comm *C, const ShardHeader &h) {
+    if (C->tcp) {
+        for (int r = 1; r < C->world; r++) if (!send_all(C->fds[r], &h, sizeof h)) { set_error("tcp scatter: a rank went away"); return PLK_ERR_IO; }
+        return PLK_OK;
+    }
+    Rccl *R = rccl();
+    memcpy(C->h_pin, &h, sizeof h);
+    PLK_HIP(hipMemcpyAsync(C->d_hdr.p, C->h_pin, sizeof h, hipMemcpyHostToDevice, C->stream));
+    ncclResult_t e = R->Broadcast(C->d_hdr.p, C->d_hdr.p, sizeof h, ncclUint8, 0, C->nccl, C->stream);
+    if (e != ncclSuccess) return rccl_fail(e, "ncclBroadcast (batch header)");
+    return PLK_OK;
+}
+static int32_t recv_header(Comm *C, ShardHeader *h) {
+    if (C->tcp) {
+        timeval none{0, 0};                                          // (waiting for work is not a fault: no receive timeout here)
+        ::setsockopt(C->fds[0], SOL_SOCKET, SO_RCVTIMEO, &none, sizeof none);
+        const bool ok = recv_all(C->fds[0], h, sizeof *h);
+        set_timeouts(C->fds[0]);
+        if (!ok) { set_error("tcp scatter: the owner went away"); return PLK_ERR_IO; }
+        return PLK_OK;
+    }
+    Rccl *R = rccl();
+    ncclResult_t e = R->Broadcast(C->d_hdr.p, C->d_hdr.p, sizeof *h, ncclUint8, 0, C->nccl, C->stream);
+    if (e != ncclSuccess) return rccl_fail(e, "ncclBroadcast (batch header)");
+    PLK_HIP(hipMemcpyAsync(C->h_pin, C->d_hdr.p, sizeof *h, hipMemcpyDeviceToHost, C->stream));
+    PLK_TRY(watch_exchange(C, C->stream, true));
+    memcpy(h, C->h_pin, sizeof *h);
+    return PLK_OK;
+}
+static uint64_t share_of(uint64_t n, uint64_t slice, int rank) {
+    const uint64_t lo = (uint64_t)rank * slice;
+    return lo >= n ? 0 : (n - lo < slice ? n - lo : slice);
+}
+
+int32_t comm_send_work(plk_ctx *ctx, const void *const *vecs, uint32_t count, uint64_t n, uint64_t slice, bool lagrange, hipStream_t producer) {
+    Comm *C = static_cast<Comm *>(ctx->comm);
+    if (count == 0 || count > 8) { set_error("scatter: batch must be 1..8"); return PLK_ERR_ARG; }
+    PLK_TRY(scatter_ready(C));
+    ShardHeader h{};
+    h.magic = SHARD_MAGIC; h.op = SHARD_COMMIT; h.count = count; h.lagrange = lagrange ? 1 : 0;
+    h.n = n; h.slice = slice; h.seq = ++C->seq;
+    if (h.slice == 0) { set_error("scatter: no key resident on the owner"); return PLK_ERR_SRS; }
+    if (C->tcp) {                                                    // test tier: through host memory
+        PLK_HIP(hipStreamSynchronize(producer));
+        PLK_TRY(send_header(C, h));
+        for (int r = 1; r < C->world; r++) {
+            const uint64_t len = share_of(n, h.slice, r);
+            if (!len) continue;
+            C->h_stage.resize((size_t)len * 32);
+            for (uint32_t k = 0; k < count; k++) {
+                PLK_HIP(hipMemcpy(C->h_stage.data(), static_cast<const char *>(vecs[k]) + (size_t)r * h.slice * 32, (size_t)len * 32, hipMemcpyDeviceToHost));
+                if (!send_all(C->fds[r], C->h_stage.data(), (size_t)len * 32)) { set_error("tcp scatter: a rank went away"); return PLK_ERR_IO; }
+            }
+        }
+        return PLK_OK;
+    }
+    Rccl *R = rccl();
+    PLK_HIP(hipEventRecord(C->ev, producer));                        // the scalars are still being written on the prover's stream
+    PLK_HIP(hipStreamWaitEvent(C->stream, C->ev, 0));
+    PLK_TRY(send_header(C, h));
+    ncclResult_t e = R->GroupStart();
+    if (e != ncclSuccess) return rccl_fail(e, "ncclGroupStart");
+    for (int r = 1; r < C->world && e == ncclSuccess; r++) {
+        const uint64_t len = share_of(n, h.slice, r);
+        for (uint32_t k = 0; k < count && len && e == ncclSuccess; k++)
+            e = R->Send(static_cast<const char *>(vecs[k]) + (size_t)r * h.slice * 32, (size_t)len * 32, ncclUint8, r, C->nccl, C->stream);
+    }
+    const ncclResult_t e2 = R->GroupEnd();
+    if (e != ncclSuccess) return rccl_fail(e, "ncclSend (scalar slices)");
+    if (e2 != ncclSuccess) return rccl_fail(e2, "ncclGroupEnd");
+    return PLK_OK;                                                   // (not waited for: the batch's all-gather follows on the same stream)
+}
+
+int32_t comm_recv_work(plk_ctx *ctx, ShardWork *w, hipStream_t consumer) {
+    Comm *C = static_cast<Comm *>(ctx->comm);
+    PLK_TRY(scatter_ready(C));
+    ShardHeader h{};
+    PLK_TRY(recv_header(C, &h));
+    if (h.magic != SHARD_MAGIC || (h.op != SHARD_COMMIT && h.op != SHARD_STOP) || h.seq != ++C->seq) { set_error("scatter: batch header out of step (do all ranks run the same mode?)"); return PLK_ERR_IO; }
+    *w = ShardWork();
+    w->op = h.op;
+    if (h.op == SHARD_STOP) return PLK_OK;
+    if (h.count == 0 || h.count > 8 || h.slice == 0) { set_error("scatter: malformed batch header"); return PLK_ERR_IO; }
+    w->count = h.count; w->lagrange = h.lagrange; w->n = h.n; w->slice = h.slice;
+    w->len = share_of(h.n, h.slice, C->rank);
+    if (!w->len) return PLK_OK;
+    PLK_TRY(C->d_work.reserve((size_t)h.count * w->len * 32));
+    for (uint32_t k = 0; k < h.count; k++) w->vec[k] = static_cast<char *>(C->d_work.p) + (size_t)k * w->len * 32;
+    if (C->tcp) {
+        C->h_stage.resize((size_t)w->len * 32);
+        for (uint32_t k = 0; k < h.count; k++) {
+            if (!recv_all(C->fds[0], C->h_stage.data(), (size_t)w->len * 32)) { set_error("tcp scatter: the owner went away"); return PLK_ERR_IO; }
+            PLK_HIP(hipMemcpy(const_cast<void *>(w->vec[k]), C->h_stage.data(), (size_t)w->len * 32, hipMemcpyHostToDevice));
+        }
+        return PLK_OK;
+    }
+    Rccl *R = rccl();
+    ncclResult_t e = R->GroupStart();
+    if (e != ncclSuccess) return rccl_fail(e, "ncclGroupStart");
+    for (uint32_t k = 0; k < h.count && e == ncclSuccess; k++) e = R->Recv(const_cast<void *>(w->vec[k]), (size_t)w->len * 32, ncclUint8, 0, C->nccl, C->stream);
+    const ncclResult_t e2 = R->GroupEnd();
+    if (e != ncclSuccess) return rccl_fail(e, "ncclRecv (scalar slices)");
+    if (e2 != ncclSuccess) return rccl_fail(e2, "ncclGroupEnd");
+    PLK_HIP(hipEventRecord(C->ev, C->stream));                       // the commitment's kernels read the slices on the consumer's stream
+    PLK_HIP(hipStreamWaitEvent(consumer, C->ev, 0));
+    return PLK_OK;
+}
+
+int32_t comm_send_stop(plk_ctx *ctx) {
+    Comm *C = static_cast<Comm *>(ctx->comm);
+    PLK_TRY(scatter_ready(C));
+    ShardHeader h{};
+    h.magic = SHARD_MAGIC; h.op = SHARD_STOP; h.seq = ++C->seq;
+    PLK_TRY(send_header(C, h));
+    if (!C->tcp) PLK_TRY(watch_exchange(C, C->stream));
+    return PLK_OK;
 }
 
 void comm_release(plk_ctx *ctx) {
@@ -276,6 +448,7 @@ int32_t plk_comm_init(plk_ctx *ctx, int32_t rank, int32_t world, const plk_comm_
     if (e != ncclSuccess) { C->nccl = nullptr; comm_free(C); return rccl_fail(e, "ncclCommInitRank (one rank per GPU: RCCL refuses two ranks on one device)"); }
     if (hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); comm_free(C); set_error("plk_comm_init: cannot create a stream"); return PLK_ERR_HIP; }
     ctx->comm = C;
+    C->scatter = shard_mode_default();
     return plk_set_commit_shard(ctx, first_index, builtin_combine, C);
 }
 
@@ -334,8 +507,20 @@ int32_t plk_comm_init_tcp(plk_ctx *ctx, int32_t rank, int32_t world, uint16_t po
     void *C = nullptr;
     PLK_TRY(plk_comm_open_tcp(rank, world, port, &C));
     static_cast<Comm *>(C)->ctx = ctx;
+    static_cast<Comm *>(C)->scatter = shard_mode_default();
     ctx->comm = C;
     return plk_set_commit_shard(ctx, first_index, builtin_combine, C);
+}
+
+int32_t plk_comm_set_mode(plk_ctx *ctx, int32_t mode) {
+    if (!ctx || !ctx->comm || (mode != PLK_SHARD_REPLICATE && mode != PLK_SHARD_SCATTER)) { set_error("plk_comm_set_mode: no communicator on this context, or an unknown mode"); return PLK_ERR_ARG; }
+    static_cast<Comm *>(ctx->comm)->scatter = mode == PLK_SHARD_SCATTER;
+    return PLK_OK;
+}
+
+int32_t plk_comm_stop_workers(plk_ctx *ctx) {
+    if (!comm_scatter_owner(ctx)) { set_error("plk_comm_stop_workers: not the owner (rank 0) of a communicator in scatter mode"); return PLK_ERR_ARG; }
+    return comm_send_stop(ctx);
 }
 
 int32_t plk_comm_set_shard(plk_ctx *ctx, uint64_t first_index) {

@@ -19,6 +19,7 @@
 #include "poly.h"
 #include "circuit.h"
 #include "keccak.h"
+#include "comm.h"
 #include <chrono>
 #include <memory>
 #include <thread>
@@ -93,6 +94,12 @@ static int32_t commit_begin(plk_ctx *ctx, const Fr *const *vecs, uint32_t count,
     }
     const uint64_t first_base = ctx->combine ? 0 : lo;
     ctx->commit_done.clear();
+    // owner-computes mode (comm.h): the other ranks do not run this prover — they get their slices of the vectors now, commit them
+    // while this rank commits its own, and meet it in commit_end's exchange
+    if (comm_scatter_owner(ctx)) {
+        if (ctx->shard_first != 0) { set_error("scatter mode: the owner (rank 0) must hold the first slice of the key"); return PLK_ERR_ARG; }
+        PLK_TRY(comm_send_work(ctx, reinterpret_cast<const void *const *>(vecs), count, n, ctx->srs_n, lagrange, ctx->stream));
+    }
     // at the largest sizes a batch of commitments would need gigabytes of per-task partial-sum slots (2^26 gates: 16 GiB for
     // four wires, which is what stands between that domain and the 288 GB): one commitment at a time there
     if (count > 1 && hi - lo > msm_piece_terms()) {
@@ -137,6 +144,34 @@ static int32_t commit_many(plk_ctx *ctx, const Fr *const *coefs, uint32_t count,
         done += b;
     }
     return PLK_OK;
+}
+
+// plk_comm_serve, the worker side of owner-computes mode: whatever the owner's commit_begin sends is committed against this context's
+// slice of the key (commit_begin / commit_end on the received slices: same pieces, same FIFO, same exchange as a replicated rank)
+static int32_t serve_impl(plk_ctx *ctx, uint64_t *batches) {
+    for (;;) {
+        ShardWork w;
+        PLK_TRY(comm_recv_work(ctx, &w, ctx->stream));
+        if (w.op == SHARD_STOP) return PLK_OK;
+        const bool lagrange = w.lagrange != 0;
+        if (lagrange && !ctx->lag.pts) { set_error("plk_comm_serve: the owner commits against a Lagrange-form key this rank does not hold"); return PLK_ERR_SRS; }
+        {
+            SrsSlotSwap active(ctx, lagrange);
+            if (ctx->srs_n != w.slice) { set_error("plk_comm_serve: this rank's key slice has a different size than the owner's (every rank holds points [r L, (r+1) L))"); return PLK_ERR_SRS; }
+        }
+        const Fr *vecs[8];
+        static const Fr none{};
+        for (uint32_t k = 0; k < w.count; k++) vecs[k] = w.len ? static_cast<const Fr *>(w.vec[k]) : &none;
+        // (the received slices ARE this rank's index range: commit them as vectors of their own length from index 0)
+        const uint64_t keep_first = ctx->shard_first;
+        ctx->shard_first = 0;
+        int32_t rc = commit_begin(ctx, vecs, w.count, w.len, lagrange);
+        HAffine out[8];
+        if (rc == PLK_OK) rc = commit_end(ctx, w.count, out);
+        ctx->shard_first = keep_first;
+        PLK_TRY(rc);
+        if (batches) ++*batches;
+    }
 }
 
 // plk_prove / plk_setup_write_vk own the two-slot commitment FIFO for the duration of the call: it must be empty on
@@ -930,11 +965,25 @@ int32_t plk_setup_prepare_host(const plk_circuit *c, plk_setup **out) {
 int32_t plk_setup_upload(plk_ctx *ctx, plk_setup *s) {
     return guarded("plk_setup_upload", PLK_ERR_HIP, [&] { return setup_upload_impl(ctx, s); });
 }
+static int32_t not_a_worker(plk_ctx *ctx, const char *who) {
+    if (!ctx || !comm_scatter_worker(ctx)) return PLK_OK;
+    set_error(std::string(who) + ": this rank serves the owner's commitments (owner-computes mode: call plk_comm_serve; only rank 0 proves)");
+    return PLK_ERR_ARG;
+}
 int32_t plk_setup_write_vk(plk_ctx *ctx, const plk_setup *s, const uint8_t g2_bytes[256], uint8_t *out, uint64_t cap, uint64_t *len) {
+    PLK_TRY(not_a_worker(ctx, "plk_setup_write_vk"));
     return guarded("plk_setup_write_vk", PLK_ERR_HIP, [&] { return setup_write_vk_impl(ctx, s, g2_bytes, out, cap, len); });
 }
 int32_t plk_prove(plk_ctx *ctx, const plk_setup *S, const plk_circuit *c, uint8_t *proof_out, uint64_t cap, uint64_t *len) {
+    PLK_TRY(not_a_worker(ctx, "plk_prove"));
     return guarded("plk_prove", PLK_ERR_HIP, [&] { return prove_impl(ctx, S, c, proof_out, cap, len); });
+}
+int32_t plk_comm_serve(plk_ctx *ctx, uint64_t *batches) {
+    if (batches) *batches = 0;
+    if (!ctx || !comm_scatter_worker(ctx)) { set_error("plk_comm_serve: not a worker rank (rank > 0) of a communicator in scatter mode"); return PLK_ERR_ARG; }
+    if (!ctx->srs) { set_error("plk_comm_serve: no key slice resident"); return PLK_ERR_SRS; }
+    PLK_TRY(fifo_must_be_empty(ctx, "plk_comm_serve"));
+    return guarded("plk_comm_serve", PLK_ERR_HIP, [&] { PLK_HIP(hipSetDevice(ctx->device)); FifoGuard drain(ctx); return serve_impl(ctx, batches); });
 }
 
 }  // extern "C"

@@ -213,6 +213,9 @@ def test_bench_n2_control_flow_on_one_gpu():
     assert "error" not in st and st["terms_total"] == 1 << 18 and st["terms_per_gpu"] == 1 << 17 and st["scaling_vs_1gpu"] > 0
     assert "error" not in line["prove"] and line["prove"]["n_gpus"] == 2 and line["prove"]["proof_bytes"] == 1144
     assert line["strong_value"] == st["Mscalar_mul_s"] and line["strong_scaling_vs_1gpu"] == st["scaling_vs_1gpu"]
+    sc = line["prove"]["scatter"]                                     # the same prove in owner-computes mode (rank 0 proves, rank 1 serves)
+    assert "error" not in sc and sc["n_gpus"] == 2 and sc["verified"] is True and sc["wall_s"] > 0
+    assert line["failed_legs"] == []
     pt = line["prove_throughput"]                                     # every GPU proving on its own (replicas), two proofs in flight each
     assert "error" not in pt and pt["n_gpus"] == 2 and pt["in_flight_per_gpu"] == 2 and pt["proofs_per_s"] > 0
 
@@ -258,6 +261,8 @@ def test_eight_rank_rehearsal_on_one_gpu():
     assert "error" not in pr, pr
     assert pr["n_gpus"] == 8 and pr["srs_points_per_gpu"] == (1 << 14) // 8 and pr["proof_bytes"] == 1144
     assert pr["same_proof_on_every_rank"] is True and pr["verified"] is True
+    assert "error" not in pr["scatter"] and pr["scatter"]["verified"] is True and pr["scatter"]["n_gpus"] == 8      # owner-computes mode at world 8
+    assert line["failed_legs"] == []
     assert line["strong_value"] > 0 and line["cpu_baseline"]["kind"] == "port"
 
 
@@ -304,3 +309,102 @@ print("ERRS", repr(errs))
     #  collective it can — so the call returns when the 1.5 s stall ends: well before the 6 s that four stalled exchanges would take)
     assert errs[0][2] < 3.0, "the first exchange must be abandoned, not waited out four times: %r" % (errs,)
     assert errs[1][1] == 4 and "aborted earlier" in errs[1][0] and errs[1][2] < 0.5, out
+
+
+# ---------------------------------------------------------------- owner-computes ("scatter") mode, round 5
+def _scatter_rank(rank, world, port, log_n, lagrange, q):
+    """rank 0 proves; the others hold a slice of the key and serve its commitments (plk_comm_serve)"""
+    import numpy as np
+    import torch
+    import plonkit_amd as pa
+    n = 1 << log_n
+    local = n // world
+    ctx = pa.Context(0)
+    ctx.srs_generate(local, rank * local, 42)
+    if lagrange:
+        full = pa.Context(0)
+        full.srs_generate(n, 0, 42)
+        keep = torch.zeros((n, 8), dtype=torch.int64, device="cuda:0")
+        full.g1_intt_srs_dev(log_n, keep.data_ptr())
+        full.synchronize()
+        ctx.srs_lagrange_upload(keep.cpu().numpy().view(np.uint64)[rank * local:(rank + 1) * local])
+        full.close()
+    ctx.comm_init_tcp(rank, world, port, rank * local)
+    ctx.comm_set_mode("scatter")
+    if rank == 0:
+        circ = pa.Circuit.synthetic(n - 2)
+        setup = pa.SetupForProver(ctx, circ)
+        vk = setup.verification_key_bytes(pa.crs42_g2_bytes())
+        proofs = [setup.prove(circ) for _ in range(2)]
+        ctx.comm_stop_workers()
+        q.put((0, vk, proofs, ctx.comm_info()[2]))
+        setup.close(); circ.close()
+    else:
+        try:
+            served = ctx.comm_serve()
+            q.put((rank, None, None, served))
+        except Exception as exc:                                    # noqa: BLE001
+            q.put((rank, None, repr(exc), -1))
+    ctx.close()
+
+
+@pytest.mark.parametrize("world,log_n,lagrange", [(2, 12, False), (4, 14, True), (8, 13, False)])
+def test_scatter_mode_gives_the_single_gpu_proof(world, log_n, lagrange):
+    """PLK_SHARD_SCATTER: only rank 0 runs the prover; every batch of commitments sends each other rank its slice of the scalar
+    vectors and gets 96 bytes back.  Same verification key and proof bytes as one GPU with the whole key; the workers serve
+    2 (key) + 2 x 4 (proofs) batches.  (Ranks share this box's single GPU: TCP transport of the test tier.)"""
+    import plonkit_amd as pa
+    n = 1 << log_n
+    ctx = pa.Context(0)
+    ctx.srs_generate(n, 0, 42)
+    circ = pa.Circuit.synthetic(n - 2)
+    setup = pa.SetupForProver(ctx, circ)
+    want_vk, want_proof = setup.verification_key_bytes(pa.crs42_g2_bytes()), setup.prove(circ)
+    setup.close(); circ.close(); ctx.close()
+    port = _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_scatter_rank, args=(r, world, port, log_n, lagrange, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    rank0 = res[0]
+    assert rank0[1] == want_vk and rank0[2] == [want_proof, want_proof]
+    assert rank0[3] == 2 + 2 * 4                                    # exchanges on the owner: the key in two batches, four per proof
+    for rank, _, err, served in res[1:]:
+        assert err is None and served == 2 + 2 * 4, (rank, err, served)
+
+
+def test_scatter_mode_through_the_plonkit_binary(tmp_path):
+    """PLK_SHARD_MODE=scatter with three `plonkit` processes (cli_main.cpp): rank 0 proves, ranks 1-2 print how many batches they
+    served; vk.bin / proof.bin equal the one-process files.  A worker that is asked to prove itself is refused."""
+    import subprocess
+    import plonkit_amd as pa
+    cli = os.path.join(os.path.dirname(pa.lib_path()), "plonkit")
+    log_n = 12
+    circ = pa.Circuit.synthetic((1 << log_n) - 2)
+    f = lambda name: str(tmp_path / name)
+    open(f("c.r1cs"), "wb").write(circ.export("r1cs"))
+    open(f("w.wtns"), "wb").write(circ.export("wtns"))
+    circ.close()
+    subprocess.check_call([cli, "setup", "-p", str(log_n), "-m", f("key.bin")], stderr=subprocess.DEVNULL)
+    subprocess.check_call([cli, "export-verification-key", "-m", f("key.bin"), "-c", f("c.r1cs"), "-v", f("vk1.bin")], stderr=subprocess.DEVNULL)
+    subprocess.check_call([cli, "prove", "-m", f("key.bin"), "-c", f("c.r1cs"), "-w", f("w.wtns"), "-p", f("p1.bin"), "-j", f("j1.json"), "-i", f("i1.json")],
+                          stderr=subprocess.DEVNULL)
+    world = 4
+    for cmd, outs, batches in ((["export-verification-key", "-m", f("key.bin"), "-c", f("c.r1cs"), "-v", f("vk2.bin")], ("vk1.bin", "vk2.bin"), 2),
+                               (["prove", "-m", f("key.bin"), "-c", f("c.r1cs"), "-w", f("w.wtns"), "-p", f("p2.bin"), "-j", f("j2.json"), "-i", f("i2.json")], ("p1.bin", "p2.bin"), 4)):
+        port = _free_port()
+        procs = []
+        for rank in range(world):
+            env = dict(os.environ, PLONKIT_WORLD=str(world), PLONKIT_RANK=str(rank), PLONKIT_COMM="tcp:%d" % port, PLONKIT_DEVICE="0", PLK_SHARD_MODE="scatter")
+            procs.append(subprocess.Popen([cli] + cmd, env=env, stderr=subprocess.PIPE))
+        for rank, p in enumerate(procs):
+            _, err = p.communicate(timeout=300)
+            assert p.returncode == 0, err.decode()[-2000:]
+            if rank:
+                assert ("served %d batches" % batches) in err.decode()
+        assert open(f(outs[0]), "rb").read() == open(f(outs[1]), "rb").read()
+    assert pa.verify(open(f("vk2.bin"), "rb").read(), open(f("p2.bin"), "rb").read())
