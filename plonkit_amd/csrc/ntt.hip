@@ -289,8 +289,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
 //     busy — the barriers made all eight waves of a tile (and usually both tiles of a CU) do their LDS traffic at the same time;
 //   * LDS is laid out the way the reader reads it: 64 consecutive 16-byte words per instruction, no bank conflicts on either
 //     side (pads per round from the plan), one address register with immediate offsets.
-// The butterfly arithmetic is r4_finish's, bit for bit (same lazy bounds); `nonzero` / `quarter` inputs (zero-padded natural-
-// order LDE) stay on the old kernels.
+// The old kernels (ntt_pass_cols / ntt_pass_rows) keep the shapes this one does not take: transforms of <= 2^11 points, 6-bit passes
+// (2^12, 2^13), and passes whose inter-pass twiddle table does not fit the cap.
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -406,7 +406,11 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_w(NttPassArgs a) {
             else return (((((size_t)(k1_0 + col)) << log_m) + mu) << LR) + n;
         };
         const size_t g0 = addr(0), g1 = addr(1), g2 = addr(2), g3 = addr(3);
-        x0 = ldw(in + g0); x1 = ldw(in + g1); x2 = ldw(in + g2); x3 = ldw(in + g3);
+        // (zero-padded input, the natural-order LDE: indices >= nonzero are zeros that are neither stored nor read; a zero stays a zero
+        //  through the input scaling below)
+        const size_t live = a.nonzero ? (size_t)a.nonzero : ~(size_t)0;
+        x0 = g0 < live ? ldw(in + g0) : w_zero<FrW>(); x1 = g1 < live ? ldw(in + g1) : w_zero<FrW>();
+        x2 = g2 < live ? ldw(in + g2) : w_zero<FrW>(); x3 = g3 < live ? ldw(in + g3) : w_zero<FrW>();
         const Fr *const pre_direct = a.pre_direct_b[blockIdx.y];
         const PowTable pre = a.pre_b[blockIdx.y];
         if (pre_direct) {
@@ -717,7 +721,9 @@ static bool ntt_wave_enabled() {
     return on != 0;
 }
 static bool ntt_wave_shape(const NttPassArgs &a) {
-    return ntt_wave_enabled() && a.log_r >= 7 && a.log_r <= 10 && a.log_r + a.log_c == LOG_TILE && a.nonzero == 0 && a.quarter == 0;
+    // (zero-padded inputs are taken too — `quarter`, the old kernels' copy-instead-of-butterfly shortcut for them, is simply not used;
+    //  their per-element coset tables are never combined with padding)
+    return ntt_wave_enabled() && a.log_r >= 7 && a.log_r <= 10 && a.log_r + a.log_c == LOG_TILE && !(a.nonzero && a.pre_direct_b[0]);
 }
 template <bool ROWS>
 static void ntt_launch_w(const NttPassArgs &a, dim3 grid, hipStream_t stream) {
