@@ -53,14 +53,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 ALGO_BYTES_PER_TERM = 96         # 64 B base + 32 B scalar
 # PMC traffic of msm_accumulate for ONE 2^20-term launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of
-# `bench.py --msm-only --pipeline-depth 1`, profiles/r04_pmc_traffic.txt, 77 launches, spread < 0.02 %; round 3: 1,016,200 + 52,089):
-# 1,015,858 KB fetched (15.7 M gathers of one 64-byte point each from the 0.94 GiB fixed-base table = 1.007 GB, + the 63 MB of
+# `bench.py --msm-only --pipeline-depth 1`, profiles/r05_pmc_traffic.txt, 77 launches, spread < 0.1 %; rounds 3-4: 1,016 k + 50-52 k):
+# 1,015,901 KB fetched (15.7 M gathers of one 64-byte point each from the 0.94 GiB fixed-base table = 1.007 GB, + the 63 MB of
 # entries, read once: consistent with 64 B per gather, i.e. no over-fetch; these are not wide coalesced streams, so the
-# guide's x2 correction for 16 B/lane streaming reads does not apply) + 50,047 KB written (lane partial sums).  Only for
-# --log-n 20.  It is NOT measured in the run that prints the line (PMC collection needs the profiler): `traffic_source` says so.
-PMC_TRAFFIC_BYTES_2POW20 = (1015858 + 50047) * 1024
+# guide's x2 correction for 16 B/lane streaming reads does not apply) + 101,189 KB written (lane partial sums: 50 MB of payload in 144-byte
+# flushes, counted as partial 64-byte requests — see the profile file).  Only for --log-n 20.  It is NOT measured in the run that prints the
+# line (PMC collection needs the profiler): `traffic_source` says so.
+PMC_TRAFFIC_BYTES_2POW20 = (1015901 + 101189) * 1024
 PMC_TRAFFIC_SOURCE = ("not measured in this run: FETCH_SIZE + WRITE_SIZE of msm_accumulate from separate rocprofv3 --pmc passes of the same "
-                      "command on the same code, profiles/r04_pmc_traffic.txt")
+                      "command on the same code, profiles/r05_pmc_traffic.txt")
 MSM_WINDOWS = 15                 # 17-bit signed windows over the 254-bit scalars: mixed additions per term
 # VALU yardsticks.  Hardware: v_mad_u64_u32 issues at 576.1 G wave-instructions/s chip-wide
 # (profiles/r01_ubench_int.txt, k_mad64: 4.27 cycles per wave-instruction per SIMD at 2.4 GHz) = 36.87 T lane-mads/s;

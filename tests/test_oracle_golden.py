@@ -150,7 +150,7 @@ def test_long_lc_chain_proves(golden_crs):
 
 def test_crosscheck_manifest_simple_case_is_the_reference_golden(golden_dir):
     """tools/make_crosscheck_bundle.py (run on an MI355X; its MANIFEST.json is committed as tools/crosscheck_MANIFEST.json) writes
-    six circuits' artefacts for a future comparison with a real `plonkit`.  Five of them are PARITY UNPINNED; the sixth, the
+    seven circuits' artefacts for a future comparison with a real `plonkit`.  Six of them are PARITY UNPINNED; the seventh, the
     reference's own `simple` circuit taken through circom's BINARY formats this time, must hash to the reference's committed
     files (src/tests.rs:31-73): key, verification key and proof."""
     import hashlib
@@ -159,7 +159,7 @@ def test_crosscheck_manifest_simple_case_is_the_reference_golden(golden_dir):
     m = json.load(open(os.path.join(os.path.dirname(root), "tools", "crosscheck_MANIFEST.json")))
     sha = lambda name: hashlib.sha256(open(os.path.join(golden_dir, name), "rb").read()).hexdigest()
     assert m["simple"]["vk.bin"] == sha("vk.bin") and m["simple"]["proof.bin"] == sha("proof.bin") and m["simple"]["setup.key"] == sha("setup_2pow10.key")
-    assert set(m) == {"simple", "poseidon_12", "poseidon_14", "poseidon_16", "long_lc", "dense_14"}
+    assert set(m) == {"simple", "poseidon_12", "poseidon_14", "poseidon_16", "long_lc", "dense_14", "zero_inputs"}
 
 
 def test_compiled_front_end_equals_the_python_one(golden_dir, golden_crs):
