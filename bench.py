@@ -411,7 +411,6 @@ def sharded_prove_scatter(ctx, dist, device, log_n, rank, world, proofs=3):
                 assert p == proof
             vk = setup.verification_key_bytes(pa.crs42_g2_bytes())
             verified = bool(pa.verify(vk, proof))
-            ctx.comm_stop_workers()
             setup.close(); circ.close()
             res = {"wall_s": round(sorted(times)[len(times) // 2], 4), "wall_s_min": round(min(times), 4), "domain": n, "n_gpus": world, "srs_points_per_gpu": local,
                    "verified": verified, "proof_sha256": __import__("hashlib").sha256(proof).hexdigest()[:16],
@@ -421,6 +420,11 @@ def sharded_prove_scatter(ctx, dist, device, log_n, rank, world, proofs=3):
             ctx.comm_serve()
     except Exception as exc:                                       # noqa: BLE001 — (a worker whose owner died returns from comm_serve with an error)
         err = exc
+    if rank == 0:                                                   # whatever happened to the owner: its workers wait without a deadline
+        try:
+            ctx.comm_stop_workers()
+        except Exception as exc:                                   # noqa: BLE001
+            err = err or exc
     ctx.comm_set_mode("replicate")
     good = all_ok(dist, device, err is None)
     if err is not None:

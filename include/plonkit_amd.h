@@ -190,6 +190,11 @@ int32_t plk_msm_g1_finish_sharded(plk_ctx *ctx, plk_g1_affine *out);
 int32_t plk_comm_open_tcp(int32_t rank, int32_t world, uint16_t port, void **comm_out);
 int32_t plk_comm_combine(void *comm, plk_g1_jacobian *sums, uint32_t count);
 void plk_comm_close(void *comm);
+/* test tier: the scatter step of owner-computes mode on HOST buffers over a plk_comm_open_tcp communicator (same header, shares and sequence
+ * numbers as the device path).  Rank 0 sends vecs[0..count) (n elements of 32 B; count = 0: the stop message); rank r > 0 blocks for the next
+ * message and receives count_out x len_out x 32 bytes, len_out = its share [r * slice, min((r + 1) * slice, n)).                        */
+int32_t plk_comm_scatter_host(void *comm, const void *const *vecs, uint32_t count, uint64_t n, uint64_t slice,
+                              void *mine, uint64_t mine_cap, uint32_t *count_out, uint64_t *len_out);
 int32_t plk_comm_info(const plk_ctx *ctx, int32_t *rank, int32_t *world, uint64_t *exchanges);
 
 /* ---- Lagrange-form key: Crs<E, CrsForLagrangeForm> (L_i(tau)*G, i < N), the optional `-l` key of `plonkit prove`

@@ -142,6 +142,8 @@ struct Comm {
     bool scatter = false;                    // owner-computes mode (PLK_SHARD_MODE=scatter / plk_comm_set_mode): see comm.h
     DevBuf d_hdr, d_work;                    // scatter mode: the 64-byte header, a worker's received slices
     hipEvent_t ev = nullptr;                 // orders the exchange stream against the producer / consumer stream of the scalars
+    void *h_hdr = nullptr;                   // page-locked home of the batch header, apart from h_pin: the owner's header copy is asynchronous and may still be
+                                             // pending (its stream waits for the prover's) when the batch's gather stages its partial sums in h_pin
     std::vector<char> h_stage;               // TCP transport of the slices (test tier)
     uint64_t seq = 0;                        // batches sent / received (both sides count: a header out of step is a protocol error)
     bool dead = false;                       // the watchdog aborted the communicator: every later exchange fails at once
@@ -247,12 +249,13 @@ static int32_t builtin_combine(void *user, plk_g1_jacobian *sums, uint32_t count
 
 static void comm_free(Comm *C) {
     if (!C) return;
-    if (C->leak) { C->stream = nullptr; C->d_send.p = nullptr; C->d_recv.p = nullptr; C->d_hdr.p = nullptr; C->d_work.p = nullptr; C->nccl = nullptr; C->h_pin = nullptr; }      // see watch_exchange
+    if (C->leak) { C->stream = nullptr; C->d_send.p = nullptr; C->d_recv.p = nullptr; C->d_hdr.p = nullptr; C->d_work.p = nullptr; C->nccl = nullptr; C->h_pin = nullptr; C->h_hdr = nullptr; }      // see watch_exchange
     if (C->nccl) { Rccl *R = rccl(); if (R) (void)R->CommDestroy(C->nccl); }
     if (C->stream) (void)hipStreamDestroy(C->stream);
     C->d_send.release(); C->d_recv.release(); C->d_hdr.release(); C->d_work.release();
     if (C->ev) (void)hipEventDestroy(C->ev);
     if (C->h_pin) (void)hipHostFree(C->h_pin);
+    if (C->h_hdr) (void)hipHostFree(C->h_hdr);
     for (int fd : C->fds) if (fd >= 0) ::close(fd);
     if (C->listen_fd >= 0) ::close(C->listen_fd);
     delete C;
@@ -281,12 +284,7 @@ static int32_t scatter_ready(Comm *C) {
     PLK_HIP(hipSetDevice(C->ctx->device));
     PLK_TRY(C->d_hdr.reserve(sizeof(ShardHeader)));
     if (!C->ev) PLK_HIP(hipEventCreateWithFlags(&C->ev, hipEventDisableTiming));
-    if (C->h_pin_cap < 2 * sizeof(ShardHeader)) {
-        if (C->h_pin) (void)hipHostFree(C->h_pin);
-        C->h_pin = nullptr; C->h_pin_cap = 0;
-        PLK_HIP(hipHostMalloc(&C->h_pin, (size_t)8 * sizeof(plk_g1_jacobian) * ((size_t)C->world + 1), hipHostMallocDefault));
-        C->h_pin_cap = (size_t)8 * sizeof(plk_g1_jacobian) * ((size_t)C->world + 1);
-    }
+    if (!C->h_hdr) PLK_HIP(hipHostMalloc(&C->h_hdr, 2 * sizeof(ShardHeader), hipHostMallocDefault));
     return PLK_OK;
 }
 
@@ -297,8 +295,8 @@ static int32_t send_header(Comm *C, const ShardHeader &h) {
         return PLK_OK;
     }
     Rccl *R = rccl();
-    memcpy(C->h_pin, &h, sizeof h);
-    PLK_HIP(hipMemcpyAsync(C->d_hdr.p, C->h_pin, sizeof h, hipMemcpyHostToDevice, C->stream));
+    memcpy(C->h_hdr, &h, sizeof h);
+    PLK_HIP(hipMemcpyAsync(C->d_hdr.p, C->h_hdr, sizeof h, hipMemcpyHostToDevice, C->stream));
     ncclResult_t e = R->Broadcast(C->d_hdr.p, C->d_hdr.p, sizeof h, ncclUint8, 0, C->nccl, C->stream);
     if (e != ncclSuccess) return rccl_fail(e, "ncclBroadcast (batch header)");
     return PLK_OK;
@@ -315,9 +313,9 @@ static int32_t recv_header(Comm *C, ShardHeader *h) {
     Rccl *R = rccl();
     ncclResult_t e = R->Broadcast(C->d_hdr.p, C->d_hdr.p, sizeof *h, ncclUint8, 0, C->nccl, C->stream);
     if (e != ncclSuccess) return rccl_fail(e, "ncclBroadcast (batch header)");
-    PLK_HIP(hipMemcpyAsync(C->h_pin, C->d_hdr.p, sizeof *h, hipMemcpyDeviceToHost, C->stream));
+    PLK_HIP(hipMemcpyAsync(C->h_hdr, C->d_hdr.p, sizeof *h, hipMemcpyDeviceToHost, C->stream));
     PLK_TRY(watch_exchange(C, C->stream, true));
-    memcpy(h, C->h_pin, sizeof *h);
+    memcpy(h, C->h_hdr, sizeof *h);
     return PLK_OK;
 }
 static uint64_t share_of(uint64_t n, uint64_t slice, int rank) {
@@ -495,6 +493,40 @@ int32_t plk_comm_open_tcp(int32_t rank, int32_t world, uint16_t port, void **out
 }
 
 void plk_comm_close(void *comm) { comm_free(static_cast<Comm *>(comm)); }
+
+// the scatter step of owner-computes mode on HOST buffers over a TCP communicator (plk_comm_open_tcp): same header, same shares, same
+// sequence numbers as comm_send_work / comm_recv_work, without the device copies — what the CPU tests drive (tests/test_sharded_gloo.py).
+// rank 0: vecs[0..count) of n elements (32 B each) -> every rank r > 0 receives [r * slice, min((r + 1) * slice, n)) of each; count = 0 sends
+// the stop message.  rank > 0: blocks for the next message; *count_out = 0 means stop, else count_out x len_out x 32 bytes are in `mine`.
+int32_t plk_comm_scatter_host(void *comm, const void *const *vecs, uint32_t count, uint64_t n, uint64_t slice,
+                              void *mine, uint64_t mine_cap, uint32_t *count_out, uint64_t *len_out) {
+    Comm *C = static_cast<Comm *>(comm);
+    if (!C || !C->tcp || count > 8) { set_error("plk_comm_scatter_host: needs a TCP communicator (plk_comm_open_tcp) and at most 8 vectors"); return PLK_ERR_ARG; }
+    if (C->rank == 0) {
+        if (count && (!vecs || slice == 0)) { set_error("plk_comm_scatter_host: bad argument"); return PLK_ERR_ARG; }
+        ShardHeader h{};
+        h.magic = SHARD_MAGIC; h.op = count ? SHARD_COMMIT : SHARD_STOP; h.count = count; h.n = n; h.slice = slice; h.seq = ++C->seq;
+        PLK_TRY(send_header(C, h));
+        for (int r = 1; r < C->world && count; r++) {
+            const uint64_t len = share_of(n, slice, r);
+            for (uint32_t k = 0; k < count && len; k++)
+                if (!send_all(C->fds[r], static_cast<const char *>(vecs[k]) + (size_t)r * slice * 32, (size_t)len * 32)) { set_error("tcp scatter: a rank went away"); return PLK_ERR_IO; }
+        }
+        if (count_out) *count_out = count;
+        if (len_out) *len_out = share_of(n, slice, 0);
+        return PLK_OK;
+    }
+    if (!count_out || !len_out) { set_error("plk_comm_scatter_host: bad argument"); return PLK_ERR_ARG; }
+    ShardHeader h{};
+    PLK_TRY(recv_header(C, &h));
+    if (h.magic != SHARD_MAGIC || (h.op != SHARD_COMMIT && h.op != SHARD_STOP) || h.seq != ++C->seq) { set_error("scatter: batch header out of step"); return PLK_ERR_IO; }
+    *count_out = h.op == SHARD_STOP ? 0 : h.count;
+    *len_out = h.op == SHARD_STOP ? 0 : share_of(h.n, h.slice, C->rank);
+    if ((uint64_t)*count_out * *len_out * 32 > mine_cap || (*count_out && *len_out && !mine)) { set_error("plk_comm_scatter_host: receive buffer too small"); return PLK_ERR_ARG; }
+    for (uint32_t k = 0; k < *count_out && *len_out; k++)
+        if (!recv_all(C->fds[0], static_cast<char *>(mine) + (size_t)k * *len_out * 32, (size_t)*len_out * 32)) { set_error("tcp scatter: the owner went away"); return PLK_ERR_IO; }
+    return PLK_OK;
+}
 
 int32_t plk_comm_combine(void *comm, plk_g1_jacobian *sums, uint32_t count) {
     if (!comm || !sums) { set_error("plk_comm_combine: bad argument"); return PLK_ERR_ARG; }

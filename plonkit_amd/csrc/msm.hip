@@ -37,6 +37,7 @@
 // everything else (recoding, partition, bucket reduction, drivers, the FIFO of three slots, plk_ctx_share_srs) is here.
 #include "msm_shape.h"
 #include "msm.h"
+#include "comm.h"
 #include "hostmath.h"
 #include <cstring>
 #include <cstdlib>
@@ -965,9 +966,17 @@ int32_t plk_msm_g1_finish_batch(plk_ctx *ctx, plk_g1_jacobian *out, uint32_t cou
     for (uint32_t k = 0; k < count; k++) { memcpy(out[k].x, j[k].x.l, 32); memcpy(out[k].y, j[k].y.l, 32); memcpy(out[k].z, j[k].z.l, 32); }
     return PLK_OK;
 }
+// The commitment-level sharded entry points assume that EVERY rank calls them with its slice of the scalars (replicate mode).  In owner-computes
+// mode the workers sit in plk_comm_serve waiting for a batch header, so an exchange started here would never be answered: refuse instead of hanging.
+static int32_t sharded_entry_is_replicate_only(plk_ctx *ctx, const char *who) {
+    if (!comm_scatter_owner(ctx) && !comm_scatter_worker(ctx)) return PLK_OK;
+    set_error(std::string(who) + ": the communicator is in owner-computes mode (PLK_SHARD_SCATTER) — commitment-level sharded calls need replicate mode");
+    return PLK_ERR_ARG;
+}
 // finish + the context's combiner (one exchange for the whole batch), affine results
 int32_t plk_msm_g1_finish_batch_sharded(plk_ctx *ctx, plk_g1_affine *out, uint32_t count) {
     if (!ctx || !out || count == 0 || count > MSM_MAX_BATCH) { set_error("plk_msm_g1_finish_batch_sharded: bad argument"); return PLK_ERR_ARG; }
+    PLK_TRY(sharded_entry_is_replicate_only(ctx, "plk_msm_g1_finish_batch_sharded"));
     plk_g1_jacobian j[MSM_MAX_BATCH];
     PLK_TRY(plk_msm_g1_finish_batch(ctx, j, count));
     if (ctx->combine) {
@@ -990,6 +999,7 @@ int32_t plk_msm_g1_finish(plk_ctx *ctx, plk_g1_jacobian *out) {
 // The exchange of commitment k runs while the kernels of commitment k + 1 (enqueued before this call) occupy the GPU.
 int32_t plk_msm_g1_finish_sharded(plk_ctx *ctx, plk_g1_affine *out) {
     if (!ctx || !out) { set_error("plk_msm_g1_finish_sharded: bad argument"); return PLK_ERR_ARG; }
+    PLK_TRY(sharded_entry_is_replicate_only(ctx, "plk_msm_g1_finish_sharded"));
     plk_g1_jacobian j;
     PLK_TRY(plk_msm_g1_finish(ctx, &j));
     if (ctx->combine) {

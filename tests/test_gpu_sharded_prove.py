@@ -332,11 +332,18 @@ def _scatter_rank(rank, world, port, log_n, lagrange, q):
     ctx.comm_init_tcp(rank, world, port, rank * local)
     ctx.comm_set_mode("scatter")
     if rank == 0:
-        circ = pa.Circuit.synthetic(n - 2)
-        setup = pa.SetupForProver(ctx, circ)
-        vk = setup.verification_key_bytes(pa.crs42_g2_bytes())
-        proofs = [setup.prove(circ) for _ in range(2)]
-        ctx.comm_stop_workers()
+        try:
+            circ = pa.Circuit.synthetic(n - 2)
+            setup = pa.SetupForProver(ctx, circ)
+            vk = setup.verification_key_bytes(pa.crs42_g2_bytes())
+            proofs = [setup.prove(circ) for _ in range(2)]
+            try:                                                    # commitment-level sharded calls are replicate-mode only: refused, not hung
+                ctx.msm_finish_sharded()
+                raise AssertionError("plk_msm_g1_finish_sharded must be refused in owner-computes mode")
+            except pa.PlkError as e:
+                assert "owner-computes" in str(e)
+        finally:
+            ctx.comm_stop_workers()                                 # (the workers wait without a deadline)
         q.put((0, vk, proofs, ctx.comm_info()[2]))
         setup.close(); circ.close()
     else:

@@ -166,3 +166,62 @@ def test_native_combiner_world2_world3_and_world8():
             p.join(timeout=60)
         assert [r[:2] for r in res] == [(r, True) for r in range(world)]
         assert len({r[2] for r in res}) == 1                      # every rank ends with the same bytes
+
+
+# ------------------------------------------------------------------ owner-computes mode: the scatter step on host buffers (comm.cpp)
+def _scatter_worker(rank, world, port, n, slice_, q):
+    """rank 0 scatters three batches (2 vectors of n elements, 1 vector, 8 short vectors that leave the last ranks empty-handed) and
+    stops; every other rank must receive exactly its share of every vector; a combine after every batch keeps the exchange in step"""
+    import ctypes
+    import plonkit_amd as pa
+    L = pa.lib()
+    comm = ctypes.c_void_p()
+    assert L.plk_comm_open_tcp(ctypes.c_int32(rank), ctypes.c_int32(world), ctypes.c_uint16(port), ctypes.byref(comm)) == 0, pa.last_error()
+    try:
+        rng = np.random.default_rng(2025)                          # the same data on every rank: workers know what to expect
+        batches = [(2, n), (1, n), (8, slice_ + slice_ // 2)]
+        ok = True
+        for count, length in batches:
+            vecs = [rng.integers(0, 1 << 63, size=(length, 4), dtype=np.uint64) for _ in range(count)]
+            cnt, ln = ctypes.c_uint32(0), ctypes.c_uint64(0)
+            if rank == 0:
+                arr = (ctypes.c_void_p * count)(*[v.ctypes.data for v in vecs])
+                assert L.plk_comm_scatter_host(comm, arr, ctypes.c_uint32(count), ctypes.c_uint64(length), ctypes.c_uint64(slice_), None, ctypes.c_uint64(0),
+                                               ctypes.byref(cnt), ctypes.byref(ln)) == 0, pa.last_error()
+            else:
+                mine = np.zeros((8 * slice_, 4), dtype=np.uint64)
+                assert L.plk_comm_scatter_host(comm, None, ctypes.c_uint32(0), ctypes.c_uint64(0), ctypes.c_uint64(0), mine.ctypes.data_as(ctypes.c_void_p),
+                                               ctypes.c_uint64(mine.nbytes), ctypes.byref(cnt), ctypes.byref(ln)) == 0, pa.last_error()
+                lo = min(rank * slice_, length); hi = min((rank + 1) * slice_, length)
+                ok &= cnt.value == count and ln.value == hi - lo
+                for k in range(count):
+                    ok &= bool(np.array_equal(mine[k * (hi - lo):(k + 1) * (hi - lo)], vecs[k][lo:hi]))
+            sums = np.zeros((1, 12), dtype=np.uint64)               # (infinity from everyone: only the framing matters here)
+            assert L.plk_comm_combine(comm, sums.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(1)) == 0, pa.last_error()
+        cnt, ln = ctypes.c_uint32(9), ctypes.c_uint64(9)
+        if rank == 0:
+            assert L.plk_comm_scatter_host(comm, None, ctypes.c_uint32(0), ctypes.c_uint64(0), ctypes.c_uint64(0), None, ctypes.c_uint64(0), None, None) == 0
+        else:
+            assert L.plk_comm_scatter_host(comm, None, ctypes.c_uint32(0), ctypes.c_uint64(0), ctypes.c_uint64(0), None, ctypes.c_uint64(0),
+                                           ctypes.byref(cnt), ctypes.byref(ln)) == 0, pa.last_error()
+            ok &= cnt.value == 0 and ln.value == 0                  # the stop message
+        q.put((rank, bool(ok)))
+    finally:
+        L.plk_comm_close(comm)
+
+
+def test_scatter_step_world2_world3_and_world8():
+    """PLK_SHARD_SCATTER's transport without a GPU: header, shares (incl. ragged and empty ones), sequence numbers, stop"""
+    for world in (2, 3, 8):
+        port = _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        n = 1 << 10
+        slice_ = (n + world - 1) // world                          # world 3: the last share is shorter
+        procs = [ctx.Process(target=_scatter_worker, args=(r, world, port, n, slice_, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=240) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+        assert res == [(r, True) for r in range(world)]
