@@ -36,6 +36,30 @@ def test_ntt_matches_oracle(ctx, log_n):
     assert np.array_equal(ctx.ntt(a, log_n, inverse=True), ol.ntt(a, log_n, inverse=True))
 
 
+@pytest.mark.parametrize("log_n", [11, 13, 14, 15, 16, 18, 20])
+def test_ntt_extreme_residues(ctx, log_n):
+    """the lazy bounds of the butterflies at their worst inputs (random vectors of `_rand_fr` stay below 2^252): every element r - 1, r - 1
+    alternating with 0 at stride 1 and at the stride of the first pass, residues within 2^16 of r, and all zeros — plain, inverse and
+    coset transforms against the oracle.  The sizes cover every pass shape: the old kernels (2^11, 6-bit passes of 2^13) and the wave-owned
+    ones at 7 + 7, 8 + 7, 8 + 8, 9 + 9 and 10 + 10 bits."""
+    n = 1 << log_n
+    top = np.array(ol.int_to_limbs(R_MOD - 1), dtype=np.uint64)
+    cases = [np.tile(top, (n, 1))]
+    alt = np.zeros((n, 4), dtype=np.uint64); alt[::2] = top
+    cases.append(alt)
+    blk = np.zeros((n, 4), dtype=np.uint64); blk[(np.arange(n) >> (log_n // 2)) & 1 == 1] = top
+    cases.append(blk)
+    rng = np.random.default_rng(log_n)
+    near = ol.ints_to_array([R_MOD - 1 - int(x) for x in rng.integers(0, 1 << 16, size=min(n, 1 << 12))])
+    cases.append(np.tile(near, (n // near.shape[0], 1)))
+    cases.append(np.zeros((n, 4), dtype=np.uint64))
+    for a in cases:
+        a = np.ascontiguousarray(a)
+        assert np.array_equal(ctx.ntt(a, log_n), ol.ntt(a, log_n))
+        assert np.array_equal(ctx.ntt(a, log_n, inverse=True), ol.ntt(a, log_n, inverse=True))
+        assert np.array_equal(ctx.ntt(a, log_n, coset=ol.fr_mont(7)), ol.ntt(a, log_n, coset=7))
+
+
 @pytest.mark.parametrize("log_n", [3, 9, 12, 15, 17])
 def test_coset_ntt_and_roundtrip(ctx, log_n):
     a = _rand_fr(1 << log_n, 7 + log_n)
