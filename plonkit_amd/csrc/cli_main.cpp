@@ -65,6 +65,7 @@ template <class F> static void worker_guard(Fatal *err, F &&body) {
     t_in_worker = false;
 }
 static void rethrow_on_main(const Fatal &err) { if (err.code) fatal(err.code, err.msg); }
+struct JoinOnExit { std::thread &t; ~JoinOnExit() { if (t.joinable()) t.join(); } };      // a thread object must not die joinable, whatever unwinds past it
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static double g_t0 = 0;
 // PLK_CLI_TIMING=1: phase times on stderr (whole-CLI measurement of DESIGN.md §4)
@@ -246,15 +247,21 @@ static int serve_owner(plk_ctx *ctx) {
     fprintf(stderr, "served %llu batches of commitments\n", (unsigned long long)batches);
     return 0;
 }
-// uploads the key; with several ranks only this rank's slice [rank * N/world, (rank + 1) * N/world) of its first N points
-static void load_key(plk_ctx *ctx, const std::string &path, uint8_t g2[256], bool lagrange = false, const Ranks &rk = Ranks(), uint64_t N = 0) {
+// a key file read and checked on the host (Crs::read: every point on the curve): no GPU needed, so the single-process commands do it on a
+// thread of its own WHILE the HIP runtime initialises (0.06 s of the 0.24 s the GPU side of `prove` used to take at the 2^20 domain)
+struct ParsedKey { std::vector<plk_g1_affine> pts; uint64_t n = 0; uint8_t g2[256]; };
+static void parse_key(const std::string &path, bool lagrange, ParsedKey *k) {
     const char *what = lagrange ? "read key_lagrange_form err" : "read key_monomial_form err";
     std::vector<uint8_t> raw = slurp(path, what);
-    uint64_t n = 0;
-    CK(what, plk_key_parse(raw.data(), raw.size(), nullptr, 0, &n, g2));
-    std::vector<plk_g1_affine> pts(n);
-    CK(what, plk_key_parse(raw.data(), raw.size(), pts.data(), n, &n, g2));
-    const plk_g1_affine *first = pts.data();
+    CK(what, plk_key_parse(raw.data(), raw.size(), nullptr, 0, &k->n, k->g2));
+    k->pts.resize(k->n);
+    CK(what, plk_key_parse(raw.data(), raw.size(), k->pts.data(), k->n, &k->n, k->g2));
+}
+// uploads the key; with several ranks only this rank's slice [rank * N/world, (rank + 1) * N/world) of its first N points
+static void upload_key(plk_ctx *ctx, const ParsedKey &k, bool lagrange, const Ranks &rk = Ranks(), uint64_t N = 0) {
+    const char *what = lagrange ? "read key_lagrange_form err" : "read key_monomial_form err";
+    const plk_g1_affine *first = k.pts.data();
+    uint64_t n = k.n;
     if (rk.world > 1) {
         if (n < N) fatal(101, std::string(what) + ": key has " + std::to_string(n) + " points, the domain needs " + std::to_string(N));
         first += (uint64_t)rk.rank * (N / rk.world);
@@ -262,6 +269,12 @@ static void load_key(plk_ctx *ctx, const std::string &path, uint8_t g2[256], boo
     }
     if (lagrange) CK("srs upload", plk_srs_lagrange_upload(ctx, first, n));
     else CK("srs upload", plk_srs_upload(ctx, first, n));
+}
+static void load_key(plk_ctx *ctx, const std::string &path, uint8_t g2[256], bool lagrange = false, const Ranks &rk = Ranks(), uint64_t N = 0) {
+    ParsedKey k;
+    parse_key(path, lagrange, &k);
+    memcpy(g2, k.g2, 256);
+    upload_key(ctx, k, lagrange, rk, N);
 }
 
 static int run(int argc, char **argv) {
@@ -328,8 +341,15 @@ static int run(int argc, char **argv) {
             plk_ctx *gpu_ctx = nullptr;
             std::thread gpu([&gpu_err, &gpu_ctx, &g2, rk, key_path] {
                 worker_guard(&gpu_err, [&] {
+                    ParsedKey key;                                      // read + checked beside the HIP initialisation
+                    Fatal key_err{0, ""};
+                    std::thread reader([&] { worker_guard(&key_err, [&] { parse_key(key_path, false, &key); }); });
+                    JoinOnExit reader_guard{reader};
                     gpu_ctx = open_ctx(rk);
-                    load_key(gpu_ctx, key_path, g2);
+                    reader.join();
+                    if (key_err.code) fatal(key_err.code, key_err.msg);
+                    memcpy(g2, key.g2, 256);
+                    upload_key(gpu_ctx, key, false);
                     CK("srs precompute", plk_srs_precompute(gpu_ctx));
                 });
             });
@@ -385,11 +405,18 @@ static int run(int argc, char **argv) {
                     const bool tm = getenv("PLK_CLI_TIMING") != nullptr;
                     double t0 = now_s(), t1;
                     auto lap = [&](const char *what) { if (tm) { t1 = now_s(); fprintf(stderr, "[timing]   gpu thread: %-24s +%.3f s\n", what, t1 - t0); t0 = t1; } };
+                    ParsedKey key, lkey;                                // read + checked beside the HIP initialisation
+                    Fatal key_err{0, ""};
+                    std::thread reader([&] { worker_guard(&key_err, [&] { parse_key(key_path, false, &key); if (!lag.empty()) parse_key(lag, true, &lkey); }); });
+                    JoinOnExit reader_guard{reader};
                     gpu_ctx = open_ctx(rk);
                     lap("plk_create (HIP init)");
-                    load_key(gpu_ctx, key_path, g2);
-                    if (!lag.empty()) { uint8_t g2l[256]; load_key(gpu_ctx, lag, g2l, true); }
-                    lap("key read + parse + upload");
+                    reader.join();
+                    if (key_err.code) fatal(key_err.code, key_err.msg);
+                    memcpy(g2, key.g2, 256);
+                    upload_key(gpu_ctx, key, false);
+                    if (!lag.empty()) upload_key(gpu_ctx, lkey, true);
+                    lap("key upload (read + parse ran beside HIP init)");
                     CK("srs precompute", plk_srs_precompute(gpu_ctx));
                     lap("MSM table");
                 });
