@@ -76,16 +76,44 @@ LOOP_ISOLATED_GMADD = 16.3
 
 
 FAILED_LEGS = []                 # (leg, repr(exception), is_correctness) of every secondary leg that raised: the line keeps going, the exit status does not lie
+CURRENT_LEG = [None]             # what the leg watchdog names when it fires
 
 
 def leg(name, fn):
     """run a secondary leg of the line: an exception becomes {"error": ...} in its place AND an entry of the top-level `failed_legs`;
     an AssertionError / a failed byte-identity or verification check also makes the process exit non-zero after the line is printed"""
+    CURRENT_LEG[0] = name
     try:
+        if os.environ.get("PLK_BENCH_TEST_STALL_LEG") == name:     # TEST HOOK (tests/test_gpu_sharded_prove.py): this leg never returns
+            time.sleep(3600)
         return fn()
     except Exception as exc:                                       # noqa: BLE001
         FAILED_LEGS.append((name, repr(exc), isinstance(exc, AssertionError) or "differs" in repr(exc) or "mismatch" in repr(exc)))
         return {"error": repr(exc)}
+
+
+def start_leg_watchdog(rank, line_box):
+    """N > 1 only.  The legs after the headline hold collectives of RCCL and of the library's own communicator; a rank parked in one
+    that its peers never enter (a host-blocking ncclGroupEnd, a leg that desynchronised) would hang the whole launch and cost the
+    headline line already measured.  After PLK_BENCH_LEG_TIMEOUT_S (default 420; the legs take about a minute on 8 GPUs) rank 0
+    prints the line with what it has — the stuck leg named in `failed_legs` — and the process exits with status 3; the launcher
+    then ends the other ranks (they fire 20 s later on their own if it does not)."""
+    import threading
+    limit = float(os.environ.get("PLK_BENCH_LEG_TIMEOUT_S", "420"))
+
+    def fire():
+        line = line_box[0]
+        if rank == 0 and line is not None:
+            line["failed_legs"] = [{"leg": a, "error": b, "correctness": c} for a, b, c in FAILED_LEGS] + [
+                {"leg": CURRENT_LEG[0], "error": "did not return within %g s (PLK_BENCH_LEG_TIMEOUT_S): the line is printed by the watchdog, "
+                                                 "the legs after it never ran" % limit, "correctness": False}]
+            print(json.dumps(line, ensure_ascii=False), flush=True)
+        os._exit(3)
+
+    t = threading.Timer(limit + (0 if rank == 0 else 20), fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def all_ok(dist, device, ok):
@@ -397,6 +425,8 @@ def sharded_prove_scatter(ctx, dist, device, log_n, rank, world, proofs=3):
     ctx.srs_generate(local, rank * local, 42)
     ctx.comm_set_shard(rank * local)
     ctx.comm_set_mode("scatter")
+    # a batch job: an owner that fails without reaching comm_stop_workers must not leave its workers waiting for ever
+    os.environ.setdefault("PLK_COMM_IDLE_TIMEOUT_MS", "90000")
     res, err = None, None
     try:
         if rank == 0:
@@ -823,25 +853,32 @@ def main():
             if isinstance(line["prove"].get("dense"), dict) and line["prove"]["dense"].get("verified") is False:
                 FAILED_LEGS.append(("prove.dense", "the host verifier rejects the dense proof", True))
             line["kernels"] = leg("kernels", lambda: prover_bench.kernel_table(ctx, device))
+    watchdog = None
     if world > 1 or force_dist:
+        watchdog = start_leg_watchdog(rank, [line])
         # (a) strong scaling of ONE 2^24-term commitment (configs[2]); (b) multi-GPU prove at the 2^log_n domain: the SRS
         # sliced across the ranks, commitments combined over RCCL, NTTs replicated.  Every rank takes part;
         # a failure here must not cost the headline line.
+        # (rank 0 files every leg as soon as it returns: the watchdog prints what is there)
         strong = leg("strong", lambda: strong_scaling_msm(ctx, dist, device, rank, world, log_total=args.strong_log_n))
-        sharded = leg("prove(sharded)", lambda: sharded_prove(ctx, dist, device, args.log_n, rank, world))
-        scattered = leg("prove(scatter)", lambda: sharded_prove_scatter(ctx, dist, device, args.log_n, rank, world))
-        replicas = leg("prove_throughput", lambda: replica_prove_throughput(dist, device, args.log_n, rank, world))
         if rank == 0:
             line["strong"] = strong
-            line["prove"] = sharded
-            if isinstance(line["prove"], dict):
-                line["prove"]["scatter"] = scattered
-            line["prove_throughput"] = replicas
             # the figure north_star's ">= 6x MSM scaling 1 -> 8 GPUs" reads, where a reader will look for it: `value` above is
             # WEAK scaling (2^log_n terms per GPU), these two are STRONG scaling of one fixed 2^strong_log_n-term commitment
             line["strong_value"] = strong.get("Mscalar_mul_s")
             line["strong_unit"] = "Mscalar·mul/s (one 2^%d-term commitment, SRS split over %d GPUs)" % (args.strong_log_n, world)
             line["strong_scaling_vs_1gpu"] = strong.get("scaling_vs_1gpu")
+        sharded = leg("prove(sharded)", lambda: sharded_prove(ctx, dist, device, args.log_n, rank, world))
+        if rank == 0:
+            line["prove"] = sharded
+        scattered = leg("prove(scatter)", lambda: sharded_prove_scatter(ctx, dist, device, args.log_n, rank, world))
+        if rank == 0 and isinstance(line["prove"], dict):
+            line["prove"]["scatter"] = scattered
+        replicas = leg("prove_throughput", lambda: replica_prove_throughput(dist, device, args.log_n, rank, world))
+        if rank == 0:
+            line["prove_throughput"] = replicas
+    if watchdog:
+        watchdog.cancel()
     if rank == 0:
         line["failed_legs"] = [{"leg": a, "error": b, "correctness": c} for a, b, c in FAILED_LEGS]
         print(json.dumps(line, ensure_ascii=False), flush=True)

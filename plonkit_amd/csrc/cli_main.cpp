@@ -242,6 +242,9 @@ static void join_ranks(plk_ctx *ctx, const Ranks &rk, uint64_t N) {
 // commitments from their slice of the key and never touch the witness
 static bool scatter_mode(const Ranks &rk) { const char *e = getenv("PLK_SHARD_MODE"); return rk.world > 1 && e && !strcmp(e, "scatter"); }
 static int serve_owner(plk_ctx *ctx) {
+    // one command, one job: an owner that exits on an error never sends the stop batch, and its workers must not outlive it for ever
+    // (the reference's process simply ends when a step panics).  Ten minutes between two batches is far beyond any step of a 2^26 proof.
+    setenv("PLK_COMM_IDLE_TIMEOUT_MS", "600000", 0);
     uint64_t batches = 0;
     CK("serve (owner-computes mode)", plk_comm_serve(ctx, &batches));
     fprintf(stderr, "served %llu batches of commitments\n", (unsigned long long)batches);

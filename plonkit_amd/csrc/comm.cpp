@@ -91,6 +91,15 @@ long comm_timeout_ms() {
     if (e && *e) { char *end = nullptr; long v = strtol(e, &end, 10); if (end != e && v > 0) return v; }      // (0 or junk: the default —
     return COMM_TIMEOUT_S * 1000L;                                       //  a zero deadline would fail every exchange on its first poll)
 }
+// PLK_COMM_IDLE_TIMEOUT_MS (default 0 = none): how long a worker of owner-computes mode waits for the owner's NEXT batch.  Waiting for
+// work is not a fault — the owner may be between two proofs for hours — so there is no deadline unless the embedder sets one; a batch
+// job (bench.py, the CLI under a launcher) sets it so that an owner that failed without reaching plk_comm_stop_workers cannot leave
+// its workers parked in ncclBroadcast for ever (an aborted peer is NOT reported by ncclCommGetAsyncError inside one node).
+long comm_idle_timeout_ms() {
+    const char *e = getenv("PLK_COMM_IDLE_TIMEOUT_MS");
+    if (e && *e) { char *end = nullptr; long v = strtol(e, &end, 10); if (end != e && v > 0) return v; }
+    return 0;
+}
 // TEST HOOK (tests/test_gpu_sharded_prove.py): PLK_COMM_TEST_STALL_MS=<ms> parks the exchange stream for that long before
 // every all-gather — a peer that does not answer —, so that the watchdog's abort path MUST run when the deadline is shorter
 long comm_test_stall_ms() {
@@ -159,8 +168,11 @@ static int32_t watch_exchange(Comm *C, hipStream_t st, bool no_deadline = false)
     Rccl *R = rccl();
     const auto t0 = clk::now();
     // (no_deadline: a worker waiting for the owner's next batch — the owner may be inside its transforms, or between two proofs, for
-    //  any length of time; a peer that DIED still ends the wait through ncclCommGetAsyncError)
-    const auto deadline = no_deadline ? clk::time_point::max() : t0 + std::chrono::milliseconds(comm_timeout_ms());
+    //  any length of time: only PLK_COMM_IDLE_TIMEOUT_MS, if set, bounds it; a peer PROCESS that died may end the wait through
+    //  ncclCommGetAsyncError)
+    const long idle_ms = no_deadline ? comm_idle_timeout_ms() : 0;
+    const auto deadline = !no_deadline ? t0 + std::chrono::milliseconds(comm_timeout_ms())
+                                       : (idle_ms > 0 ? t0 + std::chrono::milliseconds(idle_ms) : clk::time_point::max());
     for (unsigned it = 0;; it++) {
         hipError_t q = hipStreamQuery(st);
         if (q == hipSuccess) return PLK_OK;
@@ -168,7 +180,8 @@ static int32_t watch_exchange(Comm *C, hipStream_t st, bool no_deadline = false)
         (void)hipGetLastError();
         const auto now = clk::now();
         bool failed = now >= deadline;
-        const char *why = "no answer from a peer before the deadline (PLK_COMM_TIMEOUT_MS)";
+        const char *why = no_deadline ? "no batch from the owner before the idle deadline (PLK_COMM_IDLE_TIMEOUT_MS)"
+                                      : "no answer from a peer before the deadline (PLK_COMM_TIMEOUT_MS)";
         if (!failed && (it & 1023) == 1023 && R->CommGetAsyncError) {
             ncclResult_t ae = ncclSuccess;
             if (R->CommGetAsyncError(C->nccl, &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress) { failed = true; why = "asynchronous RCCL error (a peer went away)"; }
@@ -303,7 +316,8 @@ static int32_t send_header(Comm *C, const ShardHeader &h) {
 }
 static int32_t recv_header(Comm *C, ShardHeader *h) {
     if (C->tcp) {
-        timeval none{0, 0};                                          // (waiting for work is not a fault: no receive timeout here)
+        const long idle_ms = comm_idle_timeout_ms();                 // (waiting for work is not a fault: no receive timeout unless one is set)
+        timeval none{idle_ms / 1000, (idle_ms % 1000) * 1000};
         ::setsockopt(C->fds[0], SOL_SOCKET, SO_RCVTIMEO, &none, sizeof none);
         const bool ok = recv_all(C->fds[0], h, sizeof *h);
         set_timeouts(C->fds[0]);

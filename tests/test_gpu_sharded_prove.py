@@ -220,6 +220,27 @@ def test_bench_n2_control_flow_on_one_gpu():
     assert "error" not in pt and pt["n_gpus"] == 2 and pt["in_flight_per_gpu"] == 2 and pt["proofs_per_s"] > 0
 
 
+def test_bench_leg_watchdog_prints_the_line_and_exits():
+    """a leg after the headline that never returns (here: every rank parked before the sharded prove) must not cost the line already
+    measured: after PLK_BENCH_LEG_TIMEOUT_S rank 0 prints it, the stuck leg named in `failed_legs`, and the launch ends non-zero"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PLK_BENCH_SHARE_DEVICE="1", PLK_BENCH_LEG_TIMEOUT_S="25", PLK_BENCH_TEST_STALL_LEG="prove(sharded)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--log-n", "14", "--strong-log-n", "16", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout + r.stderr)[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert "error" not in line["strong"] and line["strong_scaling_vs_1gpu"] > 0      # the leg before the stuck one is in the line
+    assert [f["leg"] for f in line["failed_legs"]] == ["prove(sharded)"] and "did not return" in line["failed_legs"][0]["error"]
+
+
 def _run_plain_bench(n_gpus, extra, timeout=900):
     """`python bench.py --gpus N ...` invoked PLAINLY (no launcher): bench.py must spawn its own N ranks"""
     import json

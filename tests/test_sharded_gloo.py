@@ -225,3 +225,43 @@ def test_scatter_step_world2_world3_and_world8():
         for p in procs:
             p.join(timeout=60)
         assert res == [(r, True) for r in range(world)]
+
+
+def _idle_worker(rank, world, port, q):
+    """the owner opens the communicator and then never sends a batch (it "failed" before plk_comm_stop_workers)"""
+    import ctypes
+    import time
+    import plonkit_amd as pa
+    if rank != 0:
+        os.environ["PLK_COMM_IDLE_TIMEOUT_MS"] = "400"
+    L = pa.lib()
+    comm = ctypes.c_void_p()
+    assert L.plk_comm_open_tcp(ctypes.c_int32(rank), ctypes.c_int32(world), ctypes.c_uint16(port), ctypes.byref(comm)) == 0, pa.last_error()
+    try:
+        if rank == 0:
+            time.sleep(3.0)                                        # alive, connected, silent
+            q.put((rank, 0, 0.0, ""))
+        else:
+            cnt, ln = ctypes.c_uint32(0), ctypes.c_uint64(0)
+            t0 = time.perf_counter()
+            rc = L.plk_comm_scatter_host(comm, None, ctypes.c_uint32(0), ctypes.c_uint64(0), ctypes.c_uint64(0), None, ctypes.c_uint64(0),
+                                         ctypes.byref(cnt), ctypes.byref(ln))
+            q.put((rank, rc, time.perf_counter() - t0, pa.last_error()))
+    finally:
+        L.plk_comm_close(comm)
+
+
+def test_worker_idle_deadline():
+    """PLK_COMM_IDLE_TIMEOUT_MS: a worker of owner-computes mode whose owner stays silent gives up with an error instead of waiting
+    for ever (unset, the wait has no deadline: waiting for work is not a fault)"""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_idle_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    rank, rc, waited, why = res[1]
+    assert rank == 1 and rc != 0 and 0.3 <= waited < 2.5 and "owner" in why, res
