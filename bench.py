@@ -77,6 +77,7 @@ LOOP_ISOLATED_GMADD = 16.3
 
 FAILED_LEGS = []                 # (leg, repr(exception), is_correctness) of every secondary leg that raised: the line keeps going, the exit status does not lie
 CURRENT_LEG = [None]             # what the leg watchdog names when it fires
+NATIVE_EXCHANGE = [True]         # False: the library's communicator could not be opened, partial sums travel through torch.distributed
 
 
 def leg(name, fn):
@@ -562,7 +563,7 @@ def strong_scaling_msm(ctx, dist, device, rank, world, log_total=24, reps=5):
     scal = rand_scalars(local, 0x24 + rank, device)
     torch.cuda.synchronize()
     ctx.srs_generate(local, rank * local, 42)
-    msm = ShardedMsm(ctx, dist, device, native=True)              # the communicator main() created
+    msm = ShardedMsm(ctx, dist, device if NATIVE_EXCHANGE[0] else red_device(device), native=NATIVE_EXCHANGE[0])   # the communicator main() created (or torch.distributed: see main)
     stream = torch.cuda.Stream(device=device)
     for _ in msm.commit_stream((scal for _ in range(2)), local, stream=stream):
         pass
@@ -703,25 +704,46 @@ def main():
     torch.cuda.synchronize()                             # the scalars are consumed on another stream
     stream = torch.cuda.Stream(device=device)
     multi = world > 1 or force_dist
+    native_exchange = True
     if multi:
         # the exchange of the partial sums runs inside the library (comm.cpp: ncclAllGather on the communicator's own stream + host
         # EC sum); torch.distributed only carries the 128-byte RCCL id to the other ranks and the timing barriers
-        if share:
-            # rank 0 picks a free port for the library's TCP hub and tells the others (MASTER_PORT + k may be taken or exceed 65535)
-            box = [None]
-            if rank == 0:
+        # Every rank runs every collective of this block whatever happens to it locally; if ANY rank cannot open the library's
+        # communicator (a librccl the loader cannot find, an RCCL that refuses the id), ALL ranks fall back to exchanging the partial
+        # sums through torch.distributed — the headline needs an all-gather of 96 bytes per rank, not a particular carrier of it.
+        err, box = None, [None]
+        try:
+            if os.environ.get("PLK_BENCH_TEST_NO_COMM"):           # TEST HOOK (tests/test_gpu_sharded_prove.py): the fallback must work
+                raise RuntimeError("PLK_BENCH_TEST_NO_COMM")
+            if rank == 0 and share:
+                # rank 0 picks a free port for the library's TCP hub and tells the others (MASTER_PORT + k may be taken or exceed 65535)
                 import socket
                 sk = socket.socket()
                 sk.bind(("127.0.0.1", 0))
-                box[0] = sk.getsockname()[1]
+                box = [sk.getsockname()[1]]
                 sk.close()
-            dist.broadcast_object_list(box, src=0)
-            ctx.comm_init_tcp(rank, world, int(box[0]), rank * n)
-        else:
-            box = [pa.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            ctx.comm_init(rank, world, box[0], rank * n)
-    msm = ShardedMsm(ctx, dist if multi else None, device, native=multi)
+            elif rank == 0:
+                box = [pa.comm_unique_id()]
+        except Exception as exc:                                   # noqa: BLE001
+            err = exc
+        dist.broadcast_object_list(box, src=0)
+        try:
+            if box[0] is None:
+                raise err or RuntimeError("rank 0 could not create the communicator's id")
+            if share:
+                ctx.comm_init_tcp(rank, world, int(box[0]), rank * n)
+            else:
+                ctx.comm_init(rank, world, box[0], rank * n)
+        except Exception as exc:                                   # noqa: BLE001
+            err = exc
+        if not all_ok(dist, device, err is None):
+            try:
+                ctx.comm_destroy()
+            except Exception:                                      # noqa: BLE001
+                pass
+            native_exchange = NATIVE_EXCHANGE[0] = False
+            FAILED_LEGS.append(("comm_init", repr(err) if err else "another rank could not open the library's communicator", False))
+    msm = ShardedMsm(ctx, dist if multi else None, device if native_exchange else red_device(device), native=multi and native_exchange)
     ctx.set_kernel_timing(True)
 
     # W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; the exchange of commitment k
@@ -783,6 +805,8 @@ def main():
             "config": {"workload": "Pippenger G1 MSM, 2^%d uniform scalars per GPU, tau=42 monomial SRS sharded by rank "
                                    "(BASELINE.json configs[1]: SRS 2^20, single MI355X at N=1)" % args.log_n,
                        "terms_per_gpu": n, "parallelism": "srs-shard x%d + all_gather of partial sums" % world,
+                       "exchange": ("none (one GPU)" if not multi else "ncclAllGather inside the library (plk_comm_init)" if native_exchange
+                                    else "torch.distributed all_gather (fallback: the library's communicator could not be opened, see failed_legs)"),
                        "pipeline_depth": args.pipeline_depth, "settle_steps": args.settle_steps,
                        "result_x_be": pa.g1_to_bytes(out).hex()[:64]},
             # `bound`: what limits the kernel is VALU issue (v_mad_u64_u32), not HBM and not MFMA (integer modular arithmetic) — said so here;

@@ -241,6 +241,29 @@ def test_bench_leg_watchdog_prints_the_line_and_exits():
     assert [f["leg"] for f in line["failed_legs"]] == ["prove(sharded)"] and "did not return" in line["failed_legs"][0]["error"]
 
 
+def test_bench_falls_back_to_torch_distributed_without_the_library_communicator():
+    """if the library's communicator cannot be opened on some rank, every rank exchanges the partial sums through torch.distributed
+    instead: the headline and the strong-scaling leg still come out, the legs that need the communicator say so in `failed_legs`"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PLK_BENCH_SHARE_DEVICE="1", PLK_BENCH_TEST_NO_COMM="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--log-n", "14", "--strong-log-n", "16", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "fallback" in line["config"]["exchange"]
+    assert "error" not in line["strong"] and line["strong_scaling_vs_1gpu"] > 0
+    failed = [f["leg"] for f in line["failed_legs"]]
+    assert failed[0] == "comm_init" and not any(f["correctness"] for f in line["failed_legs"])
+    assert "error" not in line["prove_throughput"] and line["prove_throughput"]["proofs_per_s"] > 0      # replicas need no communicator
+
+
 def _run_plain_bench(n_gpus, extra, timeout=900):
     """`python bench.py --gpus N ...` invoked PLAINLY (no launcher): bench.py must spawn its own N ranks"""
     import json
