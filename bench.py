@@ -734,6 +734,15 @@ def main():
                 ctx.comm_init_tcp(rank, world, int(box[0]), rank * n)
             else:
                 ctx.comm_init(rank, world, box[0], rank * n)
+            # one small commitment through the exchange before anything is timed, under a short deadline: a communicator that
+            # opens but whose first all-gather never completes is found here (45 s), not in the warm-up steps (180 s, fatal)
+            keep = os.environ.get("PLK_COMM_TIMEOUT_MS")
+            os.environ["PLK_COMM_TIMEOUT_MS"] = keep or "45000"
+            try:
+                ShardedMsm(ctx, None, device, native=True).commit(scalars, min(n, 4096))
+            finally:
+                if keep is None:
+                    del os.environ["PLK_COMM_TIMEOUT_MS"]
         except Exception as exc:                                   # noqa: BLE001
             err = exc
         if not all_ok(dist, device, err is None):
