@@ -3,7 +3,7 @@
 # one-in-flight commitment, interleaved.   usage (GPU box): tools/msm_rl_ab.sh <tag>
 out=gpurun_out/$1; mkdir -p $out
 for rep in 1 2 3; do
-  for rl in 0 6 5 4; do
+  for rl in 0 5 4; do
     echo "== rep $rep PLK_MSM_RL_LOG=$rl" >> $out/rl_ab.txt
     PLK_MSM_RL_LOG=$rl PROBE_VERIFY=1 timeout 120 python tools/prove_probe.py 20 15 2>&1 | tail -2 >> $out/rl_ab.txt
     PLK_MSM_RL_LOG=$rl timeout 120 python bench.py --msm-only --pipeline-depth 1 --steps 30 --warmup 5 2>/dev/null | python -c "
