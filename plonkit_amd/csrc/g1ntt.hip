@@ -5,7 +5,7 @@
 // Radix-2 DIT over group elements: a butterfly is (A, B) -> (A + w*B, A - w*B) where w*B is a full 254-bit scalar
 // multiplication, so the kernel is bound by v_mad_u64_u32 issue and HBM traffic (144 B per point per stage) is
 // negligible.  One lane per butterfly, XYZZ coordinates on the 9 x 29-bit layer between stages, a single Fermat
-// inversion per point at the end; 1/N is folded into the bit-reversing load pass.
+// inversion per point at the end; 1/N rides on the last stage (N/2 extra scalar multiplications, not N).
 //
 // Scalar multiplication on a SIMT machine: with double-and-add (or any sparse recoding) some lane of the wave has a
 // non-zero digit at nearly every bit, so the whole wave pays one addition per bit.  Fixed signed 3-bit windows make
@@ -90,9 +90,10 @@ __device__ __forceinline__ XyzzW g1_mul_scalar(const XyzzW &b, const Fr &k, uint
     return acc;
 }
 
-// pts[bitrev(i)] = n_inv * in[i]   (in: affine, external form; pts: XYZZ on the 29-bit layer)
-__global__ void __launch_bounds__(G1NTT_THREADS, 1) g1ntt_load(XyzzW *pts, const G1Affine *in, uint32_t log_n, Fr n_inv_canon) {
-    extern __shared__ uint32_t g1tab[];
+// pts[bitrev(i)] = in[i]   (in: affine, external form; pts: XYZZ on the 29-bit layer).  The factor 1/N is applied by the LAST stage
+// (g1ntt_stage, SCALE): there half of the points are multiplied by a twiddle anyway, which takes 1/N along for nothing, so the
+// scaling costs N/2 scalar multiplications instead of the N of a pass of its own (one stage's worth of the transform's 22).
+__global__ void __launch_bounds__(256) g1ntt_load(XyzzW *pts, const G1Affine *in, uint32_t log_n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (1u << log_n)) return;
     const G1Affine a = load_affine(in + i);
@@ -101,22 +102,28 @@ __global__ void __launch_bounds__(G1NTT_THREADS, 1) g1ntt_load(XyzzW *pts, const
         p.x = csub_p(w_from_s(unpack<FqW>(a.x))); p.y = csub_p(w_from_s(unpack<FqW>(a.y)));
         p.zz = w_one<FqW>(); p.zzz = w_one<FqW>();
     }
-    store_xyzzw(pts + brev32(i, log_n), g1_mul_scalar(p, n_inv_canon, g1tab));
+    store_xyzzw(pts + brev32(i, log_n), p);
 }
 
-// one DIT stage with half-size h = 2^s
-__global__ void __launch_bounds__(G1NTT_THREADS, 1) g1ntt_stage(XyzzW *pts, uint32_t log_n, uint32_t s, PowTable tw_inv) {
+// one DIT stage with half-size h = 2^s; SCALE (the last stage): both outputs times n_inv (Montgomery form) — (A n_inv) +- (w n_inv) B
+template <bool SCALE>
+__global__ void __launch_bounds__(G1NTT_THREADS, 1) g1ntt_stage(XyzzW *pts, uint32_t log_n, uint32_t s, PowTable tw_inv, Fr n_inv) {
     extern __shared__ uint32_t g1tab[];
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= (1u << (log_n - 1))) return;
     uint32_t h = 1u << s, jl = j & (h - 1);
     uint32_t i0 = ((j >> s) << (s + 1)) | jl, i1 = i0 + h;
     XyzzW a = load_xyzzw(pts + i0), b = load_xyzzw(pts + i1);
-    if (jl) {
-        // omega_N^-(jl * N / 2h)
-        uint32_t e = (jl << (log_n - s - 1)) << (MAX_LOG_N - log_n);
-        Fr w = mul(load_fp(tw_inv.lo + (e & (POW_TAB - 1))), load_fp(tw_inv.hi + (e >> POW_SPLIT)));
+    if (jl || SCALE) {
+        Fr w = n_inv;
+        if (jl) {
+            // omega_N^-(jl * N / 2h)
+            uint32_t e = (jl << (log_n - s - 1)) << (MAX_LOG_N - log_n);
+            w = mul(load_fp(tw_inv.lo + (e & (POW_TAB - 1))), load_fp(tw_inv.hi + (e >> POW_SPLIT)));
+            if (SCALE) w = mul(w, n_inv);
+        }
         b = g1_mul_scalar(b, to_canonical(w), g1tab);
+        if (SCALE) a = g1_mul_scalar(a, to_canonical(n_inv), g1tab);
     }
     XyzzW lo = a, nb = b;
     nb.y = sub6(w_zero<FqW>(), b.y);
@@ -149,16 +156,18 @@ int32_t g1_intt_dev(plk_ctx *ctx, const G1Affine *in, uint32_t log_n, G1Affine *
     if (ctx->msm_enq != ctx->msm_fin) { set_error("g1_intt: a commitment enqueued with plk_msm_g1_enqueue_dev is still in flight (call plk_msm_g1_finish first)"); return PLK_ERR_ARG; }
     PLK_TRY(ctx->slot[0].c.reserve((size_t)n * sizeof(XyzzW)));
     XyzzW *pts = ctx->slot[0].c.as<XyzzW>();
-    Fr n_inv = to_canonical(ctx->n_inv[log_n]);
+    const Fr n_inv = ctx->n_inv[log_n];                           // Montgomery form; 1 for log_n = 0 (no stage, nothing to scale)
     static std::atomic<bool> attr_set{false};
     if (!attr_set) {
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_load), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL(g1ntt_load, dim3((n + G1NTT_THREADS - 1) / G1NTT_THREADS), dim3(G1NTT_THREADS), G1NTT_LDS, st, pts, in, log_n, n_inv);
-    for (uint32_t s = 0; s < log_n; s++)
-        hipLaunchKernelGGL(g1ntt_stage, dim3((n / 2 + G1NTT_THREADS - 1) / G1NTT_THREADS), dim3(G1NTT_THREADS), G1NTT_LDS, st, pts, log_n, s, ctx->tw_inv);
+    hipLaunchKernelGGL(g1ntt_load, dim3((n + 255) / 256), dim3(256), 0, st, pts, in, log_n);
+    const dim3 sgrid((n / 2 + G1NTT_THREADS - 1) / G1NTT_THREADS);
+    for (uint32_t s = 0; s + 1 < log_n; s++)
+        hipLaunchKernelGGL(g1ntt_stage<false>, sgrid, dim3(G1NTT_THREADS), G1NTT_LDS, st, pts, log_n, s, ctx->tw_inv, n_inv);
+    if (log_n) hipLaunchKernelGGL(g1ntt_stage<true>, sgrid, dim3(G1NTT_THREADS), G1NTT_LDS, st, pts, log_n, log_n - 1, ctx->tw_inv, n_inv);
     hipLaunchKernelGGL(g1ntt_to_affine, dim3((n + 255) / 256), dim3(256), 0, st, out, (const XyzzW *)pts, n);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
