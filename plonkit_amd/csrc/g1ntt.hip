@@ -111,8 +111,15 @@ __global__ void __launch_bounds__(G1NTT_THREADS, 1) g1ntt_stage(XyzzW *pts, uint
     extern __shared__ uint32_t g1tab[];
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= (1u << (log_n - 1))) return;
-    uint32_t h = 1u << s, jl = j & (h - 1);
-    uint32_t i0 = ((j >> s) << (s + 1)) | jl, i1 = i0 + h;
+    // butterfly j of the stage: group jh, position jl inside the half (twiddle exponent).  jl = 0 needs no multiplication; in the early
+    // stages (h < 64) consecutive lanes would all differ in jl and every wave would pay for the one lane in h that has it.  There the
+    // position is the SLOW index of the launch: whole waves (workgroups) share jl, and those with jl = 0 — half of stage 1, a quarter of
+    // stage 2, .. — only add.  (The accesses become strided; memory traffic is nothing in this kernel.)
+    const uint32_t h = 1u << s;
+    uint32_t jl, jh;
+    if (s < 6 && log_n >= 8) { jl = j >> (log_n - 1 - s); jh = j & ((1u << (log_n - 1 - s)) - 1); }
+    else { jl = j & (h - 1); jh = j >> s; }
+    const uint32_t i0 = (jh << (s + 1)) | jl, i1 = i0 + h;
     XyzzW a = load_xyzzw(pts + i0), b = load_xyzzw(pts + i1);
     if (jl || SCALE) {
         Fr w = n_inv;
