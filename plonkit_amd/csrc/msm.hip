@@ -485,10 +485,16 @@ __device__ __forceinline__ uint32_t bucket_span(const uint32_t *meta, uint32_t b
     const uint32_t s0 = meta[b], e0 = meta[b + 1];
     return e0 > s0 ? (e0 - 1) / mu - s0 / mu : 0;
 }
+// The reduction kernels below are chains of dependent additions run by one or two waves per SIMD: they need few issue slots, but every slot
+// they wait for lengthens the tail of a commitment, which is on the critical path of a proof.  When they share a SIMD with throughput
+// kernels (the background transforms of the prover, the accumulation of another proof in flight) they ask the arbiter to go first.
+__device__ __forceinline__ void latency_chain_priority() { __builtin_amdgcn_s_setprio(3); }
+
 template <uint32_t FB, uint32_t RL_LOG>
 __global__ void __launch_bounds__(MSM_THREADS) msm_fold_hot(XyzzW *partials, const uint32_t *task_meta, const uint32_t *task_start, uint32_t total_bins) {
     constexpr uint32_t FINE = Shape<FB>::FINE, SLOT_PRIMARY = Shape<FB>::SLOT_PRIMARY, SLOT_HEAD = Shape<FB>::SLOT_HEAD,
                        SLOTS_PER_TASK = Shape<FB>::SLOTS_PER_TASK, META_PER_TASK = Shape<FB>::META_PER_TASK, RL = 1u << RL_LOG, RB = FINE / RL;
+    latency_chain_priority();
     const uint32_t gt = blockIdx.x * MSM_THREADS + threadIdx.x;
     const uint32_t task = gt / RL, sub = gt % RL;
     const bool live = task < task_start[total_bins];
@@ -527,6 +533,7 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_task_reduce(const XyzzW *p
     constexpr uint32_t FINE = Shape<FB>::FINE, SLOT_PRIMARY = Shape<FB>::SLOT_PRIMARY, SLOT_HEAD = Shape<FB>::SLOT_HEAD, SLOT_TAIL = Shape<FB>::SLOT_TAIL,
                        SLOTS_PER_TASK = Shape<FB>::SLOTS_PER_TASK, META_PER_TASK = Shape<FB>::META_PER_TASK, RL = 1u << RL_LOG, RB = FINE / RL, RB_LOG = FB - RL_LOG;
     static_assert(FB >= RL_LOG + 1, "at least two buckets per lane");
+    latency_chain_priority();
     const uint32_t gt = blockIdx.x * MSM_THREADS + threadIdx.x;
     const uint32_t task = gt / RL, sub = gt % RL;
     const bool live = task < task_start[total_bins];
@@ -599,6 +606,7 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_task_reduce(const XyzzW *p
 // for uniform scalars the kernel only reads the task offsets.
 constexpr uint32_t BIN_FOLD_MIN = 4;
 __global__ void __launch_bounds__(MSM_THREADS) msm_bin_fold(XyzzW *task_out, const uint32_t *task_start, uint32_t total_bins) {
+    latency_chain_priority();
     const uint32_t bin = blockIdx.x * (MSM_THREADS / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
     if (bin >= total_bins) return;
     const uint32_t t0 = task_start[bin], t1 = task_start[bin + 1];
@@ -626,6 +634,7 @@ static_assert((1u << THREADS_LOG) == MSM_THREADS, "THREADS_LOG");
 constexpr uint32_t WS_BIT_ROLES = THREADS_LOG, WS_FIRST_F_ROLE = 1 + WS_BIT_ROLES;
 __global__ void __launch_bounds__(MSM_THREADS, 2) msm_window_sums(const XyzzW *task_out, const uint32_t *task_start, G1Xyzz *window_out, uint32_t nbins, uint32_t roles) {
     __shared__ __attribute__((aligned(16))) XyzzW sh[MSM_THREADS];
+    latency_chain_priority();
     const uint32_t tid = threadIdx.x, w = blockIdx.x, role = blockIdx.y;
     const uint32_t halves = (nbins + MSM_THREADS - 1) / MSM_THREADS;            // 1 .. 4
     const bool takes_part = role == 0 || role >= WS_FIRST_F_ROLE || ((tid >> (role - 1)) & 1);
