@@ -425,6 +425,21 @@ def sharded_prove_scatter(ctx, dist, device, log_n, rank, world, proofs=3):
     local = n // world
     ctx.srs_generate(local, rank * local, 42)
     ctx.comm_set_shard(rank * local)
+    # the point-to-point transport first, on every rank (header broadcast + one grouped ring step, 45 s deadline): a node where it does not
+    # work costs this leg, not a hang
+    err0 = None
+    if not os.environ.get("PLK_BENCH_SHARE_DEVICE"):              # (the single-GPU test tier runs over the TCP transport: nothing to probe)
+        keep = os.environ.get("PLK_COMM_TIMEOUT_MS")
+        os.environ["PLK_COMM_TIMEOUT_MS"] = keep or "45000"
+        try:
+            ctx.comm_selftest()
+        except Exception as exc:                                   # noqa: BLE001
+            err0 = exc
+        finally:
+            if keep is None:
+                del os.environ["PLK_COMM_TIMEOUT_MS"]
+    if not all_ok(dist, device, err0 is None):
+        raise err0 or RuntimeError("plk_comm_selftest failed on another rank")
     ctx.comm_set_mode("scatter")
     # a batch job: an owner that fails without reaching comm_stop_workers must not leave its workers waiting for ever
     os.environ.setdefault("PLK_COMM_IDLE_TIMEOUT_MS", "90000")

@@ -182,6 +182,9 @@ int32_t plk_comm_set_mode(plk_ctx *ctx, int32_t mode);
  * owner calls plk_comm_stop_workers (returns PLK_OK) or goes away (PLK_ERR_HIP / PLK_ERR_IO).  *batches = batches served.            */
 int32_t plk_comm_serve(plk_ctx *ctx, uint64_t *batches);
 int32_t plk_comm_stop_workers(plk_ctx *ctx);                            /* owner: ends every worker's plk_comm_serve */
+/* every rank: one header broadcast + one grouped ring step (send to rank + 1, receive from rank - 1) over the RCCL communicator, checked
+ * byte by byte — the transport of owner-computes mode, exercised before the mode is trusted on a new node (works with one rank too).       */
+int32_t plk_comm_selftest(plk_ctx *ctx);
 int32_t plk_comm_destroy(plk_ctx *ctx);                                 /* back to single-GPU commitments */
 /* plk_msm_g1_finish + the combiner: the commitment over all ranks' shards (each rank enqueued its own slice), affine */
 int32_t plk_msm_g1_finish_sharded(plk_ctx *ctx, plk_g1_affine *out);

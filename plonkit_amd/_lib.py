@@ -167,6 +167,10 @@ class Context:
         _check(lib().plk_msm_g1_finish_sharded(self._h, _np(out)))
         return out
 
+    def comm_selftest(self):
+        """header broadcast + one grouped ring step over the RCCL communicator, checked byte by byte (every rank calls it)"""
+        _check(lib().plk_comm_selftest(self._h))
+
     def comm_destroy(self):
         _check(lib().plk_comm_destroy(self._h))
 

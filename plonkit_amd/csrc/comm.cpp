@@ -569,6 +569,48 @@ int32_t plk_comm_stop_workers(plk_ctx *ctx) {
     return comm_send_stop(ctx);
 }
 
+// Every point-to-point piece of owner-computes mode once, on any communicator (world >= 1, every rank calls it): a 64-byte header
+// broadcast from rank 0, then a ring step — rank r sends 4 KiB to rank r + 1 and receives from rank r - 1 in ONE group (with one rank:
+// to and from itself) — checked word by word.  What a deployment runs on a new node before it trusts the mode (bench.py does, before its
+// owner-computes leg), and the only way the RCCL side of that transport can run on a single GPU.
+int32_t plk_comm_selftest(plk_ctx *ctx) {
+    Comm *C = ctx ? static_cast<Comm *>(ctx->comm) : nullptr;
+    if (!C || C->tcp) { set_error("plk_comm_selftest: needs an RCCL communicator on this context (plk_comm_init)"); return PLK_ERR_ARG; }
+    PLK_TRY(scatter_ready(C));
+    Rccl *R = rccl();
+    constexpr size_t WORDS = 1024;
+    PLK_TRY(C->d_work.reserve(2 * WORDS * sizeof(uint32_t)));
+    uint32_t *d_out = C->d_work.as<uint32_t>(), *d_in = d_out + WORDS;
+    const int next = (C->rank + 1) % C->world, prev = (C->rank + C->world - 1) % C->world;
+    auto word = [](int rank, size_t i) { return (uint32_t)rank * 0x01000193u + (uint32_t)i * 0x9e3779b9u + 7u; };
+    std::vector<uint32_t> h(WORDS), got(WORDS, 0);
+    for (size_t i = 0; i < WORDS; i++) h[i] = word(C->rank, i);
+    PLK_HIP(hipMemcpyAsync(d_out, h.data(), WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, C->stream));
+    PLK_HIP(hipMemsetAsync(d_in, 0, WORDS * sizeof(uint32_t), C->stream));
+    ShardHeader hd{};
+    hd.magic = SHARD_MAGIC; hd.op = 0x74736574u /* "test" */; hd.n = 0x0123456789abcdefull;
+    if (C->rank == 0) { memcpy(C->h_hdr, &hd, sizeof hd); PLK_HIP(hipMemcpyAsync(C->d_hdr.p, C->h_hdr, sizeof hd, hipMemcpyHostToDevice, C->stream)); }
+    else PLK_HIP(hipMemsetAsync(C->d_hdr.p, 0, sizeof hd, C->stream));
+    ncclResult_t e = R->Broadcast(C->d_hdr.p, C->d_hdr.p, sizeof hd, ncclUint8, 0, C->nccl, C->stream);
+    if (e != ncclSuccess) return rccl_fail(e, "ncclBroadcast (self-test)");
+    e = R->GroupStart();
+    if (e != ncclSuccess) return rccl_fail(e, "ncclGroupStart");
+    e = R->Send(d_out, WORDS * sizeof(uint32_t), ncclUint8, next, C->nccl, C->stream);
+    const ncclResult_t e1 = R->Recv(d_in, WORDS * sizeof(uint32_t), ncclUint8, prev, C->nccl, C->stream);
+    const ncclResult_t e2 = R->GroupEnd();
+    if (e != ncclSuccess) return rccl_fail(e, "ncclSend (self-test)");
+    if (e1 != ncclSuccess) return rccl_fail(e1, "ncclRecv (self-test)");
+    if (e2 != ncclSuccess) return rccl_fail(e2, "ncclGroupEnd");
+    char *back = static_cast<char *>(C->h_hdr) + sizeof(ShardHeader);
+    PLK_HIP(hipMemcpyAsync(back, C->d_hdr.p, sizeof hd, hipMemcpyDeviceToHost, C->stream));
+    PLK_TRY(watch_exchange(C, C->stream));
+    PLK_HIP(hipMemcpy(got.data(), d_in, WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (memcmp(back, &hd, sizeof hd) != 0) { set_error("plk_comm_selftest: the broadcast header arrived changed"); return PLK_ERR_IO; }
+    for (size_t i = 0; i < WORDS; i++)
+        if (got[i] != word(prev, i)) { set_error("plk_comm_selftest: the ring step delivered other bytes than rank " + std::to_string(prev) + " sent"); return PLK_ERR_IO; }
+    return PLK_OK;
+}
+
 int32_t plk_comm_set_shard(plk_ctx *ctx, uint64_t first_index) {
     if (!ctx || !ctx->comm) { set_error("plk_comm_set_shard: no communicator on this context (plk_comm_init)"); return PLK_ERR_ARG; }
     return plk_set_commit_shard(ctx, first_index, builtin_combine, ctx->comm);

@@ -94,7 +94,13 @@ def test_rccl_communicator_of_one_rank():
     assert setup.verification_key_bytes(pa.crs42_g2_bytes()) == want_vk
     assert setup.prove(circ) == want_proof
     assert ctx.comm_info()[2] == 2 + 4                           # 11 commitments of the key in two batches; a proof has 4 batches (4 wires, z, 4 quotient parts, 2 openings)
+    # the transport of owner-computes mode over the same communicator: ncclBroadcast + grouped ncclSend / ncclRecv (one rank: to and from itself)
+    ctx.comm_selftest()
+    ctx.comm_selftest()
+    assert setup.prove(circ) == want_proof                       # ... and the exchange stream is still in step afterwards
     ctx.comm_destroy()
+    with pytest.raises(Exception):
+        ctx.comm_selftest()                                      # no communicator: an error, not a crash
     assert setup.prove(circ) == want_proof and ctx.comm_info() == (0, 1, 0)
     ctx.close()
 
