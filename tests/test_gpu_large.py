@@ -74,6 +74,54 @@ def test_msm_2pow24_trapdoor(ctx24, kind):
     assert np.array_equal(pa.g1_sum_jacobian(np.stack([lo, hi])), want)
 
 
+@pytest.mark.parametrize("log_n", [27, 28])
+def test_ntt_up_to_the_two_adicity_of_fr(log_n):
+    """plk_ntt's largest sizes (2^28 = the 2-adicity of Fr; error code 2 above it): a sparse polynomial against its
+    closed form at eight indices, plain and on the coset 7 * <omega>, and the round trip of a dense random vector compared on the device"""
+    import torch
+    import plonkit_amd as pa
+    ctx = pa.Context(0)
+    dev = torch.device("cuda:0")
+    n = 1 << log_n
+    w = ol.omega(log_n)
+    pos = [0, 1, 12345, n // 2 + 3, n - 1]
+    coef = [5, R_MOD - 2, 0x1234567890abcdef, 7, R_MOD - 1]
+    t = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+    for p_, c in zip(pos, coef):
+        t[p_] = torch.from_numpy(np.asarray(ol.fr_mont(c), dtype=np.uint64).view(np.int64).reshape(4).copy()).to(dev)
+    for coset in (None, 7):
+        x = t.clone()
+        torch.cuda.synchronize()                                   # the library runs on its own stream
+        g = ol.fr_mont(coset) if coset else None
+        ctx.ntt_dev(x, log_n, coset=g)
+        ctx.synchronize()
+        for k in (0, 1, 2, 977, n // 3, n // 2, n - 2, n - 1):
+            pt = (coset or 1) * pow(w, k, R_MOD) % R_MOD
+            want = sum(c * pow(pt, p_, R_MOD) for p_, c in zip(pos, coef)) % R_MOD
+            assert ol.fr_ints(x[k:k + 1].cpu().numpy().view(np.uint64))[0] == want, (k, coset)
+        ctx.ntt_dev(x, log_n, inverse=True, coset=g)
+        ctx.synchronize()
+        assert torch.equal(x, t), coset
+        del x
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(log_n)
+    d = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device=dev, generator=gen)
+    d[:, 3] &= (1 << 60) - 1                                       # < 2^252: valid residues, every other limb full range
+    e = d.clone()
+    torch.cuda.synchronize()
+    ctx.ntt_dev(e, log_n)
+    ctx.synchronize()
+    assert not torch.equal(e, d)
+    ctx.ntt_dev(e, log_n, inverse=True)
+    ctx.synchronize()
+    assert torch.equal(e, d)
+    with pytest.raises(Exception):
+        ctx.ntt_dev(e, 29)                                         # beyond the 2-adicity: refused, not attempted
+    del t, d, e
+    ctx.close()
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("log_n", [24, 26])
 def test_ntt_recursive_prover_shapes(log_n):
     """NTT 2^24 (N) and 2^26 (4N) of the recursive circuit: round trip, linearity, evaluation at four points"""
