@@ -18,6 +18,9 @@
  *     96-byte partial sums of every commitment are all-gathered over RCCL and added, inside the library).
  *   - `*_dev` entry points take HIP device pointers (e.g. torch tensors' data_ptr()) and a
  *     hipStream_t passed as void* (NULL = the context's own stream); `host` ones take host memory.
+ *     The context's stream is NOT ordered against the caller's streams: data a caller's kernel is still writing (a torch op
+ *     on torch's stream, say) must be complete before a `_dev` call that passes NULL reads it — synchronise first, or pass the
+ *     producing stream, which the call then runs on (the commitments instead wait for an event recorded on it, see below).
  *   - There is NO CPU fallback: without a gfx950 device plk_create fails with PLK_ERR_HIP.
  */
 #ifndef PLONKIT_AMD_H
