@@ -105,6 +105,11 @@ struct plk_ctx {
         hipEvent_t acc_done = nullptr;       // recorded behind msm_accumulate: from here on the commitment only runs its latency-bound reduction
         hipEvent_t ev[2] = {nullptr, nullptr};   // optional bracket around msm_accumulate (bench roofline)
         bool busy = false;
+        // short-commitment path (msm_small.hip): what msm_finish_batch needs to run the ordinary pipeline if a bucket list overflowed
+        bool small = false;
+        const void *fb_bases = nullptr, *fb_scalars[8] = {nullptr};
+        uint64_t fb_srs_n = 0, fb_n = 0;
+        uint32_t fb_copies = 0, fb_cbits = 0, fb_nbits = 0;
     } slot[MSM_SLOTS];
     uint64_t msm_enq = 0, msm_fin = 0;       // FIFO counters; commitment number k lives in slot[fifo[k % MSM_SLOTS]]
     uint8_t fifo[MSM_SLOTS] = {};

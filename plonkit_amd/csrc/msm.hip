@@ -45,15 +45,17 @@
 
 namespace plk {
 
-// -------------------------------------------------------------------------- scalar recoding
-__device__ __forceinline__ uint32_t extract_bits(const uint32_t *k, uint32_t pos, uint32_t c) {
-    uint32_t limb = pos >> 5, off = pos & 31;
-    if (limb >= 8) return 0;
-    uint64_t v = k[limb];
-    if (limb + 1 < 8) v |= (uint64_t)k[limb + 1] << 32;
-    return (uint32_t)(v >> off) & ((1u << c) - 1);
+// msm_small.hip: the short-commitment path
+int32_t msm_small_launch(plk_ctx::MsmSlot &S, hipStream_t stream, const G1Affine *bases, uint32_t copy_stride, const ScalarSet &set,
+                         uint32_t batch, uint32_t n, bool ev_on);
+constexpr uint32_t SM_PLANES_HOST = 17;
+// terms up to which a commitment takes it (PLK_MSM_SMALL_MAX overrides, 0 = never: A/B knob)
+static uint64_t msm_small_max() {
+    static const uint64_t v = [] { const char *e = getenv("PLK_MSM_SMALL_MAX"); return e ? strtoull(e, nullptr, 10) : (1ull << 14); }();
+    return v;
 }
 
+// -------------------------------------------------------------------------- scalar recoding
 // Step 1: every scalar leaves Montgomery form once and is recoded into W signed c-bit digits in
 // [-2^(c-1), 2^(c-1)] (c = 17: +-65536), stored as int32 per (commitment, window): digits[(m*W + w)*n + i].
 __global__ void __launch_bounds__(MSM_THREADS) msm_digits(ScalarSet set, MsmParams p, int32_t *digits) {
@@ -199,18 +201,8 @@ __global__ void __launch_bounds__(1024) msm_scan_bins(uint32_t *hist, uint32_t *
 // critical path of every round of a proof, and in a stream of commitments its workgroups displace accumulate workgroups).
 // The workgroup of the scatter pass takes RC_SCALARS scalars x 15 windows = 15360 entries, the same LDS staging volume
 // and the same ~15-entry runs per (workgroup, coarse bin) as the per-window partition it replaces.
-constexpr int RC_THREADS = 1024, RC_SCALARS = 1024, RC_WINDOWS = 15;
+constexpr int RC_THREADS = 1024, RC_SCALARS = 1024;                    // (RC_WINDOWS, recode17: msm_shape.h — shared with msm_small.hip)
 static_assert(RC_WINDOWS == 254 / 17 + 1, "the fused path is the c = 17 shape");
-
-// the signed digits of msm_digits for c = 17, 15 windows, in registers
-__device__ __forceinline__ void recode17(const Fr &k, int32_t (&d)[RC_WINDOWS]) {
-    uint32_t carry = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < RC_WINDOWS; w++) {
-        const uint32_t v = extract_bits(k.l, w * 17, 17) + carry;
-        if (v >= (1u << 16) && w + 1 < RC_WINDOWS) { d[w] = (int32_t)v - (1 << 17); carry = 1; } else { d[w] = (int32_t)v; carry = 0; }
-    }
-}
 
 // true for every lane of the wave iff all its live lanes hold the same scalar (then every window's digit is the same in all of them)
 __device__ __forceinline__ bool wave_same_scalar(const Fr &k, bool live, uint64_t live_mask) {
@@ -732,73 +724,27 @@ static int32_t slot_pinned(plk_ctx::MsmSlot &S, size_t bytes) {
     return PLK_OK;
 }
 
-// `caller` is the stream on which the scalars were produced; the commitment runs on its slot's own stream after an
-// event recorded there.  The caller must leave the scalars alone until the matching msm_finish_batch.
-int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t batch, uint64_t n, uint64_t base_offset, hipStream_t caller) {
-    if (ctx->msm_enq - ctx->msm_fin >= plk_ctx::MSM_SLOTS) { set_error("msm: " + std::to_string(plk_ctx::MSM_SLOTS) + " commitments are already in flight (call the finish function first)"); return PLK_ERR_ARG; }
-    uint32_t slot_index = 0;
-    while (ctx->slot[slot_index].busy) slot_index++;          // lowest free slot (there is one: fewer than MSM_SLOTS are in flight)
-    plk_ctx::MsmSlot &S = ctx->slot[slot_index];
-    auto in_flight = [&]() { ctx->fifo[ctx->msm_enq % plk_ctx::MSM_SLOTS] = (uint8_t)slot_index; S.busy = true; ctx->msm_enq++; };
-    if (!S.stream) {
-        PLK_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
-        PLK_HIP(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
-        PLK_HIP(hipEventCreateWithFlags(&S.acc_done, hipEventDisableTiming));
-    }
-    if (ctx->ev_on && !S.ev[0]) { PLK_HIP(hipEventCreate(&S.ev[0])); PLK_HIP(hipEventCreate(&S.ev[1])); }
-    PLK_HIP(hipEventRecord(S.ready, caller));
-    PLK_HIP(hipStreamWaitEvent(S.stream, S.ready, 0));
-    hipStream_t stream = S.stream;
-    if (!ctx->srs) { set_error("msm: no SRS uploaded (plk_srs_upload)"); return PLK_ERR_SRS; }
-    if (base_offset + n > ctx->srs_n) { set_error("msm: SRS too small for this commitment"); return PLK_ERR_SRS; }
-    if (n >= (1ull << 24) + 1) { set_error("msm: more than 2^24 terms in one pass (plk_msm_g1 / plk_msm_g1_dev / plk_prove split longer commitments; the enqueue and batch entry points do not)"); return PLK_ERR_SIZE; }
-    if (batch < 1 || batch > MSM_MAX_BATCH) { set_error("msm: batch must be 1..8"); return PLK_ERR_ARG; }
-    // resident table of the SRS in the 2^261 domain of the lazy field layer; large commitments use its shifted copies
-    uint32_t nbits = 1;
-    while ((1ull << nbits) < n) nbits++;
-    const uint32_t c_bits = n >= 4096 ? pick_window_bits(n, table_copies_for(ctx->srs_n) > 1) : 0;
-    uint32_t copies = 1;
-    if (c_bits == COPY_SHIFT) {
-        copies = table_copies_for(ctx->srs_n);
-        PLK_TRY(ensure_base_table(ctx, copies, stream));
-        while (copies > 1 && (MAX_COPIES % copies != 0 || ((uint64_t)copies << nbits) > (1ull << 24))) copies--;   // a divisor of 15 that fits the 24-bit (copy, index) field of an entry
-        static const int probe_copies = [] { const char *e = getenv("PLK_MSM_COPIES"); return e ? atoi(e) : 0; }();   // tuning probe, read once
-        if (probe_copies >= 1 && (uint32_t)probe_copies <= copies && MAX_COPIES % probe_copies == 0) copies = (uint32_t)probe_copies;
-    } else PLK_TRY(ensure_base_table(ctx, 1, stream));
-    const G1Affine *bases = ctx->srs_w.as<G1Affine>() + base_offset;
-    S.pending_parts = 0;
-    S.windows = 0;
-    S.batch = batch;
-    if (n == 0) { (void)hipEventRecord(S.acc_done, stream); in_flight(); return PLK_OK; }
-    if (n < 4096) {
-        uint32_t blocks = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
-        PLK_TRY(S.d.reserve((size_t)batch * blocks * sizeof(G1Xyzz)));
-        for (uint32_t m = 0; m < batch; m++)
-            hipLaunchKernelGGL(msm_naive, dim3(blocks), dim3(MSM_THREADS), 0, stream, bases, scalars_dev[m], (uint32_t)n, S.d.as<G1Xyzz>() + (size_t)m * blocks);
-        PLK_HIP(hipGetLastError());
-        (void)hipEventRecord(S.acc_done, stream);
-        S.pending_parts = blocks;
-        S.c_bits = 0;
-        PLK_TRY(slot_pinned(S, (size_t)batch * blocks * sizeof(G1Xyzz)));
-        PLK_HIP(hipMemcpyAsync(S.pinned, S.d.p, (size_t)batch * blocks * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
-        in_flight();
-        return PLK_OK;
-    }
+// the 2^20-shaped pipeline (recode / partition, accumulate, bucket reduction) for one batch on the slot's stream; everything it needs is
+// in the arguments, so that msm_finish_batch can run it again for a short commitment whose lists overflowed (msm_small.hip)
+struct BigArgs { const G1Affine *bases; uint64_t srs_n; uint32_t copies, c_bits, nbits; ScalarSet set; uint32_t batch; uint64_t n; };
+static int32_t msm_big_launch(plk_ctx *ctx, plk_ctx::MsmSlot &S, hipStream_t stream, const BigArgs &A) {
+    const G1Affine *bases = A.bases;
+    const uint32_t batch = A.batch, copies = A.copies;
+    const uint64_t n = A.n;
     MsmParams p;
     p.n = (uint32_t)n;
-    p.c = c_bits;
+    p.c = A.c_bits;
     p.windows = 254 / p.c + 1;
     p.groups = p.windows / copies;                            // copies > 1 only for c = 17: 15 windows, copies | 15
-    p.nbits = nbits;
-    p.copy_stride = copies > 1 ? (uint32_t)(p.groups * ctx->srs_n) : 0;
+    p.nbits = A.nbits;
+    p.copy_stride = copies > 1 ? (uint32_t)(p.groups * A.srs_n) : 0;
     p.fine_bits = pick_fine_bits(n, p.c);
     p.coarse_bits = p.c - 1 - p.fine_bits;
     p.nbins = 1u << p.coarse_bits;
     p.batch = batch;
     static const uint32_t probe_debug = [] { const char *e = getenv("PLK_MSM_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();   // experiments only, read once
     p.debug = probe_debug;
-    ScalarSet set{};
-    for (uint32_t m = 0; m < batch; m++) set.v[m] = scalars_dev[m];
+    const ScalarSet &set = A.set;
     const uint32_t total_sets = batch * p.groups, total_bins = total_sets * p.nbins, total_windows = batch * p.windows;
     const uint32_t max_tasks = total_bins + (uint32_t)(((uint64_t)total_windows * n) / TASK_MAX) + 1;
     PLK_TRY(S.a.reserve((size_t)(3 * total_bins + 4) * sizeof(uint32_t)));               // hist/cursor, bin_start, task_start
@@ -876,6 +822,88 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     S.windows = p.groups;
     S.c_bits = p.c;
     S.fine_bits = p.fine_bits;
+    return PLK_OK;
+}
+
+// fewer than 4096 terms without the table's copies: one double-and-add per term (msm_naive), block sums to the host
+static int32_t msm_naive_launch(plk_ctx::MsmSlot &S, hipStream_t stream, const BigArgs &A) {
+    const uint32_t blocks = (uint32_t)((A.n + MSM_THREADS - 1) / MSM_THREADS);
+    PLK_TRY(S.d.reserve((size_t)A.batch * blocks * sizeof(G1Xyzz)));
+    for (uint32_t m = 0; m < A.batch; m++)
+        hipLaunchKernelGGL(msm_naive, dim3(blocks), dim3(MSM_THREADS), 0, stream, A.bases, A.set.v[m], (uint32_t)A.n, S.d.as<G1Xyzz>() + (size_t)m * blocks);
+    PLK_HIP(hipGetLastError());
+    (void)hipEventRecord(S.acc_done, stream);
+    S.pending_parts = blocks;
+    S.windows = 0;
+    S.c_bits = 0;
+    PLK_TRY(slot_pinned(S, (size_t)A.batch * blocks * sizeof(G1Xyzz)));
+    PLK_HIP(hipMemcpyAsync(S.pinned, S.d.p, (size_t)A.batch * blocks * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
+    return PLK_OK;
+}
+
+// `caller` is the stream on which the scalars were produced; the commitment runs on its slot's own stream after an
+// event recorded there.  The caller must leave the scalars alone until the matching msm_finish_batch.
+int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t batch, uint64_t n, uint64_t base_offset, hipStream_t caller) {
+    if (ctx->msm_enq - ctx->msm_fin >= plk_ctx::MSM_SLOTS) { set_error("msm: " + std::to_string(plk_ctx::MSM_SLOTS) + " commitments are already in flight (call the finish function first)"); return PLK_ERR_ARG; }
+    uint32_t slot_index = 0;
+    while (ctx->slot[slot_index].busy) slot_index++;          // lowest free slot (there is one: fewer than MSM_SLOTS are in flight)
+    plk_ctx::MsmSlot &S = ctx->slot[slot_index];
+    auto in_flight = [&]() { ctx->fifo[ctx->msm_enq % plk_ctx::MSM_SLOTS] = (uint8_t)slot_index; S.busy = true; ctx->msm_enq++; };
+    if (!S.stream) {
+        PLK_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+        PLK_HIP(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
+        PLK_HIP(hipEventCreateWithFlags(&S.acc_done, hipEventDisableTiming));
+    }
+    if (ctx->ev_on && !S.ev[0]) { PLK_HIP(hipEventCreate(&S.ev[0])); PLK_HIP(hipEventCreate(&S.ev[1])); }
+    PLK_HIP(hipEventRecord(S.ready, caller));
+    PLK_HIP(hipStreamWaitEvent(S.stream, S.ready, 0));
+    hipStream_t stream = S.stream;
+    if (!ctx->srs) { set_error("msm: no SRS uploaded (plk_srs_upload)"); return PLK_ERR_SRS; }
+    if (base_offset + n > ctx->srs_n) { set_error("msm: SRS too small for this commitment"); return PLK_ERR_SRS; }
+    if (n >= (1ull << 24) + 1) { set_error("msm: more than 2^24 terms in one pass (plk_msm_g1 / plk_msm_g1_dev / plk_prove split longer commitments; the enqueue and batch entry points do not)"); return PLK_ERR_SIZE; }
+    if (batch < 1 || batch > MSM_MAX_BATCH) { set_error("msm: batch must be 1..8"); return PLK_ERR_ARG; }
+    // resident table of the SRS in the 2^261 domain of the lazy field layer; large commitments use its shifted copies
+    uint32_t nbits = 1;
+    while ((1ull << nbits) < n) nbits++;
+    // short commitments (msm_small.hip) need all 15 copies of the table: every commitment of >= 4096 terms builds them anyway; a shorter one
+    // only asks for them when the key is small enough for that to be cheap (<= 2^21 points: 80 ms once per key) or has them already
+    const bool small_wanted = n >= 1 && n <= msm_small_max() && table_copies_for(ctx->srs_n) == MAX_COPIES &&
+                              (n >= 4096 || ctx->srs_n <= (1ull << 21) || (ctx->srs_w_valid && ctx->srs_w_copies == MAX_COPIES));
+    const uint32_t c_bits = small_wanted ? COPY_SHIFT : (n >= 4096 ? pick_window_bits(n, table_copies_for(ctx->srs_n) > 1) : 0);
+    uint32_t copies = 1;
+    if (c_bits == COPY_SHIFT) {
+        copies = table_copies_for(ctx->srs_n);
+        PLK_TRY(ensure_base_table(ctx, copies, stream));
+        while (copies > 1 && (MAX_COPIES % copies != 0 || ((uint64_t)copies << nbits) > (1ull << 24))) copies--;   // a divisor of 15 that fits the 24-bit (copy, index) field of an entry
+        static const int probe_copies = [] { const char *e = getenv("PLK_MSM_COPIES"); return e ? atoi(e) : 0; }();   // tuning probe, read once
+        if (probe_copies >= 1 && (uint32_t)probe_copies <= copies && MAX_COPIES % probe_copies == 0) copies = (uint32_t)probe_copies;
+    } else PLK_TRY(ensure_base_table(ctx, 1, stream));
+    const bool small = small_wanted && copies == MAX_COPIES;
+    const G1Affine *bases = ctx->srs_w.as<G1Affine>() + base_offset;
+    S.pending_parts = 0;
+    S.windows = 0;
+    S.batch = batch;
+    S.small = false;
+    if (n == 0) { (void)hipEventRecord(S.acc_done, stream); in_flight(); return PLK_OK; }
+    BigArgs A{bases, ctx->srs_n, copies, c_bits, nbits, ScalarSet{}, batch, n};
+    for (uint32_t m = 0; m < batch; m++) A.set.v[m] = scalars_dev[m];
+    if (n < 4096 && !small) {
+        PLK_TRY(msm_naive_launch(S, stream, A));
+        in_flight();
+        return PLK_OK;
+    }
+    // short commitments: three short launches instead of the 2^20-shaped pipeline (msm_small.hip).  They need all 15 table copies.
+    if (small) {
+        PLK_TRY(msm_small_launch(S, stream, bases, (uint32_t)ctx->srs_n, A.set, batch, (uint32_t)n, ctx->ev_on));
+        PLK_TRY(slot_pinned(S, (size_t)batch * SM_PLANES_HOST * sizeof(G1Xyzz) + 16));
+        PLK_HIP(hipMemcpyAsync(S.pinned, S.d.p, (size_t)batch * SM_PLANES_HOST * sizeof(G1Xyzz) + 16, hipMemcpyDeviceToHost, stream));
+        S.small = true;
+        S.fb_bases = bases; S.fb_srs_n = ctx->srs_n; S.fb_n = n; S.fb_copies = copies; S.fb_cbits = c_bits; S.fb_nbits = nbits;
+        for (uint32_t m = 0; m < batch; m++) S.fb_scalars[m] = scalars_dev[m];
+        in_flight();
+        return PLK_OK;
+    }
+    PLK_TRY(msm_big_launch(ctx, S, stream, A));
     in_flight();
     return PLK_OK;
 }
@@ -906,9 +934,23 @@ int32_t msm_finish_batch(plk_ctx *ctx, hipStream_t, host::HJac *out) {
     ctx->msm_fin++;
     S.busy = false;
     PLK_HIP(hipStreamSynchronize(S.stream));
+    if (S.small) {
+        const uint32_t flag = *reinterpret_cast<const volatile uint32_t *>(static_cast<const char *>(S.pinned) + (size_t)S.batch * SM_PLANES_HOST * sizeof(G1Xyzz));
+        if (flag) {                                           // a bucket list overflowed (msm_small.hip): the ordinary pipeline on the same inputs
+            BigArgs A{static_cast<const G1Affine *>(S.fb_bases), S.fb_srs_n, S.fb_copies, S.fb_cbits, S.fb_nbits, ScalarSet{}, S.batch, S.fb_n};
+            for (uint32_t m = 0; m < S.batch; m++) A.set.v[m] = static_cast<const Fr *>(S.fb_scalars[m]);
+            S.small = false;
+            if (S.fb_n < 4096) PLK_TRY(msm_naive_launch(S, S.stream, A)); else PLK_TRY(msm_big_launch(ctx, S, S.stream, A));
+            PLK_HIP(hipStreamSynchronize(S.stream));
+        }
+    }
     for (uint32_t m = 0; m < S.batch; m++) {
         HJac acc = HJac::inf();
-        if (S.windows) {
+        if (S.small) {
+            // seventeen plane sums Q_0..Q_16 per commitment: sum_b 2^b * Q_b (bits 0-7: the lo digit, 8-16: the hi digit)
+            const uint64_t *raw = reinterpret_cast<const uint64_t *>(S.pinned) + (size_t)16 * SM_PLANES_HOST * m;
+            for (int b = (int)SM_PLANES_HOST - 1; b >= 0; b--) acc = jac_add(jac_double(acc), xyzz_host_to_jac(raw + 16 * b));
+        } else if (S.windows) {
             // per bucket set the device leaves (sum S, G_0..G_7, F_1, .., F_{halves-1});
             // W = sum S + 2^FB * (sum_b 2^b G_b + 2^8 * sum_u u*F_u)
             const size_t per = (size_t)16 * S.roles;

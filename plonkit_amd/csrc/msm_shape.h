@@ -43,6 +43,25 @@ struct MsmParams {
 
 struct ScalarSet { const Fr *v[MSM_MAX_BATCH]; };
 
+// ---- scalar recoding shared by msm.hip (fused pre-phase) and msm_small.hip
+__device__ __forceinline__ uint32_t extract_bits(const uint32_t *k, uint32_t pos, uint32_t c) {
+    uint32_t limb = pos >> 5, off = pos & 31;
+    if (limb >= 8) return 0;
+    uint64_t v = k[limb];
+    if (limb + 1 < 8) v |= (uint64_t)k[limb + 1] << 32;
+    return (uint32_t)(v >> off) & ((1u << c) - 1);
+}
+constexpr int RC_WINDOWS = 15;                      // 17-bit windows over the 254-bit scalars
+// the signed digits of msm_digits for c = 17, 15 windows, in registers: d[w] in [-2^16, 2^16], top window unsigned
+__device__ __forceinline__ void recode17(const Fr &k, int32_t (&d)[RC_WINDOWS]) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < RC_WINDOWS; w++) {
+        const uint32_t v = extract_bits(k.l, w * 17, 17) + carry;
+        if (v >= (1u << 16) && w + 1 < RC_WINDOWS) { d[w] = (int32_t)v - (1 << 17); carry = 1; } else { d[w] = (int32_t)v; carry = 0; }
+    }
+}
+
 // Per-task output of kernel A: 128 PRIMARY slots (a bucket whose run lies inside one lane's slice), and per
 // lane one HEAD slot (its first run continues a bucket begun by an earlier lane) and one TAIL slot (its last
 // run is continued by a later lane).  Which slots are live follows from the bucket offsets alone.

@@ -216,6 +216,23 @@ def test_msm_scalar_distributions(ctx, srs16, kind, n):
         assert pa.g1_to_bytes(got) == b"\x40" + b"\x00" * 63
 
 
+@pytest.mark.parametrize("n", [64, 300, 4096, 8192, 10000])
+def test_msm_short_path_list_overflow(ctx, srs16, n):
+    """short commitments (msm_small.hip, <= 2^14 terms): a bucket list holds 64 entries of a 64-term workgroup; a constant column whose scalar carries
+    the SAME digit in several windows (3 * (1 + 2^17 + .. + 2^68): five windows put five entries each into lo bucket 3, and 2^8-multiples
+    do the same to a hi bucket) overflows it — the overflow flag makes msm_finish_batch run the ordinary pipeline (or, below 4096 terms,
+    the per-term double-and-add) on the same inputs.  Also a mix: half the column constant, half uniform."""
+    ctx.srs_upload(srs16)
+    rep = sum(3 << (17 * w) for w in range(5)) + sum((7 << 8) << (17 * w) for w in range(6, 11))
+    ks = [rep] * n
+    assert np.array_equal(ctx.msm(ol.fr_vec(ks)), _trapdoor(ks))
+    rng = random.Random(n)
+    ks = [rep if i % 2 else rng.randrange(R_MOD) for i in range(n)]
+    assert np.array_equal(ctx.msm(ol.fr_vec(ks)), _trapdoor(ks))
+    ks = [1] * n                                                    # one entry per term, all in lo bucket 1: 64 per list, exactly the capacity
+    assert np.array_equal(ctx.msm(ol.fr_vec(ks)), _trapdoor(ks))
+
+
 def test_msm_duplicate_and_opposite_bases(ctx, srs16):
     """add == double and P + (-P) inside one bucket; infinity bases are skipped"""
     p = srs16[3]
