@@ -47,12 +47,14 @@ namespace plk {
 
 // msm_small.hip: the short-commitment path
 int32_t msm_small_launch(plk_ctx::MsmSlot &S, hipStream_t stream, const G1Affine *bases, uint32_t copy_stride, const ScalarSet &set,
-                         uint32_t batch, uint32_t n, bool ev_on);
+                         uint32_t batch, uint32_t n, bool ev_on, void *host_out);
 constexpr uint32_t SM_PLANES_HOST = 17;
-// terms up to which a commitment takes it (PLK_MSM_SMALL_MAX overrides, 0 = never: A/B knob)
-static uint64_t msm_small_max() {
-    static const uint64_t v = [] { const char *e = getenv("PLK_MSM_SMALL_MAX"); return e ? strtoull(e, nullptr, 10) : (1ull << 14); }();
-    return v;
+// terms up to which a commitment takes it: 2^15 for one or two commitments per launch, 2^14 for a larger batch (measured, same box, one at a
+// time: 2^14 terms 0.29 against 0.62 ms, 2^15 0.43 against 0.53, 2^16 0.66 against 0.54; a batch of four 2^15-term commitments inside a proof
+// is a tie).  PLK_MSM_SMALL_MAX overrides (0 = never: A/B knob)
+static uint64_t msm_small_max(uint32_t batch) {
+    static const long long v = [] { const char *e = getenv("PLK_MSM_SMALL_MAX"); return e ? (long long)strtoull(e, nullptr, 10) : -1ll; }();
+    return v >= 0 ? (uint64_t)v : (batch <= 2 ? (1ull << 15) : (1ull << 14));
 }
 
 // -------------------------------------------------------------------------- scalar recoding
@@ -867,7 +869,7 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     while ((1ull << nbits) < n) nbits++;
     // short commitments (msm_small.hip) need all 15 copies of the table: every commitment of >= 4096 terms builds them anyway; a shorter one
     // only asks for them when the key is small enough for that to be cheap (<= 2^21 points: 80 ms once per key) or has them already
-    const bool small_wanted = n >= 1 && n <= msm_small_max() && table_copies_for(ctx->srs_n) == MAX_COPIES &&
+    const bool small_wanted = n >= 1 && n <= msm_small_max(batch) && table_copies_for(ctx->srs_n) == MAX_COPIES &&
                               (n >= 4096 || ctx->srs_n <= (1ull << 21) || (ctx->srs_w_valid && ctx->srs_w_copies == MAX_COPIES));
     const uint32_t c_bits = small_wanted ? COPY_SHIFT : (n >= 4096 ? pick_window_bits(n, table_copies_for(ctx->srs_n) > 1) : 0);
     uint32_t copies = 1;
@@ -894,9 +896,8 @@ int32_t msm_enqueue_batch(plk_ctx *ctx, const Fr *const *scalars_dev, uint32_t b
     }
     // short commitments: three short launches instead of the 2^20-shaped pipeline (msm_small.hip).  They need all 15 table copies.
     if (small) {
-        PLK_TRY(msm_small_launch(S, stream, bases, (uint32_t)ctx->srs_n, A.set, batch, (uint32_t)n, ctx->ev_on));
-        PLK_TRY(slot_pinned(S, (size_t)batch * SM_PLANES_HOST * sizeof(G1Xyzz) + 16));
-        PLK_HIP(hipMemcpyAsync(S.pinned, S.d.p, (size_t)batch * SM_PLANES_HOST * sizeof(G1Xyzz) + 16, hipMemcpyDeviceToHost, stream));
+        PLK_TRY(slot_pinned(S, (size_t)MSM_MAX_BATCH * SM_PLANES_HOST * sizeof(G1Xyzz) + 16));
+        PLK_TRY(msm_small_launch(S, stream, bases, (uint32_t)ctx->srs_n, A.set, batch, (uint32_t)n, ctx->ev_on, S.pinned));
         S.small = true;
         S.fb_bases = bases; S.fb_srs_n = ctx->srs_n; S.fb_n = n; S.fb_copies = copies; S.fb_cbits = c_bits; S.fb_nbits = nbits;
         for (uint32_t m = 0; m < batch; m++) S.fb_scalars[m] = scalars_dev[m];

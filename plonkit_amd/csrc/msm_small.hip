@@ -19,13 +19,18 @@
 // No MFMA (256-bit modular integers); bound by the latency of the EC addition chains.
 #include "msm_shape.h"
 #include "msm.h"
+#include "ec29_quad_dev.h"
 
 namespace plk {
 
-constexpr uint32_t SM_THREADS = 512;             // = buckets of a workgroup: index v in [1, 255] = lo value v, index 255 + v = hi value v in [1, 256]
-constexpr uint32_t SM_CH = 64;                   // terms per workgroup
-constexpr uint32_t SM_CAP = 64, SM_STRIDE = SM_CAP + 1;      // list slots per bucket (odd stride: the lanes' reads fall into different banks)
-constexpr size_t SM_LDS = (size_t)(SM_THREADS + SM_THREADS * SM_STRIDE) * sizeof(uint32_t);
+constexpr uint32_t SM_BUCKETS = 512;             // index v in [1, 255] = lo value v, index 255 + v = hi value v in [1, 256]
+constexpr uint32_t SM_THREADS = 256;             // a workgroup owns ONE of the two bucket sets of its terms: lane = bucket, one wave per SIMD
+// Terms per workgroup (= slots per bucket list: a constant column fills exactly that many): 32, 64 or 128, chosen per launch so that the grid
+// is about one workgroup per CU — the kernel is bound by the additions a SIMD issues (~4.5 us per wave and addition), so a short commitment
+// wants many short lists on all CUs (2^12 terms: 256 workgroups, ~6 additions deep) and a batch of them fewer, longer ones (less imbalance
+// between the lanes of a wave: the longest of 64 lists decides, and fewer partial sums for msm_small_fold).
+constexpr uint32_t SM_CH_MIN = 32, SM_CH_MAX = 128;
+static size_t sm_lds(uint32_t ch) { return (size_t)(SM_THREADS + SM_THREADS * (ch + 1)) * sizeof(uint32_t); }
 
 __device__ __forceinline__ void small_chain_priority() { __builtin_amdgcn_s_setprio(3); }
 
@@ -41,31 +46,41 @@ __device__ __forceinline__ XyzzW sm_shfl_xor(const XyzzW &v, int mask) {
     return r;
 }
 
-// grid (G, batch).  bases = copy 0 of the fixed-base table at the commitment's first point; copy w lies w * copy_stride points on.
-__global__ void __launch_bounds__(SM_THREADS, 1) msm_small_accumulate(const G1Affine *bases, ScalarSet set, uint32_t n, uint32_t copy_stride,
+// grid (4 G, batch): workgroup 4 g + s takes terms [g ch, (g + 1) ch) and a QUARTER of the bucket space — s & 1: lo / hi values, s >> 1: which half
+// of the 256 values — with TWO lanes per bucket (lane b and lane b + 128): an entry joins the shorter of its bucket's two lists.  With one list per
+// bucket the longest of the 65536 lists of a 2^12-term commitment held 10-11 entries against a mean of 1.9, and since every SIMD of the chip runs
+// exactly one wave of this kernel the longest list IS the kernel's duration (measured 73-80 us); two choices cut that tail.
+// bases = copy 0 of the fixed-base table at the commitment's first point; copy w lies w * copy_stride points on.
+__global__ void __launch_bounds__(SM_THREADS, 1) msm_small_accumulate(const G1Affine *bases, ScalarSet set, uint32_t n, uint32_t ch, uint32_t copy_stride,
                                                                      XyzzW *partials, uint32_t *flag) {
-    extern __shared__ uint32_t sm_lds[];
-    uint32_t *cnt = sm_lds, *list = sm_lds + SM_THREADS;
-    const uint32_t tid = threadIdx.x, g = blockIdx.x, m = blockIdx.y, first = g * SM_CH;
+    extern __shared__ uint32_t sm_lds_mem[];
+    uint32_t *cnt = sm_lds_mem, *list = sm_lds_mem + SM_THREADS;
+    const uint32_t tid = threadIdx.x, g = blockIdx.x >> 2, hi_set = blockIdx.x & 1, half = (blockIdx.x >> 1) & 1, m = blockIdx.y, first = g * ch;
+    const uint32_t stride = ch + 1;                            // (odd stride: the lanes' reads fall into different banks)
     cnt[tid] = 0;
     __syncthreads();
-    if (tid < SM_CH && first + tid < n) {
+    if (tid < ch && first + tid < n) {
         int32_t d[RC_WINDOWS];
         recode17(to_canonical(load_fp(set.v[m] + first + tid)), d);
 #pragma unroll
         for (uint32_t w = 0; w < RC_WINDOWS; w++) {
             if (!d[w]) continue;
-            const uint32_t mg = (uint32_t)(d[w] < 0 ? -d[w] : d[w]), lo = mg & 255u, hi = mg >> 8;
-            const uint32_t e = (d[w] < 0 ? 0x80000000u : 0u) | (w << 8) | tid;
-            if (lo) { const uint32_t pos = atomicAdd(&cnt[lo], 1u); if (pos < SM_CAP) list[lo * SM_STRIDE + pos] = e; }
-            if (hi) { const uint32_t pos = atomicAdd(&cnt[255 + hi], 1u); if (pos < SM_CAP) list[(255 + hi) * SM_STRIDE + pos] = e; }
+            const uint32_t mg = (uint32_t)(d[w] < 0 ? -d[w] : d[w]);
+            const uint32_t v = hi_set ? mg >> 8 : mg & 255u;                  // lo in [0, 255], hi in [0, 256]; 0 = no entry in this set
+            if (!v) continue;
+            const uint32_t b = hi_set ? v - 1 : v;                           // bucket index inside the set
+            if ((b >> 7) != half) continue;
+            uint32_t t = b & 127u;
+            if (cnt[t + 128] < cnt[t]) t += 128;                            // (a stale read only makes the choice a little worse)
+            const uint32_t pos = atomicAdd(&cnt[t], 1u);
+            if (pos < ch) list[t * stride + pos] = (d[w] < 0 ? 0x80000000u : 0u) | (w << 8) | tid;
         }
     }
     __syncthreads();
     uint32_t c = cnt[tid];
-    if (c > SM_CAP) { atomicOr(flag, 1u); c = SM_CAP; }
-    const uint32_t *mine = list + tid * SM_STRIDE;
-    auto point = [&](uint32_t e) __attribute__((always_inline)) { return bases + (size_t)((e >> 8) & 15u) * copy_stride + first + (e & 63u); };
+    if (c > ch) { atomicOr(flag, 1u); c = ch; }
+    const uint32_t *mine = list + tid * stride;
+    auto point = [&](uint32_t e) __attribute__((always_inline)) { return bases + (size_t)((e >> 8) & 15u) * copy_stride + first + (e & 255u); };
     XyzzW acc = xyzzw_identity();
     uint32_t e_next = c ? mine[0] : 0;
     G1Affine nx;
@@ -77,77 +92,100 @@ __global__ void __launch_bounds__(SM_THREADS, 1) msm_small_accumulate(const G1Af
         AffW q; q.x = unpack<FqW>(cur.x); q.y = unpack<FqW>(cur.y);
         xyzzw_add_mixed(acc, q, neg);
     }
-    store_xyzzw(partials + ((size_t)m * gridDim.x + g) * SM_THREADS + tid, acc);
+    // partial sums: [m][2 g + copy][512 buckets] — msm_small_fold sees 2 G "workgroups"
+    store_xyzzw(partials + ((size_t)m * (gridDim.x >> 1) + 2 * g + (tid >> 7)) * SM_BUCKETS + hi_set * 256 + half * 128 + (tid & 127u), acc);
 }
 
-// grid (128, batch), 256 threads: wave -> bucket b = 4 * blockIdx.x + wave; buckets[m][b] = sum over the G workgroups.
-// One addition site (operands chosen beforehand), as in msm_task_reduce: two 144-byte points through an out-of-line call cost more than the arithmetic.
-__global__ void __launch_bounds__(256) msm_small_fold(const XyzzW *partials, uint32_t G, XyzzW *buckets) {
+// The two tree kernels run their full additions four lanes at a time (ec29_quad_dev.h: a quad of lanes shares one addition, four products
+// deep instead of fourteen): ~2.6 us per tree level instead of ~7.3.  One addition site per kernel (the operand is chosen beforehand).
+//
+// grid (512, batch), 256 threads = 64 quads: buckets[m][b] = sum of the G2 partial sums of bucket b (two per accumulate chunk: the bucket's
+// two lanes).  Quad q takes partial sums q, q + 64, .. one after the other, then a tree over the 16 quads of a wave (shuffles) and over the
+// four waves (LDS).
+__global__ void __launch_bounds__(256) msm_small_fold(const XyzzW *partials, uint32_t G2, XyzzW *buckets) {
+    __shared__ __attribute__((aligned(16))) XyzzW sh[4];
     small_chain_priority();
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, b = blockIdx.x * 4 + wave, m = blockIdx.y;
-    const XyzzW *P = partials + (size_t)m * G * SM_THREADS + b;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, role = tid & 3, quad = tid >> 2, b = blockIdx.x, m = blockIdx.y;
+    const XyzzW *P = partials + (size_t)m * G2 * SM_BUCKETS + b;
+    const uint32_t nseq = (G2 + 63) / 64, total = nseq + 4 + 2;
     XyzzW X = xyzzw_identity();
-    uint32_t g = lane, step = 0;
-    for (;;) {
-        const bool loading = __any(g < G);                    // wave-uniform
-        if (!loading && step == 6) break;
+    for (uint32_t step = 0; step < total; step++) {
         XyzzW O = xyzzw_identity();
-        if (loading) { if (g < G) { O = load_xyzzw(P + (size_t)g * SM_THREADS); g += 64; } }
-        else { O = sm_shfl_xor(X, 1 << step); step++; }
-        xyzzw_add(X, O);
+        if (step < nseq) {
+            const uint32_t g = quad + 64 * step;
+            if (g < G2) O = load_xyzzw(P + (size_t)g * SM_BUCKETS);
+        } else {
+            const uint32_t k = step - nseq;
+            if (k == 4) {                                     // the four waves' sums change hands through LDS; every wave then folds all four (same result)
+                if (lane == 0) sh[wave] = X;
+                __syncthreads();
+                X = (lane >> 2) < 4 ? sh[lane >> 2] : xyzzw_identity();
+            }
+            O = sm_shfl_xor(X, k < 4 ? 4 << k : 4 << (k - 4));
+        }
+        X = xyzzw_add_quad(X, O, role);
     }
-    if (lane == 0) store_xyzzw(buckets + (size_t)m * SM_THREADS + b, X);
+    if (tid == 0) store_xyzzw(buckets + (size_t)m * SM_BUCKETS + b, X);
 }
 
-// grid (17, batch), 128 threads.  Plane p < 8: bit p of the lo value; plane 8 + b: bit b of the hi value (b = 8: the one bucket hi = 256).
+// grid (17, batch), 512 threads = 128 quads.  Plane p < 8: bit p of the lo value; plane 8 + b: bit b of the hi value (b = 8: the one bucket hi = 256).
+// Quad q holds the q-th bucket of the plane; tree over the 16 quads of a wave, then over the eight waves.
 constexpr uint32_t SM_PLANES = 17;
-__global__ void __launch_bounds__(128) msm_small_planes(const XyzzW *buckets, G1Xyzz *planes) {
-    __shared__ __attribute__((aligned(16))) XyzzW sh;
+__global__ void __launch_bounds__(512) msm_small_planes(const XyzzW *buckets, G1Xyzz *planes, const uint32_t *flag, uint32_t *flag_out, uint32_t extra) {
+    __shared__ __attribute__((aligned(16))) XyzzW sh[8];
     small_chain_priority();
-    const uint32_t p = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
+    const uint32_t p = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, role = tid & 3, quad = tid >> 2;
     const bool hi = p >= 8;
     const uint32_t bit = hi ? p - 8 : p;
-    const XyzzW *B = buckets + (size_t)m * SM_THREADS;
+    const XyzzW *B = buckets + (size_t)m * SM_BUCKETS;
     XyzzW X = xyzzw_identity();
     if (bit < 8) {
-        const uint32_t v = ((tid >> bit) << (bit + 1)) | (1u << bit) | (tid & ((1u << bit) - 1));     // the 128 values of [1, 255] with `bit` set
+        const uint32_t v = ((quad >> bit) << (bit + 1)) | (1u << bit) | (quad & ((1u << bit) - 1));   // the 128 values of [1, 255] with `bit` set
         X = load_xyzzw(B + (hi ? 255 + v : v));
-    } else if (tid == 0) X = load_xyzzw(B + 511);
-    for (uint32_t step = 0; step < 7; step++) {
-        XyzzW O;
-        if (step < 6) O = sm_shfl_xor(X, 1 << step);
-        else {
-            if (tid == 64) sh = X;
+    } else if (quad == 0) X = load_xyzzw(B + 511);
+    for (uint32_t k = 0; k < 7 + extra; k++) {                 // (extra: measurement knob PLK_MSM_SMALL_EXTRA — more levels that add the identity)
+        if (k == 4) {
+            if (lane == 0) sh[wave] = X;
             __syncthreads();
-            O = tid < 64 ? sh : xyzzw_identity();
+            X = (lane >> 2) < 8 ? sh[lane >> 2] : xyzzw_identity();
         }
-        xyzzw_add(X, O);                                      // the one addition site of the kernel
+        XyzzW O = sm_shfl_xor(X, k < 4 ? 4 << k : 4 << ((k - 4) & 3));
+        if (k >= 7) O = xyzzw_identity();
+        X = xyzzw_add_quad(X, O, role);                       // the one addition site of the kernel
     }
     if (tid == 0) store_xyzz(planes + (size_t)m * SM_PLANES + p, xyzzw_export(X));
+    if (tid == 0 && p == 0 && m == 0) *flag_out = *flag;
 }
 
-// enqueues the three launches on `stream`; planes_out: batch * 17 points followed by the overflow flag (one uint32)
+// enqueues the three launches on `stream`.  The seventeen points per commitment and the overflow flag (one uint32 behind them) are stored by the
+// last kernel straight into `host_out` (page-locked, device-visible): no copy launch on the tail of a chain this short.
 int32_t msm_small_launch(plk_ctx::MsmSlot &S, hipStream_t stream, const G1Affine *bases, uint32_t copy_stride, const ScalarSet &set,
-                         uint32_t batch, uint32_t n, bool ev_on) {
+                         uint32_t batch, uint32_t n, bool ev_on, void *host_out) {
     static std::atomic<bool> attr_set{false};
     if (!attr_set) {
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_small_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM_LDS));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_small_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_lds(SM_CH_MAX)));
         attr_set = true;
     }
-    const uint32_t G = (n + SM_CH - 1) / SM_CH;
-    PLK_TRY(S.e.reserve((size_t)batch * G * SM_THREADS * sizeof(XyzzW)));
-    PLK_TRY(S.c.reserve((size_t)batch * SM_THREADS * sizeof(XyzzW)));
-    PLK_TRY(S.d.reserve((size_t)batch * SM_PLANES * sizeof(G1Xyzz) + 16));
+    static const uint32_t probe_ch = [] { const char *e = getenv("PLK_MSM_SMALL_CH"); return e ? (uint32_t)atoi(e) : 0u; }();   // A/B knob: 32, 64 or 128
+    static const uint32_t probe_extra = [] { const char *e = getenv("PLK_MSM_SMALL_EXTRA"); return e ? (uint32_t)atoi(e) : 0u; }();
+    static const uint32_t want_wgs = [] { const char *e = getenv("PLK_MSM_SMALL_WGS"); return e ? (uint32_t)atoi(e) : 256u; }();
+    uint32_t ch = SM_CH_MIN;
+    while (ch < SM_CH_MAX && (uint64_t)batch * 4 * ((n + ch - 1) / ch) > want_wgs) ch <<= 1;
+    if (probe_ch == 32 || probe_ch == 64 || probe_ch == 128) ch = probe_ch;
+    const uint32_t G = (n + ch - 1) / ch;
+    PLK_TRY(S.e.reserve((size_t)batch * 2 * G * SM_BUCKETS * sizeof(XyzzW)));
+    PLK_TRY(S.c.reserve((size_t)batch * SM_BUCKETS * sizeof(XyzzW) + 16));
     XyzzW *partials = S.e.as<XyzzW>(), *buckets = S.c.as<XyzzW>();
-    G1Xyzz *planes = S.d.as<G1Xyzz>();
-    uint32_t *flag = reinterpret_cast<uint32_t *>(planes + (size_t)batch * SM_PLANES);
+    uint32_t *flag = reinterpret_cast<uint32_t *>(buckets + (size_t)batch * SM_BUCKETS);
+    G1Xyzz *planes = static_cast<G1Xyzz *>(host_out);
     PLK_HIP(hipMemsetAsync(flag, 0, 16, stream));
     if (ev_on) PLK_HIP(hipEventRecord(S.ev[0], stream));
-    hipLaunchKernelGGL(msm_small_accumulate, dim3(G, batch), dim3(SM_THREADS), SM_LDS, stream, bases, set, n, copy_stride, partials, flag);
+    hipLaunchKernelGGL(msm_small_accumulate, dim3(4 * G, batch), dim3(SM_THREADS), sm_lds(ch), stream, bases, set, n, ch, copy_stride, partials, flag);
     if (ev_on) (void)hipEventRecord(S.ev[1], stream);
     (void)hipEventRecord(S.acc_done, stream);
-    hipLaunchKernelGGL(msm_small_fold, dim3(SM_THREADS / 4, batch), dim3(256), 0, stream, (const XyzzW *)partials, G, buckets);
-    hipLaunchKernelGGL(msm_small_planes, dim3(SM_PLANES, batch), dim3(128), 0, stream, (const XyzzW *)buckets, planes);
+    hipLaunchKernelGGL(msm_small_fold, dim3(SM_BUCKETS, batch), dim3(256), 0, stream, (const XyzzW *)partials, 2 * G, buckets);
+    hipLaunchKernelGGL(msm_small_planes, dim3(SM_PLANES, batch), dim3(512), 0, stream, (const XyzzW *)buckets, planes, (const uint32_t *)flag,
+                       reinterpret_cast<uint32_t *>(planes + (size_t)batch * SM_PLANES), probe_extra);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
 }
