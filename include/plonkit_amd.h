@@ -80,7 +80,9 @@ int32_t plk_srs_precompute(plk_ctx *ctx);
  * keeps ownership and refuses to replace a key that a borrower holds (PLK_ERR_ARG; a Lagrange-form key it did not have when the
  * loans were made may still be installed — the borrowers do not see it, share again for that).  Destroying `src` before its
  * borrowers is safe: the key and the tables outlive it until the last borrower returns its loan (plk_destroy / a key of its own).
- * A borrower that is given a key of its own (upload / generate / set_dev) simply stops borrowing.                              */
+ * A borrower that is given a key of its own (upload / generate / set_dev) simply stops borrowing.
+ * plk_ctx_share_srs MUST NOT RUN CONCURRENTLY WITH ANY CALL ON `src` (nor on `dst`): `src` swaps its monomial / Lagrange key slots for the
+ * duration of a Lagrange-form commitment, and a loan taken at that moment would lend the wrong key.  Share first, then start the threads.  */
 int32_t plk_ctx_share_srs(plk_ctx *dst, plk_ctx *src);
 
 /* ---- Polynomial::{fft,ifft,coset_fft,icoset_fft} over Fr (bellman_ce::plonk::polynomials; driven
@@ -177,7 +179,12 @@ int32_t plk_comm_set_shard(plk_ctx *ctx, uint64_t first_index);         /* same 
  *                                  ranks only hold their slice of the key and sit in plk_comm_serve.  Same proof bytes.  Rank r must
  *                                  hold the key points [r * L, (r + 1) * L), L = the owner's key size (plk_comm_init's first_index).
  * Every rank of a communicator must be in the same mode: PLK_SHARD_MODE=scatter in the environment of all of them, or
- * plk_comm_set_mode on all of them right after plk_comm_init.                                                                        */
+ * plk_comm_set_mode on all of them right after plk_comm_init.
+ * PLK_SHARD_SCATTER IS EXPERIMENTAL BETWEEN GPUS: its RCCL transport (header broadcast + grouped ncclSend / ncclRecv) has run on one GPU only
+ * (plk_comm_selftest, plk_comm_scatter_selftest) and over the TCP tier of the tests — no multi-GPU node has run it.  On an RCCL communicator of
+ * more than one rank plk_comm_set_mode(SCATTER) therefore runs plk_comm_selftest first (a collective, like the call itself) and refuses the mode
+ * if that fails.  If the owner's plk_prove / plk_setup_write_vk returns an error after a batch went out (PLK_ERR_UNSAT, ...), the batch's exchange
+ * is still run, so that the workers stay in step and the communicator stays usable.                                                       */
 #define PLK_SHARD_REPLICATE 0
 #define PLK_SHARD_SCATTER 1
 int32_t plk_comm_set_mode(plk_ctx *ctx, int32_t mode);
@@ -188,6 +195,13 @@ int32_t plk_comm_stop_workers(plk_ctx *ctx);                            /* owner
 /* every rank: one header broadcast + one grouped ring step (send to rank + 1, receive from rank - 1) over the RCCL communicator, checked
  * byte by byte — the transport of owner-computes mode, exercised before the mode is trusted on a new node (works with one rank too).       */
 int32_t plk_comm_selftest(plk_ctx *ctx);
+/* one GPU, RCCL communicator of ONE rank, key of >= 2^log_n points: the scatter step of owner-computes mode through the real RCCL branch
+ * (comm_send_work / comm_recv_work, rank 0 receiving its own share), `iterations` times, with the scalars STILL BEING WRITTEN on the context's
+ * stream when the step is called — the ordering the TCP tier cannot test.  The commitment of what arrived must equal the commitment of the
+ * vector itself; *mismatches = iterations where it does not (0 is the pass).  No reference counterpart (bellman's Worker shares memory).    */
+int32_t plk_comm_scatter_selftest(plk_ctx *ctx, uint32_t log_n, uint32_t iterations, uint32_t *mismatches);
+/* ranks RCCL itself counts in the context's communicator (ncclCommCount); 0 without an RCCL communicator — the multi-GPU bench line prints it */
+int32_t plk_comm_nccl_count(const plk_ctx *ctx, int32_t *count);
 int32_t plk_comm_destroy(plk_ctx *ctx);                                 /* back to single-GPU commitments */
 /* plk_msm_g1_finish + the combiner: the commitment over all ranks' shards (each rank enqueued its own slice), affine */
 int32_t plk_msm_g1_finish_sharded(plk_ctx *ctx, plk_g1_affine *out);

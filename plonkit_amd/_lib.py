@@ -171,6 +171,19 @@ class Context:
         """header broadcast + one grouped ring step over the RCCL communicator, checked byte by byte (every rank calls it)"""
         _check(lib().plk_comm_selftest(self._h))
 
+    def comm_scatter_selftest(self, log_n, iterations):
+        """the scatter step of owner-computes mode through the real RCCL branch on one GPU (one-rank communicator, rank 0 receiving its own
+        share), the scalars still being written when the step is called; returns the number of iterations whose commitment differs (0 = pass)"""
+        bad = ctypes.c_uint32(0)
+        _check(lib().plk_comm_scatter_selftest(self._h, ctypes.c_uint32(log_n), ctypes.c_uint32(iterations), ctypes.byref(bad)))
+        return bad.value
+
+    def comm_nccl_count(self):
+        """ranks RCCL itself counts in this context's communicator (ncclCommCount); 0 without an RCCL communicator"""
+        k = ctypes.c_int32(0)
+        _check(lib().plk_comm_nccl_count(self._h, ctypes.byref(k)))
+        return k.value
+
     def comm_destroy(self):
         _check(lib().plk_comm_destroy(self._h))
 

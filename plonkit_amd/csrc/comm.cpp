@@ -13,6 +13,7 @@
 // the hub accepts any local process that connects and names a free rank (no authentication, no encryption, loopback only).
 #include "ctx.h"
 #include "comm.h"
+#include "msm.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <arpa/inet.h>
@@ -47,6 +48,7 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                       // optional: the watchdog's way out
     ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr; // optional
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;         // optional: how many ranks RCCL itself sees (bench line)
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -71,14 +73,24 @@ Rccl *rccl() {
         r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(r.so, "ncclRecv"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.so, "ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.so, "ncclGroupEnd"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.so, "ncclCommCount"));
         if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { dlclose(r.so); r.so = nullptr; }
     });
     return r.so ? &r : nullptr;
 }
 
+// The host driver of this pool (and of any amdgpu that only supports dmabuf IPC) needs HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment BEFORE
+// the process' first HIP call, or RCCL fails between processes with `hipIpcGetMemHandle: invalid argument` — the CLI, bench.py and sharded.py set
+// it; a C-ABI embedder has to.  The library cannot set it late, so it says so where the failure surfaces.
+std::string ipc_hint() {
+    const char *e = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+    if (e && !strcmp(e, "0")) return "";
+    return " (HSA_ENABLE_IPC_MODE_LEGACY is not 0 in this process: on dmabuf-only drivers RCCL fails between processes with "
+           "`hipIpcGetMemHandle: invalid argument` unless it is set before the first HIP call)";
+}
 int32_t rccl_fail(ncclResult_t e, const char *what) {
     Rccl *R = rccl();
-    set_error(std::string("RCCL: ") + what + ": " + (R && R->GetErrorString ? R->GetErrorString(e) : "error") );
+    set_error(std::string("RCCL: ") + what + ": " + (R && R->GetErrorString ? R->GetErrorString(e) : "error") + ipc_hint());
     return PLK_ERR_HIP;
 }
 
@@ -110,6 +122,13 @@ long comm_test_stall_ms() {
 __global__ void comm_test_stall_kernel(unsigned long long ticks) {           // wall_clock64: constant 100 MHz counter
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+// plk_comm_scatter_selftest: n scalars (8 words each, < 2^252) that depend on `salt`
+__global__ void comm_test_fill_kernel(uint32_t *v, uint64_t n, uint32_t salt) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x = (uint32_t)i * 0x9e3779b9u + salt * 0x85ebca6bu + 0x27d4eb2fu;
+    for (int k = 0; k < 8; k++) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; v[8 * i + k] = k == 7 ? (x & 0x0fffffffu) : x; }
 }
 // PLK_SHARD_MODE=scatter: communicators start in owner-computes mode (every rank must agree); plk_comm_set_mode overrides
 bool shard_mode_default() { const char *e = getenv("PLK_SHARD_MODE"); return e && !strcmp(e, "scatter"); }
@@ -154,6 +173,7 @@ struct Comm {
     void *h_hdr = nullptr;                   // page-locked home of the batch header, apart from h_pin: the owner's header copy is asynchronous and may still be
                                              // pending (its stream waits for the prover's) when the batch's gather stages its partial sums in h_pin
     std::vector<char> h_stage;               // TCP transport of the slices (test tier)
+    bool self_loop = false;                  // plk_comm_scatter_selftest: rank 0 is also the recipient of its own share (the RCCL branch on one GPU)
     uint64_t seq = 0;                        // batches sent / received (both sides count: a header out of step is a protocol error)
     bool dead = false;                       // the watchdog aborted the communicator: every later exchange fails at once
     bool leak = false;                       // ... and could not abort the collective: stream and buffers are abandoned, not freed
@@ -340,39 +360,53 @@ static uint64_t share_of(uint64_t n, uint64_t slice, int rank) {
 int32_t comm_send_work(plk_ctx *ctx, const void *const *vecs, uint32_t count, uint64_t n, uint64_t slice, bool lagrange, hipStream_t producer) {
     Comm *C = static_cast<Comm *>(ctx->comm);
     if (count == 0 || count > 8) { set_error("scatter: batch must be 1..8"); return PLK_ERR_ARG; }
+    if (slice == 0) { set_error("scatter: no key resident on the owner"); return PLK_ERR_SRS; }
     PLK_TRY(scatter_ready(C));
+    // (arguments are checked before anything is counted or posted: a call that fails without reaching the wire must leave the owner's
+    //  sequence number where the workers' is — the next valid batch would otherwise be refused as "header out of step")
     ShardHeader h{};
     h.magic = SHARD_MAGIC; h.op = SHARD_COMMIT; h.count = count; h.lagrange = lagrange ? 1 : 0;
-    h.n = n; h.slice = slice; h.seq = ++C->seq;
-    if (h.slice == 0) { set_error("scatter: no key resident on the owner"); return PLK_ERR_SRS; }
+    h.n = n; h.slice = slice; h.seq = C->seq + 1;
     if (C->tcp) {                                                    // test tier: through host memory
         PLK_HIP(hipStreamSynchronize(producer));
         PLK_TRY(send_header(C, h));
+        C->seq++;
         for (int r = 1; r < C->world; r++) {
             const uint64_t len = share_of(n, h.slice, r);
             if (!len) continue;
             C->h_stage.resize((size_t)len * 32);
             for (uint32_t k = 0; k < count; k++) {
                 PLK_HIP(hipMemcpy(C->h_stage.data(), static_cast<const char *>(vecs[k]) + (size_t)r * h.slice * 32, (size_t)len * 32, hipMemcpyDeviceToHost));
-                if (!send_all(C->fds[r], C->h_stage.data(), (size_t)len * 32)) { set_error("tcp scatter: a rank went away"); return PLK_ERR_IO; }
+                if (!send_all(C->fds[r], C->h_stage.data(), (size_t)len * 32)) { C->dead = true; set_error("tcp scatter: a rank went away"); return PLK_ERR_IO; }
             }
         }
         return PLK_OK;
     }
     Rccl *R = rccl();
-    PLK_HIP(hipEventRecord(C->ev, producer));                        // the scalars are still being written on the prover's stream
-    PLK_HIP(hipStreamWaitEvent(C->stream, C->ev, 0));
+    // the scalars are still being written on the prover's stream: everything posted below waits for an event recorded behind them
+    // (PLK_COMM_TEST_SKIP_PRODUCER_WAIT=1, TEST HOOK of plk_comm_scatter_selftest's negative control, leaves the wait out)
+    static const bool skip_wait = [] { const char *e = getenv("PLK_COMM_TEST_SKIP_PRODUCER_WAIT"); return e && e[0] == '1'; }();
+    PLK_HIP(hipEventRecord(C->ev, producer));
+    if (!skip_wait) PLK_HIP(hipStreamWaitEvent(C->stream, C->ev, 0));
     PLK_TRY(send_header(C, h));
+    C->seq++;                                                        // the header is on the wire: from here on a failure kills the communicator
+    uint64_t self_len = 0;
+    if (C->self_loop) {                                              // one GPU: rank 0 receives its own share (send and receive in ONE group)
+        self_len = share_of(n, h.slice, 0);
+        if (C->d_work.reserve((size_t)count * self_len * 32) != PLK_OK) { C->dead = true; return PLK_ERR_HIP; }
+    }
     ncclResult_t e = R->GroupStart();
-    if (e != ncclSuccess) return rccl_fail(e, "ncclGroupStart");
-    for (int r = 1; r < C->world && e == ncclSuccess; r++) {
+    if (e != ncclSuccess) { C->dead = true; return rccl_fail(e, "ncclGroupStart"); }
+    for (int r = C->self_loop ? 0 : 1; r < (C->self_loop ? 1 : C->world) && e == ncclSuccess; r++) {
         const uint64_t len = share_of(n, h.slice, r);
-        for (uint32_t k = 0; k < count && len && e == ncclSuccess; k++)
+        for (uint32_t k = 0; k < count && len && e == ncclSuccess; k++) {
             e = R->Send(static_cast<const char *>(vecs[k]) + (size_t)r * h.slice * 32, (size_t)len * 32, ncclUint8, r, C->nccl, C->stream);
+            if (C->self_loop && e == ncclSuccess) e = R->Recv(static_cast<char *>(C->d_work.p) + (size_t)k * len * 32, (size_t)len * 32, ncclUint8, 0, C->nccl, C->stream);
+        }
     }
     const ncclResult_t e2 = R->GroupEnd();
-    if (e != ncclSuccess) return rccl_fail(e, "ncclSend (scalar slices)");
-    if (e2 != ncclSuccess) return rccl_fail(e2, "ncclGroupEnd");
+    if (e != ncclSuccess) { C->dead = true; return rccl_fail(e, "ncclSend (scalar slices)"); }
+    if (e2 != ncclSuccess) { C->dead = true; return rccl_fail(e2, "ncclGroupEnd"); }
     return PLK_OK;                                                   // (not waited for: the batch's all-gather follows on the same stream)
 }
 
@@ -381,7 +415,8 @@ int32_t comm_recv_work(plk_ctx *ctx, ShardWork *w, hipStream_t consumer) {
     PLK_TRY(scatter_ready(C));
     ShardHeader h{};
     PLK_TRY(recv_header(C, &h));
-    if (h.magic != SHARD_MAGIC || (h.op != SHARD_COMMIT && h.op != SHARD_STOP) || h.seq != ++C->seq) { set_error("scatter: batch header out of step (do all ranks run the same mode?)"); return PLK_ERR_IO; }
+    // (self loop: the same process already counted this batch when it sent it)
+    if (h.magic != SHARD_MAGIC || (h.op != SHARD_COMMIT && h.op != SHARD_STOP) || h.seq != (C->self_loop ? C->seq : ++C->seq)) { set_error("scatter: batch header out of step (do all ranks run the same mode?)"); return PLK_ERR_IO; }
     *w = ShardWork();
     w->op = h.op;
     if (h.op == SHARD_STOP) return PLK_OK;
@@ -400,12 +435,14 @@ int32_t comm_recv_work(plk_ctx *ctx, ShardWork *w, hipStream_t consumer) {
         return PLK_OK;
     }
     Rccl *R = rccl();
-    ncclResult_t e = R->GroupStart();
-    if (e != ncclSuccess) return rccl_fail(e, "ncclGroupStart");
-    for (uint32_t k = 0; k < h.count && e == ncclSuccess; k++) e = R->Recv(const_cast<void *>(w->vec[k]), (size_t)w->len * 32, ncclUint8, 0, C->nccl, C->stream);
-    const ncclResult_t e2 = R->GroupEnd();
-    if (e != ncclSuccess) return rccl_fail(e, "ncclRecv (scalar slices)");
-    if (e2 != ncclSuccess) return rccl_fail(e2, "ncclGroupEnd");
+    if (!C->self_loop) {                                             // (self loop: the receives were posted in the sender's group)
+        ncclResult_t e = R->GroupStart();
+        if (e != ncclSuccess) return rccl_fail(e, "ncclGroupStart");
+        for (uint32_t k = 0; k < h.count && e == ncclSuccess; k++) e = R->Recv(const_cast<void *>(w->vec[k]), (size_t)w->len * 32, ncclUint8, 0, C->nccl, C->stream);
+        const ncclResult_t e2 = R->GroupEnd();
+        if (e != ncclSuccess) return rccl_fail(e, "ncclRecv (scalar slices)");
+        if (e2 != ncclSuccess) return rccl_fail(e2, "ncclGroupEnd");
+    }
     PLK_HIP(hipEventRecord(C->ev, C->stream));                       // the commitment's kernels read the slices on the consumer's stream
     PLK_HIP(hipStreamWaitEvent(consumer, C->ev, 0));
     return PLK_OK;
@@ -415,8 +452,9 @@ int32_t comm_send_stop(plk_ctx *ctx) {
     Comm *C = static_cast<Comm *>(ctx->comm);
     PLK_TRY(scatter_ready(C));
     ShardHeader h{};
-    h.magic = SHARD_MAGIC; h.op = SHARD_STOP; h.seq = ++C->seq;
+    h.magic = SHARD_MAGIC; h.op = SHARD_STOP; h.seq = C->seq + 1;
     PLK_TRY(send_header(C, h));
+    C->seq++;
     if (!C->tcp) PLK_TRY(watch_exchange(C, C->stream));
     return PLK_OK;
 }
@@ -519,8 +557,9 @@ int32_t plk_comm_scatter_host(void *comm, const void *const *vecs, uint32_t coun
     if (C->rank == 0) {
         if (count && (!vecs || slice == 0)) { set_error("plk_comm_scatter_host: bad argument"); return PLK_ERR_ARG; }
         ShardHeader h{};
-        h.magic = SHARD_MAGIC; h.op = count ? SHARD_COMMIT : SHARD_STOP; h.count = count; h.n = n; h.slice = slice; h.seq = ++C->seq;
+        h.magic = SHARD_MAGIC; h.op = count ? SHARD_COMMIT : SHARD_STOP; h.count = count; h.n = n; h.slice = slice; h.seq = C->seq + 1;
         PLK_TRY(send_header(C, h));
+        C->seq++;
         for (int r = 1; r < C->world && count; r++) {
             const uint64_t len = share_of(n, slice, r);
             for (uint32_t k = 0; k < count && len; k++)
@@ -560,7 +599,14 @@ int32_t plk_comm_init_tcp(plk_ctx *ctx, int32_t rank, int32_t world, uint16_t po
 
 int32_t plk_comm_set_mode(plk_ctx *ctx, int32_t mode) {
     if (!ctx || !ctx->comm || (mode != PLK_SHARD_REPLICATE && mode != PLK_SHARD_SCATTER)) { set_error("plk_comm_set_mode: no communicator on this context, or an unknown mode"); return PLK_ERR_ARG; }
-    static_cast<Comm *>(ctx->comm)->scatter = mode == PLK_SHARD_SCATTER;
+    Comm *C = static_cast<Comm *>(ctx->comm);
+    if (mode == PLK_SHARD_SCATTER && !C->tcp && C->world > 1 && !C->scatter) {
+        // EXPERIMENTAL between GPUs (no multi-GPU node has run it: DESIGN.md section 6): every point-to-point piece of the mode once — a collective,
+        // like this call (every rank switches modes) — before the mode is trusted; a communicator that cannot do it stays in replicate mode
+        const int32_t rc = plk_comm_selftest(ctx);
+        if (rc != PLK_OK) { const std::string why = plk_last_error(); set_error("plk_comm_set_mode: owner-computes mode refused, its transport failed the self-test: " + why); return rc; }
+    }
+    C->scatter = mode == PLK_SHARD_SCATTER;
     return PLK_OK;
 }
 
@@ -608,6 +654,68 @@ int32_t plk_comm_selftest(plk_ctx *ctx) {
     if (memcmp(back, &hd, sizeof hd) != 0) { set_error("plk_comm_selftest: the broadcast header arrived changed"); return PLK_ERR_IO; }
     for (size_t i = 0; i < WORDS; i++)
         if (got[i] != word(prev, i)) { set_error("plk_comm_selftest: the ring step delivered other bytes than rank " + std::to_string(prev) + " sent"); return PLK_ERR_IO; }
+    return PLK_OK;
+}
+
+// The scatter step of owner-computes mode through the REAL RCCL branch on one GPU (round 6; the TCP tier of the tests synchronises the
+// producer before it copies, so it cannot see a missing wait): `iterations` times, a vector of 2^log_n scalars is (re)written on the
+// context's stream BEHIND a kernel that parks it for ~0.2 ms — the scalars are still being written when comm_send_work is called, as the
+// prover's are —, sent through comm_send_work (event hand-off, header broadcast, grouped ncclSend; the communicator in self-loop: rank 0
+// receives its own share inside the same group) and received through comm_recv_work (header check, event hand-off to the consumer's
+// stream); the commitment of what arrived must equal the commitment of the vector itself.  *mismatches counts the iterations where it does
+// not (a stale vector: with PLK_COMM_TEST_SKIP_PRODUCER_WAIT=1, the negative control, every one).  World 1, RCCL transport, key of >= 2^log_n points.
+int32_t plk_comm_scatter_selftest(plk_ctx *ctx, uint32_t log_n, uint32_t iterations, uint32_t *mismatches) {
+    Comm *C = ctx ? static_cast<Comm *>(ctx->comm) : nullptr;
+    if (!C || C->tcp || C->world != 1 || !mismatches || log_n > 24) { set_error("plk_comm_scatter_selftest: needs an RCCL communicator of ONE rank on this context (plk_comm_init) and log_n <= 24"); return PLK_ERR_ARG; }
+    const uint64_t n = 1ull << log_n;
+    if (!ctx->srs || ctx->srs_n < n) { set_error("plk_comm_scatter_selftest: the resident key is shorter than 2^log_n"); return PLK_ERR_SRS; }
+    if (ctx->msm_enq != ctx->msm_fin) { set_error("plk_comm_scatter_selftest: a commitment is still in flight"); return PLK_ERR_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    *mismatches = 0;
+    DevBuf v;
+    PLK_TRY(v.reserve(n * 32));
+    hipStream_t consumer = nullptr;
+    PLK_HIP(hipStreamCreateWithFlags(&consumer, hipStreamNonBlocking));
+    const bool keep_scatter = C->scatter;
+    C->self_loop = true;
+    int32_t rc = PLK_OK;
+    for (uint32_t it = 0; it < iterations && rc == PLK_OK; it++) {
+        hipLaunchKernelGGL(comm_test_stall_kernel, dim3(1), dim3(1), 0, ctx->stream, 20000ull);                 // 0.2 ms at 100 MHz
+        hipLaunchKernelGGL(comm_test_fill_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, v.as<uint32_t>(), n, it + 1);
+        const void *vec = v.p;
+        rc = comm_send_work(ctx, &vec, 1, n, n, false, ctx->stream);
+        ShardWork w;
+        if (rc == PLK_OK) rc = comm_recv_work(ctx, &w, consumer);
+        if (rc == PLK_OK && (w.op != SHARD_COMMIT || w.count != 1 || w.len != n)) { set_error("plk_comm_scatter_selftest: the batch arrived changed"); rc = PLK_ERR_IO; }
+        host::HJac got, want;
+        if (rc == PLK_OK) rc = msm_enqueue(ctx, static_cast<const Fr *>(w.vec[0]), n, 0, consumer);
+        if (rc == PLK_OK) rc = msm_finish(ctx, nullptr, &got);
+        if (rc == PLK_OK) rc = msm_enqueue(ctx, v.as<Fr>(), n, 0, ctx->stream);
+        if (rc == PLK_OK) rc = msm_finish(ctx, nullptr, &want);
+        if (rc == PLK_OK) {
+            const host::HAffine a = host::jac_to_affine(got), b = host::jac_to_affine(want);
+            if (memcmp(a.x.l, b.x.l, 32) != 0 || memcmp(a.y.l, b.y.l, 32) != 0) ++*mismatches;
+        }
+    }
+    C->self_loop = false;
+    C->scatter = keep_scatter;
+    (void)hipStreamSynchronize(consumer);
+    (void)hipStreamDestroy(consumer);
+    (void)hipStreamSynchronize(ctx->stream);
+    v.release();
+    return rc;
+}
+
+// how many ranks RCCL itself counts in this context's communicator (ncclCommCount) — what a multi-GPU bench line prints beside `n_gpus`,
+// so that a reader can tell N ranks joined by RCCL from N ranks that fell back to another carrier; 0 without an RCCL communicator
+int32_t plk_comm_nccl_count(const plk_ctx *ctx, int32_t *count) {
+    if (!ctx || !count) { set_error("plk_comm_nccl_count: bad argument"); return PLK_ERR_ARG; }
+    *count = 0;
+    const Comm *C = static_cast<const Comm *>(ctx->comm);
+    Rccl *R = rccl();
+    if (!C || C->tcp || !C->nccl || !R || !R->CommCount) return PLK_OK;
+    int k = 0;
+    if (R->CommCount(C->nccl, &k) == ncclSuccess) *count = k;
     return PLK_OK;
 }
 

@@ -131,6 +131,7 @@ struct plk_ctx {
     uint64_t shard_first = 0;
     plk_combine_fn combine = nullptr;
     void *combine_user = nullptr;
+    uint32_t scatter_open = 0;               // owner-computes mode: vectors of the batch already sent to the workers whose all-gather has not run yet (prover.hip)
     void *comm = nullptr;                    // built-in communicator (plk_comm_init / _tcp, comm.cpp), or null
     std::vector<plk::host::HJac> commit_pieces;   // partial sums of a commitment longer than one MSM call (prover.hip)
     std::vector<plk::host::HJac> commit_done;     // finished commitments of a batch that is processed one at a time

@@ -99,6 +99,7 @@ static int32_t commit_begin(plk_ctx *ctx, const Fr *const *vecs, uint32_t count,
     if (comm_scatter_owner(ctx)) {
         if (ctx->shard_first != 0) { set_error("scatter mode: the owner (rank 0) must hold the first slice of the key"); return PLK_ERR_ARG; }
         PLK_TRY(comm_send_work(ctx, reinterpret_cast<const void *const *>(vecs), count, n, ctx->srs_n, lagrange, ctx->stream));
+        ctx->scatter_open = count;                                // the workers now sit in this batch's all-gather: it MUST be run (commit_end, or the FIFO guard)
     }
     // at the largest sizes a batch of commitments would need gigabytes of per-task partial-sum slots (2^26 gates: 16 GiB for
     // four wires, which is what stands between that domain and the 288 GB): one commitment at a time there
@@ -125,6 +126,7 @@ static int32_t commit_end(plk_ctx *ctx, uint32_t count, HAffine *out) {
         plk_g1_jacobian raw[8];
         for (uint32_t k = 0; k < count; k++) { memcpy(raw[k].x, j[k].x.l, 32); memcpy(raw[k].y, j[k].y.l, 32); memcpy(raw[k].z, j[k].z.l, 32); }
         set_error("");
+        ctx->scatter_open = 0;
         const int32_t rc = ctx->combine(ctx->combine_user, raw, count);
         if (rc != PLK_OK) {                                        // (the built-in combiner says why: keep its words)
             const std::string why = plk_last_error();
@@ -192,6 +194,18 @@ struct FifoGuard {
             set_error(keep);
         }
         ctx->commit_done.clear(); ctx->commit_pieces.clear();
+        // Owner-computes mode: a batch went out to the workers (commit_begin) and the call is returning without commit_end — "must satisfy",
+        // a failed PLK_TRY in between.  The workers are committing their slices and will enter the batch's all-gather; if the owner never does,
+        // they sit there for the exchange deadline (180 s) and the owner's next broadcast meets their all-gather as a mismatched collective.
+        // Run the exchange with empty sums (nobody reads the result): owner and workers stay in step, the communicator stays usable.
+        if (ctx->scatter_open && ctx->combine) {
+            const std::string keep = plk_last_error();
+            plk_g1_jacobian raw[8];
+            memset(raw, 0, sizeof raw);
+            (void)ctx->combine(ctx->combine_user, raw, ctx->scatter_open);
+            set_error(keep);
+        }
+        ctx->scatter_open = 0;
     }
 };
 

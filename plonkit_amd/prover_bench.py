@@ -87,6 +87,92 @@ def cli_whole(log_n, runs=3):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def _run_timed(cmd, env=None, timeout=900):
+    import subprocess
+    t0 = time.perf_counter()
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    dt = time.perf_counter() - t0
+    if p.returncode != 0:
+        raise RuntimeError("%s exited %d: %s" % (" ".join(cmd[:2]), p.returncode, p.stderr[-300:]))
+    return dt, p.stderr
+
+
+def cli_table(log_n, circuit_files=None, key_log_n=None):
+    """Whole-PROCESS wall clock of every command of the reference's CI sequence (.github/workflows/integration-test.yml:105-154), in its order:
+    setup, export-verification-key, prove, dump-lagrange, prove -l, verify — this package's `plonkit` binary (C ABI only), files in /dev/shm.
+    `prove` is the median of three; the others run once.  circuit_files = (r1cs bytes, wtns bytes) of another circuit (the CI proves a 2^12-domain
+    Poseidon circuit against the 2^20 key: key_log_n = 20); default: the synthetic 2^log_n circuit against a key of its own size."""
+    import os
+    import re
+    import shutil
+    import tempfile
+    cli = os.path.join(os.path.dirname(_lib.lib_path()), "plonkit")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="plonkit_cli_", dir=base)
+    f = lambda name: os.path.join(d, name)
+    try:
+        if circuit_files is None:
+            circ = _lib.Circuit.synthetic((1 << log_n) - 2)
+            r1cs, wtns = circ.export("r1cs"), circ.export("wtns")
+            circ.close()
+        else:
+            r1cs, wtns = circuit_files
+        open(f("circuit.r1cs"), "wb").write(r1cs); open(f("witness.wtns"), "wb").write(wtns)
+        env = dict(os.environ, PLK_CLI_TIMING="1")
+        out = {"domain": 1 << log_n, "key_points": 1 << (key_log_n or log_n)}
+        out["setup_s"] = round(_run_timed([cli, "setup", "-p", str(key_log_n or log_n), "-m", f("key.bin"), "--overwrite"])[0], 3)
+        out["export_verification_key_s"] = round(_run_timed([cli, "export-verification-key", "-m", f("key.bin"), "-c", f("circuit.r1cs"), "-v", f("vk.bin"), "--overwrite"])[0], 3)
+        prove = [cli, "prove", "-m", f("key.bin"), "-c", f("circuit.r1cs"), "-w", f("witness.wtns"), "-p", f("proof.bin"), "-j", f("proof.json"), "-i", f("public.json"), "--overwrite"]
+        res = sorted((_run_timed(prove, env) for _ in range(3)), key=lambda r: r[0])
+        out["prove_s"], out["prove_s_min"], out["prove_s_max"] = round(res[1][0], 3), round(res[0][0], 3), round(res[2][0], 3)
+        phases = {}
+        for ln in res[1][1].splitlines():
+            m = re.match(r"\[timing\]\s+(.*?)\s+\+([0-9.]+) s", ln)            # "[timing] <phase, may contain '+'>   +0.123 s (total)"
+            if m:
+                phases[m.group(1).strip()] = float(m.group(2))
+        out["prove_phases_s"] = phases
+        proof = open(f("proof.bin"), "rb").read()
+        out["dump_lagrange_s"] = round(_run_timed([cli, "dump-lagrange", "-m", f("key.bin"), "-l", f("key_lagrange.bin"), "-c", f("circuit.r1cs"), "--overwrite"])[0], 3)
+        out["prove_l_s"] = round(_run_timed(prove[:4] + ["-l", f("key_lagrange.bin")] + prove[4:], env)[0], 3)
+        out["prove_l_same_bytes"] = open(f("proof.bin"), "rb").read() == proof
+        import subprocess
+        t0 = time.perf_counter()
+        ok = subprocess.call([cli, "verify", "-p", f("proof.bin"), "-v", f("vk.bin")], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 0
+        out["verify_s"] = round(time.perf_counter() - t0, 3)
+        out["verified"] = bool(ok)
+        out["files_MB"] = {"r1cs": round(len(r1cs) / 1e6, 1), "wtns": round(len(wtns) / 1e6, 1), "key": round(os.path.getsize(f("key.bin")) / 1e6, 1)}
+        out["where"] = base or "temp dir"
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def prove_row(ctx, circ, reps):
+    """one setup + `reps` warm proofs of `circ` on ctx (its key must be resident and large enough): median wall clock, the hbm fraction of
+    SURVEY.md 8(d)'s itemisation, setup time; returns (row, proof bytes)"""
+    t0 = time.perf_counter()
+    setup = _lib.SetupForProver(ctx, circ)
+    ctx.synchronize()
+    t_setup = time.perf_counter() - t0
+    n = setup.domain_size
+    proof = setup.prove(circ)
+    setup.prove(circ)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        p = setup.prove(circ)
+        ts.append(time.perf_counter() - t0)
+        assert p == proof
+    ts.sort()
+    wall = ts[len(ts) // 2]
+    vk = setup.verification_key_bytes(_lib.crs42_g2_bytes())
+    ok = _lib.verify(vk, proof)
+    setup.close()
+    b = prove_bytes(n, nonempty_commitments(proof))
+    return {"domain": n, "wall_s": round(wall, 5), "wall_s_min": round(ts[0], 5), "proofs_timed": reps, "setup_prepare_s": round(t_setup, 3),
+            "hbm_frac": round(b["survey"] / wall / HBM_PEAK_BS, 5), "commitments_nonempty": nonempty_commitments(proof), "verified": bool(ok)}, proof
+
+
 def cold(device, log_n, circ):
     """first proof of a process as a `plonkit prove` user meets it (the reference is always in this state: it passes
     `None` precomputations, src/plonk.rs:152-159): a fresh context with only the key resident — the fixed-base table of
