@@ -29,6 +29,9 @@ struct QuotientArgs {
     Fr *out;
     const Fr *w[4], *z, *q[7], *sigma[4], *pi, *l0, *x;
     Fr beta, gamma, alpha_pp, alpha2_w, beta_k[4], zh_inv_w[4];
+    // beta, alpha_pp and alpha2_w once more as mul_tw3 constants (field29_dev.h: three shifted copies, a product in 108 multiply-adds instead of 162):
+    // seven of the kernel's 24 products are by these three per-proof constants (round 6; filled by quotient() from the three fields above)
+    uint32_t beta3[27], alpha_pp3[27], alpha2_3[27];
     uint32_t m, log_m;                  // m = 4N
     // public inputs: PI(x) = sum_i in_i * L_i(x) and L_i(x) = L_0(x / omega^i), i.e. on the coset
     // PI[j] = sum_i in_i * L0[j - 4i]: with few inputs the kernel forms it from the cached L0 vector and no

@@ -339,13 +339,20 @@ __global__ void __launch_bounds__(PT) k_quotient(QuotientArgs a) {
         const uint32_t e = jnat << (MAX_LOG_N - a.log_m);
         x = mulw(mulw(ldw(a.tw_w.lo + (e & (POW_TAB - 1))), ldw(a.tw_w.hi + (e >> POW_SPLIT))), cw(a.coset_w));
     }
-    const FrW9 z = ldw(a.z + i), gamma = cw(a.gamma), beta = cw(a.beta);
+    const FrW9 z = ldw(a.z + i), gamma = cw(a.gamma);
+    // the per-proof constants as mul_tw3 operands (uniform: they sit in scalar registers); a mul_tw3 result is < 4p for a normalised operand —
+    // every use below adds it to something and normalises (well inside the 2^261 capacity), the last product of the kernel stays a mulw
+    Tw3<FrW> beta3, alpha_pp3, alpha2_3;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int l = 0; l < 9; l++) { beta3.w[q][l] = a.beta3[9 * q + l]; alpha_pp3.w[q][l] = a.alpha_pp3[9 * q + l]; alpha2_3.w[q][l] = a.alpha2_3[9 * q + l]; }
     FrW9 pa = z, pb = ldw(a.z + nxt);
     // beta * k_j * x for the coset representatives k = (1, 5, 7, 10) (prover.hip NON_RESIDUES): ONE product
     // beta * x and three small multiples formed limb-wise (5 = 4 + 1, 7 = 8 - 1, 10 = 2 * 5; limbs stay below 2^32) instead
     // of four products
     FrW9 bkx[4];
-    bkx[0] = mulw(x, beta);
+    bkx[0] = mul_tw3(x, beta3);                                  // (< 4p; the multiples below < 40p)
     {
         FrW9 t5, t7;
 #pragma unroll
@@ -360,10 +367,10 @@ __global__ void __launch_bounds__(PT) k_quotient(QuotientArgs a) {
         constexpr int j = decltype(J)::value;
         const FrW9 wg = addn(w[j], gamma);
         pa = mulw(pa, addn(wg, bkx[j]));
-        pb = mulw(pb, addn(wg, mulw(ldw(a.sigma[j] + i), beta)));
+        pb = mulw(pb, addn(wg, mul_tw3(ldw(a.sigma[j] + i), beta3)));
     });
-    FrW9 t = addn(g, mulw(cw(a.alpha_pp), sub2(pa, pb)));
-    t = addn(t, mulw(cw(a.alpha2_w), mulw(ldw(a.l0 + i), sub2(z, cw(Fr::one())))));
+    FrW9 t = addn(g, mul_tw3(sub2(pa, pb), alpha_pp3));
+    t = addn(t, mul_tw3(mulw(ldw(a.l0 + i), sub2(z, cw(Fr::one()))), alpha2_3));
     Fr zh_inv = a.zh_inv_w[0];
 #pragma unroll
     for (uint32_t c = 1; c < 4; c++) if (kc == c) zh_inv = a.zh_inv_w[c];
@@ -541,7 +548,14 @@ int32_t coset_points_w(Fr *out, const PowTable &tw_w, uint32_t log_m, const Fr &
     PLK_HIP(hipGetLastError());
     return PLK_OK;
 }
-int32_t quotient(const QuotientArgs &a, hipStream_t s) {
+int32_t quotient(const QuotientArgs &args, hipStream_t s) {
+    QuotientArgs a = args;
+    // the three shifted copies of each per-proof constant (make_tw3 runs on the host: six products of the 29-bit layer)
+    auto fill3 = [](uint32_t (&out)[27], const Fr &c) {
+        const Tw3<FrW> t = make_tw3(unpack<FrW>(c));
+        for (int q = 0; q < 3; q++) for (int l = 0; l < 9; l++) out[9 * q + l] = t.w[q][l];
+    };
+    fill3(a.beta3, a.beta); fill3(a.alpha_pp3, a.alpha_pp); fill3(a.alpha2_3, a.alpha2_w);
     hipLaunchKernelGGL(k_quotient, grid1(a.m), dim3(PT), 0, s, a);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
