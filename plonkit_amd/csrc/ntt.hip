@@ -43,6 +43,7 @@ namespace plk {
 
 constexpr int NTT_THREADS = 512;               // 8 waves per workgroup, 2 workgroups per CU (LDS): 4 waves per SIMD
 constexpr int LOG_TILE = 11;                   // 2048 elements per workgroup
+constexpr int LOG_SINGLE = 11;                 // largest transform done by one workgroup in one pass (ntt_pass_rows)
 
 constexpr uint32_t NTT_MAX_BATCH = 16;         // transforms of equal shape sharing one launch per pass (blockIdx.y)
 struct NttPassArgs {
@@ -744,7 +745,10 @@ template <int LR> static hipError_t ntt_w_attr() {
 static void digit_plan(uint32_t log_n, uint32_t d[4], uint32_t *passes) {
     d[0] = d[1] = d[2] = d[3] = 0;
     uint32_t p = 1;
-    if (log_n <= LOG_TILE) d[0] = log_n;
+    // one pass — ONE workgroup holds the whole transform in LDS — up to 2^11 points.  2^12 points in one workgroup (147 KB of the CU's 160 KB, the kernel
+    // handles it) was tried in round 6 and is SLOWER than two passes of two workgroups: 62 against 37 us per transform, same box (six rounds of two
+    // radix-4 groups per thread on one CU against two launches of three rounds on two)
+    if (log_n <= LOG_SINGLE) d[0] = log_n;
     else {
         p = (log_n + 9) / 10;                              // up to 10 bits per pass: 2^20 = 10 + 10 (two passes)
         for (uint32_t i = 0; i < p; i++) d[i] = log_n / p + (i < log_n % p ? 1 : 0);
@@ -792,7 +796,7 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
     if (log_n == 0) return PLK_OK;
     PLK_TRY(ntt_init_tables(ctx));
     if (!g_attr_set) {
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 36 << LOG_SINGLE));
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_cols), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         PLK_HIP(ntt_w_attr<7>()); PLK_HIP(ntt_w_attr<8>()); PLK_HIP(ntt_w_attr<9>()); PLK_HIP(ntt_w_attr<10>());
         g_attr_set = true;
@@ -805,7 +809,7 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
     uint32_t d[4], p;
     digit_plan(log_n, d, &p);
     const size_t n = (size_t)1 << log_n;
-    PLK_TRY(ctx->ntt_scratch[lane].reserve((size_t)count * n * sizeof(Fr)));
+    if (p > 1) PLK_TRY(ctx->ntt_scratch[lane].reserve((size_t)count * n * sizeof(Fr)));
     Fr *const scratch = ctx->ntt_scratch[lane].as<Fr>();
 
     NttPassArgs a{};
@@ -833,7 +837,9 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
         else hipLaunchKernelGGL(ntt_pass_cols, dim3(tiles, count), dim3(NTT_THREADS), lds, stream, a);
     }
     {
-        for (uint32_t b = 0; b < count; b++) { a.in_b[b] = (p == 1) ? src[b] : scratch + (size_t)b * n; a.out_b[b] = (p == 1) ? scratch + (size_t)b * n : data[b]; }
+        // (a single pass is one workgroup per transform that has read ALL of its input into LDS — a barrier — before its first store: in place is safe,
+        //  no detour through the scratch buffer and no copy launch behind it)
+        for (uint32_t b = 0; b < count; b++) { a.in_b[b] = (p == 1) ? src[b] : scratch + (size_t)b * n; a.out_b[b] = data[b]; }
         a.nonzero = (p == 1) ? (uint32_t)nonzero : 0;
         a.log_r = d[p - 1];
         if (p == 1) { a.log_r1 = 0; a.log_m1 = a.log_m2 = 0; a.log_c = 0; }
@@ -855,7 +861,6 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
         else hipLaunchKernelGGL(ntt_pass_rows, dim3(tiles, count), dim3(NTT_THREADS), lds, stream, a);
     }
     PLK_HIP(hipGetLastError());
-    if (p == 1) for (uint32_t b = 0; b < count; b++) PLK_HIP(hipMemcpyAsync(data[b], scratch + (size_t)b * n, n * sizeof(Fr), hipMemcpyDeviceToDevice, stream));
     return PLK_OK;
 }
 
