@@ -49,12 +49,13 @@ namespace plk {
 int32_t msm_small_launch(plk_ctx::MsmSlot &S, hipStream_t stream, const G1Affine *bases, uint32_t copy_stride, const ScalarSet &set,
                          uint32_t batch, uint32_t n, bool ev_on, void *host_out);
 constexpr uint32_t SM_PLANES_HOST = 17;
-// terms up to which a commitment takes it: 2^15 for one or two commitments per launch, 2^14 for a larger batch (measured, same box, one at a
-// time: 2^14 terms 0.29 against 0.62 ms, 2^15 0.43 against 0.53, 2^16 0.66 against 0.54; a batch of four 2^15-term commitments inside a proof
-// is a tie).  PLK_MSM_SMALL_MAX overrides (0 = never: A/B knob)
+// terms up to which a commitment takes it: 2^15 (measured, one at a time: 2^14 terms 0.27 against 0.62 ms, 2^15 0.35 against 0.53, 2^16 0.52 against
+// 0.54; a proof at the 2^15 domain 3.25 against 3.40 ms; at 2^16 a batch of two is SLOWER on this path — a proof 3.76 against 3.56 ms — and a batch
+// of four much slower: 4.85).  PLK_MSM_SMALL_MAX overrides (0 = never: A/B knob)
 static uint64_t msm_small_max(uint32_t batch) {
     static const long long v = [] { const char *e = getenv("PLK_MSM_SMALL_MAX"); return e ? (long long)strtoull(e, nullptr, 10) : -1ll; }();
-    return v >= 0 ? (uint64_t)v : (batch <= 2 ? (1ull << 15) : (1ull << 14));
+    (void)batch;
+    return v >= 0 ? (uint64_t)v : (1ull << 15);
 }
 
 // -------------------------------------------------------------------------- scalar recoding

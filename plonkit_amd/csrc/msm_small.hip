@@ -30,7 +30,12 @@ constexpr uint32_t SM_THREADS = 256;             // a workgroup owns ONE of the 
 // wants many short lists on all CUs (2^12 terms: 256 workgroups, ~6 additions deep) and a batch of them fewer, longer ones (less imbalance
 // between the lanes of a wave: the longest of 64 lists decides, and fewer partial sums for msm_small_fold).
 constexpr uint32_t SM_CH_MIN = 32, SM_CH_MAX = 128;
-static size_t sm_lds(uint32_t ch) { return (size_t)(SM_THREADS + SM_THREADS * (ch + 1)) * sizeof(uint32_t); }
+// slots per bucket list: a constant column puts `ch` entries into one bucket, which its two lists share — 64 slots each hold that for every chunk size
+// (128 equal scalars split 64 / 64 when the two-choice reads are fresh; if not, the overflow flag sends the commitment to the ordinary pipeline), and
+// keep the workgroup at 66 KB of LDS: two per CU, so that a SIMD's two waves average their longest lists instead of the launch waiting for one wave
+constexpr uint32_t SM_CAP_MAX = 64;
+static uint32_t sm_cap(uint32_t ch) { return ch < SM_CAP_MAX ? ch : SM_CAP_MAX; }
+static size_t sm_lds(uint32_t ch) { return (size_t)(SM_THREADS + SM_THREADS * (sm_cap(ch) + 1)) * sizeof(uint32_t); }
 
 __device__ __forceinline__ void small_chain_priority() { __builtin_amdgcn_s_setprio(3); }
 
@@ -51,12 +56,12 @@ __device__ __forceinline__ XyzzW sm_shfl_xor(const XyzzW &v, int mask) {
 // bucket the longest of the 65536 lists of a 2^12-term commitment held 10-11 entries against a mean of 1.9, and since every SIMD of the chip runs
 // exactly one wave of this kernel the longest list IS the kernel's duration (measured 73-80 us); two choices cut that tail.
 // bases = copy 0 of the fixed-base table at the commitment's first point; copy w lies w * copy_stride points on.
-__global__ void __launch_bounds__(SM_THREADS, 1) msm_small_accumulate(const G1Affine *bases, ScalarSet set, uint32_t n, uint32_t ch, uint32_t copy_stride,
+__global__ void __launch_bounds__(SM_THREADS, 2) msm_small_accumulate(const G1Affine *bases, ScalarSet set, uint32_t n, uint32_t ch, uint32_t cap, uint32_t copy_stride,
                                                                      XyzzW *partials, uint32_t *flag) {
     extern __shared__ uint32_t sm_lds_mem[];
     uint32_t *cnt = sm_lds_mem, *list = sm_lds_mem + SM_THREADS;
     const uint32_t tid = threadIdx.x, g = blockIdx.x >> 2, hi_set = blockIdx.x & 1, half = (blockIdx.x >> 1) & 1, m = blockIdx.y, first = g * ch;
-    const uint32_t stride = ch + 1;                            // (odd stride: the lanes' reads fall into different banks)
+    const uint32_t stride = cap + 1;                           // (odd stride: the lanes' reads fall into different banks)
     cnt[tid] = 0;
     __syncthreads();
     if (tid < ch && first + tid < n) {
@@ -73,12 +78,12 @@ __global__ void __launch_bounds__(SM_THREADS, 1) msm_small_accumulate(const G1Af
             uint32_t t = b & 127u;
             if (cnt[t + 128] < cnt[t]) t += 128;                            // (a stale read only makes the choice a little worse)
             const uint32_t pos = atomicAdd(&cnt[t], 1u);
-            if (pos < ch) list[t * stride + pos] = (d[w] < 0 ? 0x80000000u : 0u) | (w << 8) | tid;
+            if (pos < cap) list[t * stride + pos] = (d[w] < 0 ? 0x80000000u : 0u) | (w << 8) | tid;
         }
     }
     __syncthreads();
     uint32_t c = cnt[tid];
-    if (c > ch) { atomicOr(flag, 1u); c = ch; }
+    if (c > cap) { atomicOr(flag, 1u); c = cap; }
     const uint32_t *mine = list + tid * stride;
     auto point = [&](uint32_t e) __attribute__((always_inline)) { return bases + (size_t)((e >> 8) & 15u) * copy_stride + first + (e & 255u); };
     XyzzW acc = xyzzw_identity();
@@ -180,7 +185,7 @@ int32_t msm_small_launch(plk_ctx::MsmSlot &S, hipStream_t stream, const G1Affine
     G1Xyzz *planes = static_cast<G1Xyzz *>(host_out);
     PLK_HIP(hipMemsetAsync(flag, 0, 16, stream));
     if (ev_on) PLK_HIP(hipEventRecord(S.ev[0], stream));
-    hipLaunchKernelGGL(msm_small_accumulate, dim3(4 * G, batch), dim3(SM_THREADS), sm_lds(ch), stream, bases, set, n, ch, copy_stride, partials, flag);
+    hipLaunchKernelGGL(msm_small_accumulate, dim3(4 * G, batch), dim3(SM_THREADS), sm_lds(ch), stream, bases, set, n, ch, sm_cap(ch), copy_stride, partials, flag);
     if (ev_on) (void)hipEventRecord(S.ev[1], stream);
     (void)hipEventRecord(S.acc_done, stream);
     hipLaunchKernelGGL(msm_small_fold, dim3(SM_BUCKETS, batch), dim3(256), 0, stream, (const XyzzW *)partials, 2 * G, buckets);
