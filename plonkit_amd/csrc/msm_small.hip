@@ -104,24 +104,28 @@ __global__ void __launch_bounds__(SM_THREADS, 2) msm_small_accumulate(const G1Af
 // The two tree kernels run their full additions four lanes at a time (ec29_quad_dev.h: a quad of lanes shares one addition, four products
 // deep instead of fourteen): ~2.6 us per tree level instead of ~7.3.  One addition site per kernel (the operand is chosen beforehand).
 //
-// grid (512, batch), 256 threads = 64 quads: buckets[m][b] = sum of the G2 partial sums of bucket b (two per accumulate chunk: the bucket's
-// two lanes).  Quad q takes partial sums q, q + 64, .. one after the other, then a tree over the 16 quads of a wave (shuffles) and over the
-// four waves (LDS).
+// buckets[m][b] = sum of the G2 partial sums of bucket b (two per accumulate chunk: the bucket's two lanes).  Two shapes of one kernel:
+//   WIDE  (grid (512, batch), 256 threads = 64 quads per bucket): quad q takes partial sums q, q + 64, .. one after the other, then a tree over the 16 quads of a
+//         wave (shuffles) and over the four waves (LDS) — the shortest chain, for ONE commitment, where the chip is empty anyway;
+//   !WIDE (grid (128, batch), one wave = 16 quads per bucket, four buckets per workgroup): one step more (64 partial sums: 4 + 4 against 1 + 6) for a quarter of the
+//         waves — a batch of four commitments in the wide shape puts eight waves of these chains on every SIMD and ran 3x longer (172 against 49 us, round 6).
+template <bool WIDE>
 __global__ void __launch_bounds__(256) msm_small_fold(const XyzzW *partials, uint32_t G2, XyzzW *buckets) {
     __shared__ __attribute__((aligned(16))) XyzzW sh[4];
     small_chain_priority();
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, role = tid & 3, quad = tid >> 2, b = blockIdx.x, m = blockIdx.y;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, role = tid & 3, m = blockIdx.y;
+    const uint32_t b = WIDE ? blockIdx.x : blockIdx.x * 4 + wave, quad = WIDE ? tid >> 2 : lane >> 2, quads = WIDE ? 64 : 16;
     const XyzzW *P = partials + (size_t)m * G2 * SM_BUCKETS + b;
-    const uint32_t nseq = (G2 + 63) / 64, total = nseq + 4 + 2;
+    const uint32_t nseq = (G2 + quads - 1) / quads, total = nseq + 4 + (WIDE ? 2 : 0);
     XyzzW X = xyzzw_identity();
     for (uint32_t step = 0; step < total; step++) {
         XyzzW O = xyzzw_identity();
         if (step < nseq) {
-            const uint32_t g = quad + 64 * step;
+            const uint32_t g = quad + quads * step;
             if (g < G2) O = load_xyzzw(P + (size_t)g * SM_BUCKETS);
         } else {
             const uint32_t k = step - nseq;
-            if (k == 4) {                                     // the four waves' sums change hands through LDS; every wave then folds all four (same result)
+            if (WIDE && k == 4) {                             // the four waves' sums change hands through LDS; every wave then folds all four (same result)
                 if (lane == 0) sh[wave] = X;
                 __syncthreads();
                 X = (lane >> 2) < 4 ? sh[lane >> 2] : xyzzw_identity();
@@ -130,7 +134,7 @@ __global__ void __launch_bounds__(256) msm_small_fold(const XyzzW *partials, uin
         }
         X = xyzzw_add_quad(X, O, role);
     }
-    if (tid == 0) store_xyzzw(buckets + (size_t)m * SM_BUCKETS + b, X);
+    if (WIDE ? tid == 0 : lane == 0) store_xyzzw(buckets + (size_t)m * SM_BUCKETS + b, X);
 }
 
 // grid (17, batch), 512 threads = 128 quads.  Plane p < 8: bit p of the lo value; plane 8 + b: bit b of the hi value (b = 8: the one bucket hi = 256).
@@ -188,7 +192,8 @@ int32_t msm_small_launch(plk_ctx::MsmSlot &S, hipStream_t stream, const G1Affine
     hipLaunchKernelGGL(msm_small_accumulate, dim3(4 * G, batch), dim3(SM_THREADS), sm_lds(ch), stream, bases, set, n, ch, sm_cap(ch), copy_stride, partials, flag);
     if (ev_on) (void)hipEventRecord(S.ev[1], stream);
     (void)hipEventRecord(S.acc_done, stream);
-    hipLaunchKernelGGL(msm_small_fold, dim3(SM_BUCKETS, batch), dim3(256), 0, stream, (const XyzzW *)partials, 2 * G, buckets);
+    if (batch == 1) hipLaunchKernelGGL(msm_small_fold<true>, dim3(SM_BUCKETS, batch), dim3(256), 0, stream, (const XyzzW *)partials, 2 * G, buckets);
+    else hipLaunchKernelGGL(msm_small_fold<false>, dim3(SM_BUCKETS / 4, batch), dim3(256), 0, stream, (const XyzzW *)partials, 2 * G, buckets);
     hipLaunchKernelGGL(msm_small_planes, dim3(SM_PLANES, batch), dim3(512), 0, stream, (const XyzzW *)buckets, planes, (const uint32_t *)flag,
                        reinterpret_cast<uint32_t *>(planes + (size_t)batch * SM_PLANES), probe_extra);
     PLK_HIP(hipGetLastError());
