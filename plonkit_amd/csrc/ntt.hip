@@ -578,20 +578,50 @@ Fr cached_inverse(plk_ctx *ctx, const Fr &g) {
     return gi;
 }
 
-// four tables in ONE launch (round 4 of the prover needs z, 1/z, z*omega, 1/(z*omega): four launches of 42 us each were
-// pure latency — every thread is a dependent chain of <= 28 squarings)
-struct FourBases { Fr b[4]; Fr *buf[4]; };
-__global__ void fill_pow_tables4(FourBases a) {
+// four tables in ONE launch (round 4 of the prover needs z, 1/z, z*omega, 1/(z*omega): four launches of 42 us each were pure latency).
+// Round 6: every thread used to compute its entry base^e with its own square-and-multiply — a dependent chain of up to 28 products, 68 us of a
+// proof at EVERY domain size (4 % of a 2^12 proof).  The chain of squarings base^(2^j), j < 28, is the same for all threads of a table: the
+// host computes it (27 squarings of 30 ns) and hands it over as a kernel argument; an entry is then the product of the 14 squares its
+// exponent selects — a fixed tree of 13 independent-by-level products (a factor whose bit is clear is the Montgomery one: no divergence).
+// The products run on the 29-bit layer in lockstep pairs (mulw2).  Every mulw divides by 2^261, i.e. leaves 2^-5 relative to the R = 2^256 form the
+// squares come in; the tree has 13 products whatever the exponent, so ONE last product by `fix` = 2^(65 + 5 + 261) brings the result to base^e * 2^261
+// (the W domain the tables are read in) — 14 products of ~0.5 us per pair instead of up to 28 dependent ones of the 32-bit layer: 68 -> ~15 us.
+struct FourSquares { Fr sq[4][28]; Fr *buf[4]; Fr fix; };
+__global__ void fill_pow_tables4(FourSquares a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     if (i >= 2 * POW_TAB) return;
     Fr *lo = a.buf[k], *hi = lo + POW_TAB;
-    Fr v = i < POW_TAB ? pow_u64(a.b[k], i) : pow_u64(a.b[k], (uint64_t)(i - POW_TAB) << POW_SPLIT);
-    v = mul(v, from_u64<FrParams>(32));                             // W domain
-    store_fp(i < POW_TAB ? lo + i : hi + (i - POW_TAB), v);
+    const bool is_hi = i >= POW_TAB;
+    const uint32_t e = is_hi ? i - POW_TAB : i;                    // 14 bits; the hi table's exponents are e << 14: squares 14..27
+    FrW9 f[14];
+    const FrW9 one = unpack<FrW>(Fr::one());
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        const FrW9 q = unpack<FrW>(is_hi ? a.sq[k][14 + j] : a.sq[k][j]);
+        const uint32_t on = 0u - ((e >> j) & 1u);
+#pragma unroll
+        for (int l = 0; l < 9; l++) f[j].l[l] = (q.l[l] & on) | (one.l[l] & ~on);
+    }
+    FrW9 g[7];
+    mulw2(f[0], f[1], f[2], f[3], g[0], g[1]); mulw2(f[4], f[5], f[6], f[7], g[2], g[3]); mulw2(f[8], f[9], f[10], f[11], g[4], g[5]);
+    g[6] = mulw(f[12], f[13]);
+    FrW9 h0, h1, h2, h3;
+    mulw2(g[0], g[1], g[2], g[3], h0, h1);
+    mulw2(g[4], g[5], h0, h1, h2, h3);                            // h2 = g4 g5, h3 = (g0 g1)(g2 g3)
+    FrW9 v = mulw(mulw(h2, g[6]), h3);
+    v = csub_p(mulw(v, unpack<FrW>(a.fix)));
+    store_fp(is_hi ? hi + e : lo + e, pack<FrParams>(v));
 }
 int32_t fill_pow_tables4_into(plk_ctx *, const Fr bases[4], Fr *const bufs[4], PowTable out[4], hipStream_t s) {
-    FourBases a;
-    for (int k = 0; k < 4; k++) { a.b[k] = bases[k]; a.buf[k] = bufs[k]; out[k].lo = bufs[k]; out[k].hi = bufs[k] + POW_TAB; }
+    FourSquares a;
+    for (int k = 0; k < 4; k++) {
+        a.buf[k] = bufs[k]; out[k].lo = bufs[k]; out[k].hi = bufs[k] + POW_TAB;
+        host::HFr x; memcpy(x.l, bases[k].l, 32);                  // (same Montgomery representation on both sides: hostmath.h)
+        for (int j = 0; j < 28; j++) { memcpy(a.sq[k][j].l, x.l, 32); x = x.sqr(); }
+    }
+    // fix = 2^331 as a plain residue: 13 products x 2^-5, the last product's own 2^-261, and the W domain's 2^5 over R = 2^256
+    static const host::HFr fix = [] { host::HFr t = host::HFr::from_u64(2), r = host::HFr::one(); for (int b = 0; b < 331; b++) r = r * t; uint64_t c[4]; r.to_canonical(c); host::HFr o; memcpy(o.l, c, 32); return o; }();
+    memcpy(a.fix.l, fix.l, 32);
     hipLaunchKernelGGL(fill_pow_tables4, dim3(2 * POW_TAB / 256, 4), dim3(256), 0, s, a);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
