@@ -372,13 +372,15 @@ __device__ __forceinline__ void wave_round(FrW9 &x0, FrW9 &x1, FrW9 &x2, FrW9 &x
     }
 }
 
-template <int LR, bool ROWS>
-__global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_w(NttPassArgs a) {
-    using P = TilePlan<LR>;
+// LT = 11: a 2048-element tile owned by eight waves, two workgroups per CU; LT = 12 (round 6): a 4096-element tile owned by sixteen waves, one workgroup
+// per CU — 11-bit digits, so that a 2^21 / 2^22-point transform is two passes instead of three (ntt_plan.h).  Four waves per SIMD either way.
+template <int LR, bool ROWS, int LT = NTT_LOG_TILE>
+__global__ void __launch_bounds__(LT == NTT_LOG_TILE ? NTT_THREADS : 2 * NTT_THREADS, 4) ntt_pass_w(NttPassArgs a) {
+    using P = TilePlan<LR, LT>;
     constexpr uint32_t LC = P::LC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const LdsTile L{reinterpret_cast<u32x4 *>(smem), reinterpret_cast<u32x4 *>(smem) + NTT_W_SLOTS,
-                    reinterpret_cast<uint32_t *>(reinterpret_cast<u32x4 *>(smem) + 2 * NTT_W_SLOTS)};
+    const LdsTile L{reinterpret_cast<u32x4 *>(smem), reinterpret_cast<u32x4 *>(smem) + P::SLOTS,
+                    reinterpret_cast<uint32_t *>(reinterpret_cast<u32x4 *>(smem) + 2 * P::SLOTS)};
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, t = blockIdx.x;
     const Fr *const in = a.in_b[blockIdx.y];
     Fr *const out = a.out_b[blockIdx.y];
@@ -746,18 +748,30 @@ static std::atomic<bool> g_attr_set{false};                    // (several conte
 
 // the wave-owned passes (ntt_pass_w) take every full 2048-element tile of 7..10 row bits; PLK_NTT_WAVE=0 keeps the
 // barrier-per-round kernels for everything (A/B knob)
-constexpr size_t NTT_W_LDS = (size_t)36 * NTT_W_SLOTS;
+constexpr size_t NTT_W_LDS = (size_t)36 * NTT_W_SLOTS, NTT_W_LDS_BIG = (size_t)36 * NTT_W_SLOTS_BIG;
 static bool ntt_wave_enabled() {
     static const int on = [] { const char *e = getenv("PLK_NTT_WAVE"); return (e && e[0] == '0') ? 0 : 1; }();
     return on != 0;
 }
+// the 4096-element tile (2^21 / 2^22-point transforms in two passes); PLK_NTT_BIG_TILE=0: three passes of 2048-element tiles as before (A/B knob)
+static bool ntt_big_tile_enabled() {
+    static const int on = [] { const char *e = getenv("PLK_NTT_BIG_TILE"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0 && ntt_wave_enabled();
+}
 static bool ntt_wave_shape(const NttPassArgs &a) {
     // (zero-padded inputs are taken too — `quarter`, the old kernels' copy-instead-of-butterfly shortcut for them, is simply not used;
     //  their per-element coset tables are never combined with padding)
-    return ntt_wave_enabled() && a.log_r >= 7 && a.log_r <= 10 && a.log_r + a.log_c == LOG_TILE && !(a.nonzero && a.pre_direct_b[0]);
+    if (!ntt_wave_enabled() || (a.nonzero && a.pre_direct_b[0])) return false;
+    if (a.log_r + a.log_c == LOG_TILE) return a.log_r >= 7 && a.log_r <= 10;
+    return a.log_r + a.log_c == (uint32_t)NTT_LOG_TILE_BIG && a.log_r >= 10 && a.log_r <= 11 && ntt_big_tile_enabled();
 }
 template <bool ROWS>
 static void ntt_launch_w(const NttPassArgs &a, dim3 grid, hipStream_t stream) {
+    if (a.log_r + a.log_c == (uint32_t)NTT_LOG_TILE_BIG) {
+        if (a.log_r == 10) hipLaunchKernelGGL((ntt_pass_w<10, ROWS, NTT_LOG_TILE_BIG>), grid, dim3(2 * NTT_THREADS), NTT_W_LDS_BIG, stream, a);
+        else hipLaunchKernelGGL((ntt_pass_w<11, ROWS, NTT_LOG_TILE_BIG>), grid, dim3(2 * NTT_THREADS), NTT_W_LDS_BIG, stream, a);
+        return;
+    }
     switch (a.log_r) {
         case 7: hipLaunchKernelGGL((ntt_pass_w<7, ROWS>), grid, dim3(NTT_THREADS), NTT_W_LDS, stream, a); break;
         case 8: hipLaunchKernelGGL((ntt_pass_w<8, ROWS>), grid, dim3(NTT_THREADS), NTT_W_LDS, stream, a); break;
@@ -769,6 +783,11 @@ template <int LR> static hipError_t ntt_w_attr() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_w<LR, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_W_LDS);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_w<LR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_W_LDS);
+}
+template <int LR> static hipError_t ntt_w_attr_big() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_w<LR, false, NTT_LOG_TILE_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_W_LDS_BIG);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_w<LR, true, NTT_LOG_TILE_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_W_LDS_BIG);
 }
 
 // digits of the mixed-radix plan: up to 10 bits per pass
@@ -782,6 +801,14 @@ static void digit_plan(uint32_t log_n, uint32_t d[4], uint32_t *passes) {
     else {
         p = (log_n + 9) / 10;                              // up to 10 bits per pass: 2^20 = 10 + 10 (two passes)
         for (uint32_t i = 0; i < p; i++) d[i] = log_n / p + (i < log_n % p ? 1 : 0);
+        // 11-bit digits on the 4096-element tile: 2^21 = 11 + 10 in two passes instead of three (0.207 -> 0.194 ms, same box).  2^22 = 11 + 11 is NOT
+        // taken: both passes then run on 64-byte row segments (C = 2) and the transform is 12 % SLOWER than three passes of the 2048-element tile
+        // (0.375 -> 0.421 ms; profiles/r06_ntt_big_tile_ab.txt) — PLK_NTT_BIG_TILE=2 forces it for that measurement
+        static const bool force22 = [] { const char *e = getenv("PLK_NTT_BIG_TILE"); return e && e[0] == '2'; }();
+        if ((log_n == 21 || (log_n == 22 && force22)) && ntt_big_tile_enabled()) {
+            d[0] = 11; d[1] = log_n - 11; d[2] = 0; *passes = 2;
+            return;
+        }
         if (p == 3 && log_n <= 23) {                       // leave 14 bits to passes 2 and 3: their inter-pass twiddles
             d[0] = log_n - 14; d[1] = 7; d[2] = 7;         // then come straight out of the hi table (ntt_pass_cols)
         }
@@ -829,6 +856,7 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 36 << LOG_SINGLE));
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_cols), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         PLK_HIP(ntt_w_attr<7>()); PLK_HIP(ntt_w_attr<8>()); PLK_HIP(ntt_w_attr<9>()); PLK_HIP(ntt_w_attr<10>());
+        PLK_HIP(ntt_w_attr_big<10>()); PLK_HIP(ntt_w_attr_big<11>());
         g_attr_set = true;
     }
     PowTable pre{}, post{};
@@ -838,6 +866,7 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
     }
     uint32_t d[4], p;
     digit_plan(log_n, d, &p);
+    const uint32_t log_tile = (p == 2 && d[0] == 11) ? (uint32_t)NTT_LOG_TILE_BIG : (uint32_t)LOG_TILE;     // 11-bit digits: the 4096-element tile
     const size_t n = (size_t)1 << log_n;
     if (p > 1) PLK_TRY(ctx->ntt_scratch[lane].reserve((size_t)count * n * sizeof(Fr)));
     Fr *const scratch = ctx->ntt_scratch[lane].as<Fr>();
@@ -853,7 +882,7 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
         for (uint32_t b = 0; b < count; b++) { a.in_b[b] = (i == 0) ? src[b] : scratch + (size_t)b * n; a.out_b[b] = scratch + (size_t)b * n; }
         a.nonzero = (i == 0) ? (uint32_t)nonzero : 0;
         a.log_r = d[i]; a.log_inner = rem;
-        a.log_c = (LOG_TILE - d[i]) < rem ? (LOG_TILE - d[i]) : rem;
+        a.log_c = (log_tile - d[i]) < rem ? (log_tile - d[i]) : rem;
         for (uint32_t b = 0; b < count; b++) a.pre_b[b] = (i == 0) ? (pre_each ? pre_each[b] : pre) : PowTable{};
         for (uint32_t b = 0; b < count; b++) a.post_b[b] = PowTable{};
         for (uint32_t b = 0; b < count; b++) { a.pre_direct_b[b] = (i == 0 && pre_direct) ? pre_direct[b] : nullptr; a.post_direct_b[b] = nullptr; }
@@ -877,7 +906,7 @@ static int32_t ntt_run(plk_ctx *ctx, const Fr *const *src, uint64_t nonzero, Fr 
             a.log_r1 = d[0];
             a.log_m1 = p >= 3 ? d[1] : 0;
             a.log_m2 = p >= 4 ? d[2] : 0;
-            a.log_c = (LOG_TILE - a.log_r) < d[0] ? (LOG_TILE - a.log_r) : d[0];
+            a.log_c = (log_tile - a.log_r) < d[0] ? (log_tile - a.log_r) : d[0];
         }
         for (uint32_t b = 0; b < count; b++) a.pre_b[b] = (p == 1) ? (pre_each ? pre_each[b] : pre) : PowTable{};
         for (uint32_t b = 0; b < count; b++) a.post_b[b] = post_each ? post_each[b] : post;

@@ -27,6 +27,10 @@ namespace plk {
 constexpr int NTT_LOG_TILE = 11;
 constexpr int NTT_W_KS_MAX = 68, NTT_W_WP_MAX = 8;             // largest padded k-stride / wave pad of any round
 constexpr int NTT_W_SLOTS = 8 * (4 * NTT_W_KS_MAX + NTT_W_WP_MAX);   // LDS slots of a tile (36 bytes each): 80 640 B, two tiles per CU
+// Round 6: the same plan for a tile of 4096 elements owned by SIXTEEN waves (one workgroup per CU, 161 280 of the CU's 163 840 bytes of LDS): 11-bit digits,
+// so that a 2^21 / 2^22-point transform is two passes instead of three.  LT = log2 of the tile; a wave still holds 256 elements (four per lane).
+constexpr int NTT_LOG_TILE_BIG = 12;
+constexpr int NTT_W_SLOTS_BIG = 16 * (4 * NTT_W_KS_MAX + NTT_W_WP_MAX);
 
 PLK_HD uint32_t plan_brev(uint32_t x, int bits) {
     uint32_t r = 0;
@@ -34,11 +38,13 @@ PLK_HD uint32_t plan_brev(uint32_t x, int bits) {
     return r;
 }
 
-template <int LR>
+template <int LR, int LT = NTT_LOG_TILE>
 struct TilePlan {
-    static_assert(LR >= 7 && LR <= 10, "wave-owned passes cover 7..10 bits per pass");
-    static constexpr int LC = NTT_LOG_TILE - LR;               // log2 columns
-    static constexpr int LWR = 3;                              // 8 waves = 8 row groups
+    static_assert((LT == NTT_LOG_TILE && LR >= 7 && LR <= 10) || (LT == NTT_LOG_TILE_BIG && LR >= 10 && LR <= 11), "wave-owned passes: 7..10 row bits of a 2048-element tile, 10..11 of a 4096-element one");
+    static constexpr int LC = LT - LR;                         // log2 columns
+    static constexpr int LWR = LT - 8;                         // 8 (16) waves = 8 (16) row groups
+    static constexpr int NW = 1 << LWR;
+    static constexpr int SLOTS = NW * (4 * NTT_W_KS_MAX + NTT_W_WP_MAX);
     static constexpr int LRA = LR - LWR;                       // row bits inside a wave (LRA + LC = 8)
     static constexpr int NR = (LR + 1) / 2;                    // rounds
     // first stage / number of stages of round r: an odd LR starts with ONE twiddle-free stage
@@ -73,8 +79,8 @@ struct TilePlan {
     static PLK_HD uint32_t slot(uint32_t row, uint32_t col, uint32_t ks = KS(r), uint32_t ws = WS) {
         constexpr int s = ls(r), h = 1 << s;
         uint32_t wave, ix;
-        if (pb(r)) { wave = row & 7u; ix = row >> LWR; }
-        else { wave = (row >> A) & 7u; ix = ((row >> (A + LWR)) << A) | (row & ((1u << A) - 1)); }
+        if (pb(r)) { wave = row & (uint32_t)(NW - 1); ix = row >> LWR; }
+        else { wave = (row >> A) & (uint32_t)(NW - 1); ix = ((row >> (A + LWR)) << A) | (row & ((1u << A) - 1)); }
         const uint32_t k = (ix >> s) & 3u, j = ((ix >> (s + 2)) << s) | (ix & (h - 1));
         return wave * ws + k * ks + ((j << LC) | col);
     }
@@ -84,14 +90,18 @@ struct TilePlan {
 };
 
 // entry 0: wave stride - 272; entry r >= 1: k pad of the layout round r reads
-template <int LR> constexpr int TilePlan<LR>::pad_tab(int r) {
+template <int LR, int LT> constexpr int TilePlan<LR, LT>::pad_tab(int r) {
     constexpr int tab[4][5] = {
         /* LR = 7  */ {0, 0, 0, 0, 0},
         /* LR = 8  */ {8, 4, 0, 0, 0},
         /* LR = 9  */ {4, 2, 4, 0, 0},
         /* LR = 10 */ {2, 2, 4, 0, 0},
     };
-    return tab[LR - 7][r];
+    constexpr int big[2][6] = {                                // 4096-element tile (`ntt_plan_check search` prints the candidates)
+        /* LR = 10 */ {4, 4, 0, 0, 0, 0},
+        /* LR = 11 */ {2, 1, 4, 0, 0, 0},
+    };
+    return LT == NTT_LOG_TILE ? tab[LR - 7][r < 5 ? r : 4] : big[LR - 10][r];
 }
 
 }  // namespace plk

@@ -16,4 +16,4 @@ def test_ntt_plan_host(tmp_path):
     assert "ntt plan ok" in out.stdout
     # every exchange of every shape is free of bank conflicts on the 16-byte stores
     lines = [l for l in out.stdout.splitlines() if "ds_write_b128" in l]
-    assert len(lines) == 14 and all("array cycles 8.00" in l for l in lines), out.stdout
+    assert len(lines) == 14 + 4 + 5 and all("array cycles 8.00" in l for l in lines), out.stdout      # four shapes of the 2048-element tile, two of the 4096-element one
