@@ -306,6 +306,9 @@ int32_t plk_setup_prepare_host(const plk_circuit *c, plk_setup **out);
 int32_t plk_setup_upload(plk_ctx *ctx, plk_setup *s);
 void plk_setup_free(plk_setup *s);
 uint64_t plk_setup_domain_size(const plk_setup *s);                    /* N = n + 1              */
+/* the same N straight from the circuit: transpile only (pure CPU), no columns, no device work — all that `dump-lagrange` needs of
+ * prepare_setup_for_prover (src/bin/main.rs:360-381 builds the whole setup to read setup.n) */
+int32_t plk_circuit_domain_size(const plk_circuit *c, uint64_t *n_out);
 /* make_verification_key + VerificationKey::write (src/plonk.rs:122-124; src/bin/main.rs:501-502).
  * g2_bytes = the 2 x 128 bytes of the key file's G2 section, copied through.                    */
 int32_t plk_setup_write_vk(plk_ctx *ctx, const plk_setup *s, const uint8_t g2_bytes[256], uint8_t *out, uint64_t cap, uint64_t *len);

@@ -402,6 +402,12 @@ class Circuit:
         w = open(witness_path, "rb").read() if witness_path else None
         return cls(open(r1cs_path, "rb").read(), r1cs_path.endswith("json"), w, bool(witness_path) and witness_path.endswith("json"))
 
+    def domain_size(self):
+        """N of the circuit's setup without building it (transpile only)"""
+        n = ctypes.c_uint64(0)
+        _check(lib().plk_circuit_domain_size(self._h, ctypes.byref(n)))
+        return n.value
+
     def analyse(self):
         """plonk::analyse (src/plonk.rs:72-93) as the serde_json string of src/tests.rs:14"""
         size = 1 << 20

@@ -261,6 +261,23 @@ extern "C" {
 uint64_t plk_setup_domain_size(const plk_setup *s) { return s ? s->N : 0; }
 void plk_setup_free(plk_setup *s) { if (s) { s->store.release(); s->lde_store.release(); s->ops_dev.release(); s->terms_dev.release(); s->runs_dev.release(); delete s; } }
 
+// the domain size N (and log2 N) a circuit's setup will have — transpile only (pure CPU, ~18 ms at 2^20 gates), no columns, no device work: what
+// `dump-lagrange` needs of prepare_setup_for_prover (src/bin/main.rs:360-381 builds the whole setup to read setup.n from it)
+int32_t plk_circuit_domain_size(const plk_circuit *c, uint64_t *n_out) {
+    if (!c || !n_out) { set_error("plk_circuit_domain_size: bad argument"); return PLK_ERR_ARG; }
+    return guarded("plk_circuit_domain_size", PLK_ERR_ARG, [&]() -> int32_t {
+        Transpiled T;
+        T.collect_stats = false;
+        if (!transpile(c->r1cs, nullptr, &T)) return PLK_ERR_UNSAT;
+        const uint64_t n_real = (uint64_t)(c->r1cs.num_inputs - 1) + T.num_gates;
+        uint64_t N = 1; uint32_t log_n = 0;
+        while (N < n_real + 1) { N <<= 1; log_n++; }
+        if (log_n + 2 > MAX_LOG_N) { set_error("setup power of two is not in the correct range"); return PLK_ERR_SIZE; }
+        *n_out = N;
+        return PLK_OK;
+    });
+}
+
 // SetupForProver::prepare_setup_for_prover in two phases, so that a host program can run the first one (pure CPU:
 // transpile, selector / variable-index columns) while the GPU side of its start-up is still under way on another thread
 // (HIP initialisation, key upload, MSM table — the `plonkit` binary does exactly that), and the second one when both are done.

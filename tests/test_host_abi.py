@@ -274,6 +274,22 @@ def test_synthetic_circuit_generator_is_stable():
         c.close()
 
 
+def test_domain_size_without_a_setup(golden_dir):
+    """plk_circuit_domain_size (round 6: what `dump-lagrange` needs of prepare_setup_for_prover — src/bin/main.rs:360-381 reads setup.n): transpile only,
+    no GPU; N = next power of two above (public inputs + gates), as the oracle's setup computes it; long linear combinations count their chained gates"""
+    import plonkit_amd as pa
+    c = pa.Circuit.from_files(os.path.join(golden_dir, "circuit.r1cs.json"), os.path.join(golden_dir, "witness.json"))
+    assert c.domain_size() == 8                                   # the reference's `simple` circuit: vk.bin says n = 7
+    c.close()
+    for gates, want in ((5, 8), (6, 8), (7, 16), (4094, 4096), (4095, 8192), (40000, 1 << 16)):
+        c = pa.Circuit.synthetic(gates)                           # `gates` gates + one public input
+        assert c.domain_size() == want, gates
+        c.close()
+    c = pa.Circuit.synthetic_ex(4094, lc_terms=7)                 # the dense generator hits its gate target with chained linear combinations
+    assert c.domain_size() == 4096
+    c.close()
+
+
 def test_header_is_plain_c_and_links(tmp_path):
     """include/plonkit_amd.h is the boundary a cgo / Rust-bindgen / C caller sees: it must compile as C99 (no C++ in it) and
     a C program linked against the shared library must resolve the symbols (the calls made here need no GPU)"""
