@@ -76,10 +76,124 @@ struct F {
     }
     F pow_u64(uint64_t e) const { uint64_t ee[4] = {e, 0, 0, 0}; return pow(ee); }
     F inv_fermat() const { uint64_t e[4] = {PR::P[0] - 2, PR::P[1], PR::P[2], PR::P[3]}; return pow(e); }
-    // Inverse by the binary extended Euclid (Hankerson-Menezes-Vanstone, Alg. 2.22) on the stored limbs, then one Montgomery product by
-    // R^3 to come back to Montgomery form: (aR)^-1 * R^3 / R = a^-1 R.  About half the time of the Fermat exponentiation (383 products) —
-    // the host inversions sit between the prover's rounds, where the GPU waits for the next challenge.  inv(0) = 0, as before.
+    // Inverse.  Round 6: Bernstein-Yang division steps in batches of 62 on the low words (the variable-time "safegcd" scheme: per batch a 2x2
+    // transition matrix from 62 cheap 64-bit steps, then one application of it to the five 62-bit limbs of f, g and of the Bezout pair d, e taken
+    // modulo p) — ~2 us against the 13 us of the bit-by-bit binary Euclid it replaces (inv_euclid below); six host inversions sit between the
+    // rounds of a proof, where the GPU waits for the next challenge (4 % of a 2^12-domain proof).  The result is VERIFIED with one product and the
+    // old routine answers if it is ever wrong, so a slip in this code can cost time, never a proof.  inv(0) = 0, as before.
     F inv() const {
+        if (is_zero()) return *this;
+        static const F R3 = [] { F r2; memcpy(r2.l, PR::R2, 32); return r2 * r2; }();
+        F r;
+        if (inv_divsteps(l, r.l)) {
+            r = r * R3;                                           // (aR)^-1 * R^3 / R = a^-1 R
+            if ((*this * r) == one()) return r;
+        }
+        return inv_euclid();
+    }
+    typedef __int128 i128;
+    // raw^-1 mod p for 0 < raw < p as plain integers; false if the 12 batches did not reach g = 0 (cannot happen for gcd(raw, p) = 1: 744 steps > the 735 bound)
+    static bool inv_divsteps(const uint64_t raw[4], uint64_t out[4]) {
+        const int64_t M62 = (int64_t)(~0ULL >> 2);
+        auto to62 = [&](const uint64_t a[4], int64_t v[5]) {
+            v[0] = (int64_t)(a[0] & (uint64_t)M62);
+            v[1] = (int64_t)(((a[0] >> 62) | (a[1] << 2)) & (uint64_t)M62);
+            v[2] = (int64_t)(((a[1] >> 60) | (a[2] << 4)) & (uint64_t)M62);
+            v[3] = (int64_t)(((a[2] >> 58) | (a[3] << 6)) & (uint64_t)M62);
+            v[4] = (int64_t)(a[3] >> 56);
+        };
+        int64_t P62[5], f[5], g[5], d[5] = {0, 0, 0, 0, 0}, e[5] = {1, 0, 0, 0, 0};
+        to62(PR::P, P62); to62(PR::P, f); to62(raw, g);
+        // p^-1 mod 2^62 (Newton: five doublings of precision from the 3 correct bits of p itself for odd p)
+        uint64_t pinv = PR::P[0];
+        for (int k = 0; k < 5; k++) pinv *= 2 - PR::P[0] * pinv;
+        pinv &= (uint64_t)M62;
+        int64_t eta = -1;
+        for (int batch = 0; batch < 12; batch++) {
+            // 62 division steps on the low words: [u v; q r] with 2^62 * [f', g'] = [u v; q r] [f, g]
+            uint64_t u = 1, v = 0, q = 0, r = 1, ff = (uint64_t)f[0] | ((uint64_t)f[1] << 62), gg = (uint64_t)g[0] | ((uint64_t)g[1] << 62);
+            int i = 62;
+            for (;;) {
+                const int zeros = __builtin_ctzll(gg | (~0ULL << i));
+                gg >>= zeros; u <<= zeros; v <<= zeros; eta -= zeros; i -= zeros;
+                if (i == 0) break;
+                uint64_t m, w;
+                int limit;
+                if (eta < 0) {
+                    uint64_t t;
+                    eta = -eta;
+                    t = ff; ff = gg; gg = 0 - t;
+                    t = u; u = q; q = 0 - t;
+                    t = v; v = r; r = 0 - t;
+                    limit = (int)eta + 1 > i ? i : (int)eta + 1;
+                    m = (~0ULL >> (64 - limit)) & 63u;
+                    w = (ff * gg * (ff * ff - 2)) & m;
+                } else {
+                    limit = (int)eta + 1 > i ? i : (int)eta + 1;
+                    m = (~0ULL >> (64 - limit)) & 15u;
+                    w = ff + (((ff + 1) & 4) << 1);
+                    w = (0 - w * gg) & m;
+                }
+                gg += ff * w; q += u * w; r += v * w;
+            }
+            const int64_t tu = (int64_t)u, tv = (int64_t)v, tq = (int64_t)q, tr = (int64_t)r;
+            {   // [d, e] <- [u v; q r] [d, e] / 2^62 (mod p): multiples of p make the low 62 bits vanish first
+                const int64_t sd = d[4] >> 63, se = e[4] >> 63;
+                int64_t md = (tu & sd) + (tv & se), me = (tq & sd) + (tr & se);
+                i128 cd = (i128)tu * d[0] + (i128)tv * e[0], ce = (i128)tq * d[0] + (i128)tr * e[0];
+                md -= (int64_t)((pinv * (uint64_t)cd + (uint64_t)md) & (uint64_t)M62);
+                me -= (int64_t)((pinv * (uint64_t)ce + (uint64_t)me) & (uint64_t)M62);
+                cd += (i128)P62[0] * md; ce += (i128)P62[0] * me;
+                cd >>= 62; ce >>= 62;
+                for (int k = 1; k < 5; k++) {
+                    cd += (i128)tu * d[k] + (i128)tv * e[k] + (i128)P62[k] * md;
+                    ce += (i128)tq * d[k] + (i128)tr * e[k] + (i128)P62[k] * me;
+                    d[k - 1] = (int64_t)cd & M62; cd >>= 62;
+                    e[k - 1] = (int64_t)ce & M62; ce >>= 62;
+                }
+                d[4] = (int64_t)cd; e[4] = (int64_t)ce;
+            }
+            {   // [f, g] <- [u v; q r] [f, g] / 2^62 (exact)
+                i128 cf = (i128)tu * f[0] + (i128)tv * g[0], cg = (i128)tq * f[0] + (i128)tr * g[0];
+                cf >>= 62; cg >>= 62;
+                for (int k = 1; k < 5; k++) {
+                    cf += (i128)tu * f[k] + (i128)tv * g[k];
+                    cg += (i128)tq * f[k] + (i128)tr * g[k];
+                    f[k - 1] = (int64_t)cf & M62; cf >>= 62;
+                    g[k - 1] = (int64_t)cg & M62; cg >>= 62;
+                }
+                f[4] = (int64_t)cf; g[4] = (int64_t)cg;
+            }
+            if ((g[0] | g[1] | g[2] | g[3] | g[4]) == 0) {
+                // f = +-1 = gcd (limbs {1,0,0,0,0} or {M62,M62,M62,M62,-1}); the inverse is d * f, brought from (-2p, p) into [0, p)
+                auto is_neg = [&](const int64_t a[5]) { return a[4] < 0; };
+                auto addp = [&](int64_t a[5], int sign) {          // a += sign * p, carries normalised (the top limb keeps the sign)
+                    int64_t c = 0;
+                    for (int k = 0; k < 5; k++) { const int64_t t = a[k] + (sign > 0 ? P62[k] : -P62[k]) + c; if (k < 4) { a[k] = t & M62; c = t >> 62; } else a[k] = t; }
+                };
+                auto negate = [&](int64_t a[5]) { int64_t c = 0; for (int k = 0; k < 5; k++) { const int64_t t = -a[k] + c; if (k < 4) { a[k] = t & M62; c = t >> 62; } else a[k] = t; } };
+                const bool minus = f[4] < 0;
+                if (minus) negate(d);
+                for (int guard = 0; guard < 4 && is_neg(d); guard++) addp(d, +1);
+                for (int guard = 0; guard < 4; guard++) {          // d >= p ?  subtract
+                    int64_t t[5]; for (int k = 0; k < 5; k++) t[k] = d[k];
+                    addp(t, -1);
+                    if (is_neg(t)) break;
+                    for (int k = 0; k < 5; k++) d[k] = t[k];
+                }
+                if (is_neg(d)) return false;
+                out[0] = (uint64_t)d[0] | ((uint64_t)d[1] << 62);
+                out[1] = ((uint64_t)d[1] >> 2) | ((uint64_t)d[2] << 60);
+                out[2] = ((uint64_t)d[2] >> 4) | ((uint64_t)d[3] << 58);
+                out[3] = ((uint64_t)d[3] >> 6) | ((uint64_t)d[4] << 56);
+                return true;
+            }
+        }
+        return false;
+    }
+    // the binary extended Euclid (Hankerson-Menezes-Vanstone, Alg. 2.22) on the stored limbs, then one Montgomery product by R^3 to come back to
+    // Montgomery form — the routine of rounds 4-5, now the checked fallback of inv()
+    F inv_euclid() const {
         if (is_zero()) return *this;
         static const F R3 = [] { F r2; memcpy(r2.l, PR::R2, 32); return r2 * r2; }();
         auto is_one = [](const uint64_t *t) { return t[0] == 1 && (t[1] | t[2] | t[3]) == 0; };

@@ -43,20 +43,30 @@ template <class T, class PR> static int run(const char *name) {
             if (k < 5) for (int i = 0; i < 5; i++) if (!(a * ex[i] == mul_looped<T, PR>(a, ex[i])) || !(ex[i] * a == mul_looped<T, PR>(ex[i], a))) bad++;
         }
     }
+    // inv() is the division-step inverse of round 6 (verified inside, Euclid as its fallback): it must equal the Fermat exponentiation AND the
+    // Euclid routine, and its own path must be the one that answered — inv_divsteps never gives up and its raw result already passes the check
+    static const T R3 = [] { T r2; memcpy(r2.l, PR::R2, 32); return r2 * r2; }();
+    int fallbacks = 0;
     auto check = [&](const T &a) {
-        const T i1 = a.inv(), i2 = a.inv_fermat();
-        if (!(i1 == i2)) bad++;
+        const T i1 = a.inv(), i2 = a.inv_fermat(), i3 = a.inv_euclid();
+        if (!(i1 == i2) || !(i1 == i3)) bad++;
         if (!a.is_zero() && !(a * i1 == T::one())) bad++;
+        if (!a.is_zero()) {
+            T r;
+            if (!T::inv_divsteps(a.l, r.l) || !(a * (r * R3) == T::one())) fallbacks++;
+        }
     };
     check(T::zero()); check(T::one()); check(-T::one()); check(T::from_u64(2)); check(-T::from_u64(2));
     { T t; uint64_t c[4] = {PR::P[0] - 1, PR::P[1], PR::P[2], PR::P[3]}; memcpy(t.l, c, 32); check(t); }      // stored limbs p - 1
     { T t; uint64_t c[4] = {1, 0, 0, 0}; memcpy(t.l, c, 32); check(t); }                                       // stored limbs 1 (= R^-1)
     for (int k = 0; k < 64; k++) { T t = T::zero(); t.l[k >> 4] = 1ull << ((k & 15) * 4); if (!T::geq_p(t.l)) check(t); }   // sparse limbs
-    for (int k = 0; k < 4000; k++) {
+    for (int k = 0; k < 40000; k++) {
         uint64_t c[4] = {sm64(seed), sm64(seed), sm64(seed), sm64(seed) >> 3};
         if (T::geq_p(c)) continue;
         check(T::from_canonical(c));
+        if (k < 2000) { T t; memcpy(t.l, c, 32); check(t); }                                                  // the same limbs as STORED (Montgomery) value
     }
+    for (uint64_t v = 1; v < 3000; v++) { check(T::from_u64(v)); check(-T::from_u64(v)); T t = T::zero(); t.l[0] = v; check(t); }   // small values, p - small, small stored limbs
     // pow: the short loop against repeated multiplication, and exponents with a high top bit
     for (int k = 0; k < 50; k++) {
         uint64_t c[4] = {sm64(seed), sm64(seed), sm64(seed), sm64(seed) >> 3};
@@ -78,9 +88,12 @@ template <class T, class PR> static int run(const char *name) {
     auto t1 = std::chrono::steady_clock::now();
     for (int k = 0; k < 2000; k++) a = a.inv_fermat() + T::one();
     auto t2 = std::chrono::steady_clock::now();
-    printf("%s: %d mismatches; inverse %.2f us (binary Euclid) against %.2f us (Fermat)\n", name, bad,
-           std::chrono::duration<double, std::micro>(t1 - t0).count() / 2000, std::chrono::duration<double, std::micro>(t2 - t1).count() / 2000);
-    return bad;
+    for (int k = 0; k < 2000; k++) a = a.inv_euclid() + T::one();
+    auto t3 = std::chrono::steady_clock::now();
+    printf("%s: %d mismatches; %d fallbacks of the division-step inverse; inverse %.2f us (division steps) against %.2f us (binary Euclid) and %.2f us (Fermat)\n", name, bad, fallbacks,
+           std::chrono::duration<double, std::micro>(t1 - t0).count() / 2000, std::chrono::duration<double, std::micro>(t3 - t2).count() / 2000,
+           std::chrono::duration<double, std::micro>(t2 - t1).count() / 2000);
+    return bad + fallbacks;
 }
 
 int main() {
