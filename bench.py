@@ -418,8 +418,8 @@ def reference_binary_baseline(log_domain):
 def poseidon_shaped_circuit(perms=7, seed=84, rp=20):
     """the 2^12-domain circuit of the by-domain table: a circom-Poseidon-SHAPED hash chain (tests/gen/poseidon_like.py — the shape of the
     reference's CI circuit test/circuits/poseidon, whose artifacts are not in its tree; S-box inputs that are linear combinations of up to 24
-    signals, folded through the d column: parity unpinned).  The generator only makes INPUTS (it borrows the oracle's
-    xoshiro256** and the modulus); what is timed is the product's prover."""
+    signals, folded through the d column: parity unpinned).  The generator only makes INPUTS and imports nothing of oracle/
+    (its own xoshiro256**); what is timed is the product's prover."""
     import plonkit_amd as pa
     from tests.gen import poseidon_like as pl
     ni, nv, cons, wit = pl.build(perms, seed, rp=rp)

@@ -11,8 +11,42 @@ per output lane (constant x LC = LC).  MDS entries and round constants come from
 alongside.  Everything the transpilers do with such constraints (d / d_next chains, constant merges) is UNPINNED: no
 reference fixture reaches it — tests built on this check the product against the oracle restatement and
 against the verifier, never against the reference."""
-from oracle.plonk_oracle import Xoshiro256ss
-from oracle.oracle_lib import R_MOD
+# (self-contained on purpose: bench.py's prove.by_domain leg builds its 2^12 circuit with this generator, and nothing on a GPU-timed path may import
+#  oracle/ — the generator only makes inputs.  Same xoshiro256** / splitmix64 as oracle.plonk_oracle.Xoshiro256ss: tests/test_host_abi.py checks that.)
+R_MOD = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001          # BN254 Fr
+
+
+class Xoshiro256ss:
+    """xoshiro256** seeded through splitmix64 — the generator SURVEY.md §8(d) names for synthetic R1CS"""
+    M = (1 << 64) - 1
+
+    def __init__(self, seed):
+        s, self.s = seed & self.M, []
+        for _ in range(4):
+            s = (s + 0x9E3779B97F4A7C15) & self.M
+            zz = s
+            zz = ((zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9) & self.M
+            zz = ((zz ^ (zz >> 27)) * 0x94D049BB133111EB) & self.M
+            self.s.append(zz ^ (zz >> 31))
+
+    def next(self):
+        s = self.s
+        rot = lambda x, k: ((x << k) | (x >> (64 - k))) & self.M
+        res = (rot((s[1] * 5) & self.M, 7) * 9) & self.M
+        t = (s[1] << 17) & self.M
+        s[2] ^= s[0]
+        s[3] ^= s[1]
+        s[1] ^= s[2]
+        s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = rot(s[3], 45)
+        return res
+
+    def fr(self):
+        while True:
+            v = (self.next() | (self.next() << 64) | (self.next() << 128) | (self.next() << 192)) & ((1 << 254) - 1)
+            if v < R_MOD:
+                return v
 
 
 class _Lc:

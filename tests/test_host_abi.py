@@ -274,6 +274,15 @@ def test_synthetic_circuit_generator_is_stable():
         c.close()
 
 
+def test_input_generator_has_the_oracles_random_numbers():
+    """tests/gen/poseidon_like.py carries its own xoshiro256** (so that bench.py's GPU-timed by-domain leg imports nothing of oracle/): same stream and same
+    modulus as the oracle's, i.e. the circuits it builds did not change"""
+    from tests.gen import poseidon_like as pl
+    assert pl.R_MOD == R_MOD
+    a, b = pl.Xoshiro256ss(77), po.Xoshiro256ss(77)
+    assert [a.next() for _ in range(50)] == [b.next() for _ in range(50)] and [a.fr() for _ in range(20)] == [b.fr() for _ in range(20)]
+
+
 def test_domain_size_without_a_setup(golden_dir):
     """plk_circuit_domain_size (round 6: what `dump-lagrange` needs of prepare_setup_for_prover — src/bin/main.rs:360-381 reads setup.n): transpile only,
     no GPU; N = next power of two above (public inputs + gates), as the oracle's setup computes it; long linear combinations count their chained gates"""
