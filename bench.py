@@ -525,7 +525,11 @@ def compact_line(full):
                              "ms_per_step_one_in_flight", "algorithmic_bytes", "valu_frac"))
     if isinstance(r.get("valu"), dict):
         L["roofline"]["valu"] = pick(r["valu"], ("achieved_gmadd_s", "peak_gmadd_s", "frac_of_isolated_loop"))
-    L["roofline"]["traffic_source"] = "profiles/ (rocprofv3 --pmc of the same command; not this run)"
+    src = r.get("traffic_source") or ""
+    L["roofline"]["traffic_source"] = ("this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of --msm-only)" if src.startswith("measured in this run")
+                                       else "profiles/ (rocprofv3 --pmc of the same command; not this run)")
+    if "traffic_over_algorithmic" in r:
+        L["roofline"]["traffic_over_algorithmic"] = r["traffic_over_algorithmic"]
     if "value_sustained" in full:
         L["value_sustained"] = full["value_sustained"]
     cb = full.get("cpu_baseline")
@@ -591,6 +595,42 @@ def emit(line):
             if len(out.encode()) <= 7600:
                 break
     print(out, flush=True)
+
+
+def measure_traffic_live(log_n):
+    """roofline.traffic measured in THIS run (round-5 review: the figure was a constant pasted from profiles/): two child runs of this script's --msm-only
+    region (one commitment in flight) under `rocprofv3 --pmc <counter> --kernel-trace` — FETCH_SIZE and WRITE_SIZE need separate passes (TCC counter slots:
+    MI355X_MICROARCH.md) and no other tracing —, the median KB per msm_accumulate launch of each, summed.  No correction factor is applied: the kernel's reads
+    are 64-byte gathers, not the wide coalesced streams whose FETCH_SIZE the guide says to double.  Returns (bytes, source) or raises."""
+    import csv
+    import glob
+    import shutil
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        raise RuntimeError("rocprofv3 not found")
+    total, parts = 0, {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="plk_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--msm-only", "--pipeline-depth", "1", "--steps", "6", "--warmup", "2", "--log-n", str(log_n), "--sustained-settle-steps", "0"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                raise RuntimeError("rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-200:]))
+            vals = sorted(float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                          if "msm_accumulate" in row["Kernel_Name"] and row["Counter_Name"] == counter)
+            if len(vals) < 4:
+                raise RuntimeError("rocprofv3 --pmc %s: %d msm_accumulate launches in the trace" % (counter, len(vals)))
+            parts[counter] = vals[len(vals) // 2]
+            total += vals[len(vals) // 2] * 1024.0
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(total), ("measured in this run: median per msm_accumulate launch of two rocprofv3 --pmc child runs of `bench.py --msm-only --pipeline-depth 1` "
+                        "(FETCH_SIZE %.0f KB + WRITE_SIZE %.0f KB; separate passes, no correction factor: 64-byte gathers)" % (parts["FETCH_SIZE"], parts["WRITE_SIZE"]))
 
 
 # ------------------------------------------------------------------------------------------ multi-GPU legs
@@ -853,6 +893,7 @@ def main():
     ap.add_argument("--sustained-settle-steps", type=int, default=50,
                     help="untimed commitments between the headline region and the `sustained` region (the same K steps timed again "
                          "once the GPU has been under load for >= 70 ms: DESIGN.md §5); 0 = no sustained region")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic (the constant from profiles/ is reported instead)")
     ap.add_argument("--msm-only", action="store_true", help="only the timed commitments (no cpu_baseline / prove / kernels legs): "
                                                             "the command the rocprofv3 summary under profiles/ is taken from")
     args = ap.parse_args()
@@ -1068,6 +1109,13 @@ def main():
             if rb:
                 cb["reference_binary"] = rb
             line["cpu_baseline"] = cb
+        if world == 1 and not force_dist and not args.msm_only and not args.no_live_traffic:
+            try:
+                tb, src = measure_traffic_live(args.log_n)
+                line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tb, src
+                line["roofline"]["traffic_over_algorithmic"] = round(tb / (ALGO_BYTES_PER_TERM * n), 2)
+            except Exception as exc:                               # noqa: BLE001 — the constant stays, and says why
+                FAILED_LEGS.append(("roofline.traffic", repr(exc), False))
         if world == 1 and not force_dist and not args.msm_only:
             from plonkit_amd import prover_bench
             line["prove"] = leg("prove", lambda: prover_bench.run(ctx, args.log_n))      # a failing leg must not cost the headline line
