@@ -7,14 +7,14 @@
 //   * the fixed-base table of msm.hip stays (copy w holds 2^(17w) * P_i), so all 15 signed 17-bit windows of a commitment share
 //     one bucket space; a digit's magnitude m <= 2^16 is split m = 256 * hi + lo and the entry is dropped into TWO small bucket
 //     sets — lo in [1, 255], hi in [1, 256] — : 30 mixed additions per term instead of 15, into 511 buckets instead of 65536;
-//   * msm_small_accumulate: a workgroup of 512 lanes takes 64 terms; lane b OWNS bucket b.  One wave recodes the 64 scalars and
-//     appends every entry to the lists of its two buckets (LDS atomics), then every lane adds up its own list: ~4 mixed additions
-//     per lane for uniform scalars (a constant column — 64 equal scalars — makes one lane add 64: still shorter than the old tail);
-//   * msm_small_fold: the G = n / 64 workgroups' sums of a bucket, one wave per bucket (shuffle tree of full additions);
+//   * msm_small_accumulate: a workgroup of 256 lanes takes ch = 64 / 128 / 256 terms and 64 of the 512 buckets, FOUR lanes per bucket.
+//     The first waves recode the scalars and append every entry to its bucket's list (LDS atomics), then lane j of a bucket adds up
+//     entries j, j + 4, .. of the list (a constant column — ch equal scalars in one bucket — is ch / 4 additions per lane);
+//   * msm_small_fold: the 4 n / ch partial sums of a bucket (one per lane that owned it), a tree of four-lane full additions;
 //   * msm_small_planes: sum_j j * B_j = sum_b 2^b * (sum of the B_j with bit b of j set): seventeen plain tree sums over <= 128
 //     buckets, side by side; the seventeen points go to the host, whose Horner (16 doublings + 16 additions) takes ~15 us.
 // The longest dependent chain is ~10 mixed + 13 full additions (against ~90 + the accumulation before).
-// A list longer than its 64 slots (several WINDOWS of one scalar carrying the same digit, 64 times over: not a witness anybody
+// A list longer than its ch slots (several WINDOWS of one scalar carrying the same digit, in every term of a chunk: not a witness anybody
 // has) raises a flag; msm_finish_batch then runs the ordinary pipeline on the same inputs — never a wrong result.
 // No MFMA (256-bit modular integers); bound by the latency of the EC addition chains.
 #include "msm_shape.h"
@@ -24,18 +24,15 @@
 namespace plk {
 
 constexpr uint32_t SM_BUCKETS = 512;             // index v in [1, 255] = lo value v, index 255 + v = hi value v in [1, 256]
-constexpr uint32_t SM_THREADS = 256;             // a workgroup owns ONE of the two bucket sets of its terms: lane = bucket, one wave per SIMD
-// Terms per workgroup (= slots per bucket list: a constant column fills exactly that many): 32, 64 or 128, chosen per launch so that the grid
-// is about one workgroup per CU — the kernel is bound by the additions a SIMD issues (~4.5 us per wave and addition), so a short commitment
-// wants many short lists on all CUs (2^12 terms: 256 workgroups, ~6 additions deep) and a batch of them fewer, longer ones (less imbalance
-// between the lanes of a wave: the longest of 64 lists decides, and fewer partial sums for msm_small_fold).
-constexpr uint32_t SM_CH_MIN = 32, SM_CH_MAX = 128;
-// slots per bucket list: a constant column puts `ch` entries into one bucket, which its two lists share — 64 slots each hold that for every chunk size
-// (128 equal scalars split 64 / 64 when the two-choice reads are fresh; if not, the overflow flag sends the commitment to the ordinary pipeline), and
-// keep the workgroup at 66 KB of LDS: two per CU, so that a SIMD's two waves average their longest lists instead of the launch waiting for one wave
-constexpr uint32_t SM_CAP_MAX = 64;
-static uint32_t sm_cap(uint32_t ch) { return ch < SM_CAP_MAX ? ch : SM_CAP_MAX; }
-static size_t sm_lds(uint32_t ch) { return (size_t)(SM_THREADS + SM_THREADS * (sm_cap(ch) + 1)) * sizeof(uint32_t); }
+constexpr uint32_t SM_THREADS = 256;             // a workgroup owns 64 buckets of its terms, FOUR lanes per bucket; one or two waves per SIMD
+// Terms per workgroup (= slots of a bucket's list: a constant column fills exactly that many): 64, 128 or 256, chosen per launch so that the grid is about one
+// or two workgroups per CU.  The kernel is bound by the additions a SIMD issues (~5.6 us per wave and addition; a lone wave issues at the SIMD's rate), so what
+// counts is the LONGEST list share of a wave.  Third layout of the round: (1) one lane per bucket: the longest of 65 536 lists of a 2^12-term commitment held
+// 10-11 entries against a mean of 1.9 and WAS the kernel's duration (73-80 us); (2) two lanes per bucket, an entry joins the shorter list: 50 us, a batch of four
+// 107-145 us; (3) this one — ONE list per bucket, split evenly over four lanes (lane j takes entries j, j + 4, ..): inside a bucket the balance is exact, and
+// with 4x the terms per bucket the lists are longer and relatively more even.
+constexpr uint32_t SM_CH_MIN = 64, SM_CH_MAX = 256, SM_WG_BUCKETS = 64, SM_LANES_PER_BUCKET = 4;
+static size_t sm_lds(uint32_t ch) { return (size_t)(SM_WG_BUCKETS + SM_WG_BUCKETS * (ch + 1)) * sizeof(uint32_t); }
 
 __device__ __forceinline__ void small_chain_priority() { __builtin_amdgcn_s_setprio(3); }
 
@@ -51,18 +48,15 @@ __device__ __forceinline__ XyzzW sm_shfl_xor(const XyzzW &v, int mask) {
     return r;
 }
 
-// grid (4 G, batch): workgroup 4 g + s takes terms [g ch, (g + 1) ch) and a QUARTER of the bucket space — s & 1: lo / hi values, s >> 1: which half
-// of the 256 values — with TWO lanes per bucket (lane b and lane b + 128): an entry joins the shorter of its bucket's two lists.  With one list per
-// bucket the longest of the 65536 lists of a 2^12-term commitment held 10-11 entries against a mean of 1.9, and since every SIMD of the chip runs
-// exactly one wave of this kernel the longest list IS the kernel's duration (measured 73-80 us); two choices cut that tail.
+// grid (8 G, batch): workgroup 8 g + s takes terms [g ch, (g + 1) ch) and an EIGHTH of the bucket space — s & 1: lo / hi values, s >> 1: which 64 of the 256 values.
 // bases = copy 0 of the fixed-base table at the commitment's first point; copy w lies w * copy_stride points on.
-__global__ void __launch_bounds__(SM_THREADS, 2) msm_small_accumulate(const G1Affine *bases, ScalarSet set, uint32_t n, uint32_t ch, uint32_t cap, uint32_t copy_stride,
+__global__ void __launch_bounds__(SM_THREADS, 2) msm_small_accumulate(const G1Affine *bases, ScalarSet set, uint32_t n, uint32_t ch, uint32_t copy_stride,
                                                                      XyzzW *partials, uint32_t *flag) {
     extern __shared__ uint32_t sm_lds_mem[];
-    uint32_t *cnt = sm_lds_mem, *list = sm_lds_mem + SM_THREADS;
-    const uint32_t tid = threadIdx.x, g = blockIdx.x >> 2, hi_set = blockIdx.x & 1, half = (blockIdx.x >> 1) & 1, m = blockIdx.y, first = g * ch;
-    const uint32_t stride = cap + 1;                           // (odd stride: the lanes' reads fall into different banks)
-    cnt[tid] = 0;
+    uint32_t *cnt = sm_lds_mem, *list = sm_lds_mem + SM_WG_BUCKETS;
+    const uint32_t tid = threadIdx.x, g = blockIdx.x >> 3, hi_set = blockIdx.x & 1, eighth = (blockIdx.x >> 1) & 3, m = blockIdx.y, first = g * ch;
+    const uint32_t stride = ch + 1;                            // (odd stride: the lanes' reads fall into different banks)
+    if (tid < SM_WG_BUCKETS) cnt[tid] = 0;
     __syncthreads();
     if (tid < ch && first + tid < n) {
         int32_t d[RC_WINDOWS];
@@ -74,37 +68,36 @@ __global__ void __launch_bounds__(SM_THREADS, 2) msm_small_accumulate(const G1Af
             const uint32_t v = hi_set ? mg >> 8 : mg & 255u;                  // lo in [0, 255], hi in [0, 256]; 0 = no entry in this set
             if (!v) continue;
             const uint32_t b = hi_set ? v - 1 : v;                           // bucket index inside the set
-            if ((b >> 7) != half) continue;
-            uint32_t t = b & 127u;
-            if (cnt[t + 128] < cnt[t]) t += 128;                            // (a stale read only makes the choice a little worse)
-            const uint32_t pos = atomicAdd(&cnt[t], 1u);
-            if (pos < cap) list[t * stride + pos] = (d[w] < 0 ? 0x80000000u : 0u) | (w << 8) | tid;
+            if ((b >> 6) != eighth) continue;
+            const uint32_t t = b & 63u, pos = atomicAdd(&cnt[t], 1u);
+            if (pos < ch) list[t * stride + pos] = (d[w] < 0 ? 0x80000000u : 0u) | (w << 8) | tid;
         }
     }
     __syncthreads();
-    uint32_t c = cnt[tid];
-    if (c > cap) { atomicOr(flag, 1u); c = cap; }
-    const uint32_t *mine = list + tid * stride;
+    const uint32_t bucket = tid >> 2, sub = tid & 3;
+    uint32_t c = cnt[bucket];
+    if (c > ch) { if (sub == 0) atomicOr(flag, 1u); c = ch; }
+    const uint32_t *mine = list + bucket * stride;
     auto point = [&](uint32_t e) __attribute__((always_inline)) { return bases + (size_t)((e >> 8) & 15u) * copy_stride + first + (e & 255u); };
     XyzzW acc = xyzzw_identity();
-    uint32_t e_next = c ? mine[0] : 0;
+    uint32_t e_next = sub < c ? mine[sub] : 0;
     G1Affine nx;
-    if (c) nx = load_affine(point(e_next));
-    for (uint32_t r = 0; r < c; r++) {                        // (the next point is requested before the addition that hides its latency)
+    if (sub < c) nx = load_affine(point(e_next));
+    for (uint32_t r = sub; r < c; r += SM_LANES_PER_BUCKET) {  // (the next point is requested before the addition that hides its latency)
         const G1Affine cur = nx;
         const bool neg = (e_next >> 31) != 0;
-        if (r + 1 < c) { e_next = mine[r + 1]; nx = load_affine(point(e_next)); }
+        if (r + SM_LANES_PER_BUCKET < c) { e_next = mine[r + SM_LANES_PER_BUCKET]; nx = load_affine(point(e_next)); }
         AffW q; q.x = unpack<FqW>(cur.x); q.y = unpack<FqW>(cur.y);
         xyzzw_add_mixed(acc, q, neg);
     }
-    // partial sums: [m][2 g + copy][512 buckets] — msm_small_fold sees 2 G "workgroups"
-    store_xyzzw(partials + ((size_t)m * (gridDim.x >> 1) + 2 * g + (tid >> 7)) * SM_BUCKETS + hi_set * 256 + half * 128 + (tid & 127u), acc);
+    // partial sums: [m][4 g + sub][512 buckets] — msm_small_fold sees 4 G "workgroups"
+    store_xyzzw(partials + ((size_t)m * (gridDim.x >> 3) * 4 + 4 * g + sub) * SM_BUCKETS + hi_set * 256 + eighth * 64 + bucket, acc);
 }
 
 // The two tree kernels run their full additions four lanes at a time (ec29_quad_dev.h: a quad of lanes shares one addition, four products
 // deep instead of fourteen): ~2.6 us per tree level instead of ~7.3.  One addition site per kernel (the operand is chosen beforehand).
 //
-// buckets[m][b] = sum of the G2 partial sums of bucket b (two per accumulate chunk: the bucket's two lanes).  Two shapes of one kernel:
+// buckets[m][b] = sum of the G2 partial sums of bucket b (four per accumulate chunk: the bucket's four lanes).  Two shapes of one kernel:
 //   WIDE  (grid (512, batch), 256 threads = 64 quads per bucket): quad q takes partial sums q, q + 64, .. one after the other, then a tree over the 16 quads of a
 //         wave (shuffles) and over the four waves (LDS) — the shortest chain, for ONE commitment, where the chip is empty anyway;
 //   !WIDE (grid (128, batch), one wave = 16 quads per bucket, four buckets per workgroup): one step more (64 partial sums: 4 + 4 against 1 + 6) for a quarter of the
@@ -175,25 +168,25 @@ int32_t msm_small_launch(plk_ctx::MsmSlot &S, hipStream_t stream, const G1Affine
         PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_small_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_lds(SM_CH_MAX)));
         attr_set = true;
     }
-    static const uint32_t probe_ch = [] { const char *e = getenv("PLK_MSM_SMALL_CH"); return e ? (uint32_t)atoi(e) : 0u; }();   // A/B knob: 32, 64 or 128
+    static const uint32_t probe_ch = [] { const char *e = getenv("PLK_MSM_SMALL_CH"); return e ? (uint32_t)atoi(e) : 0u; }();   // A/B knob: 64, 128 or 256
     static const uint32_t probe_extra = [] { const char *e = getenv("PLK_MSM_SMALL_EXTRA"); return e ? (uint32_t)atoi(e) : 0u; }();
-    static const uint32_t want_wgs = [] { const char *e = getenv("PLK_MSM_SMALL_WGS"); return e ? (uint32_t)atoi(e) : 256u; }();
+    static const uint32_t want_wgs = [] { const char *e = getenv("PLK_MSM_SMALL_WGS"); return e ? (uint32_t)atoi(e) : 512u; }();
     uint32_t ch = SM_CH_MIN;
-    while (ch < SM_CH_MAX && (uint64_t)batch * 4 * ((n + ch - 1) / ch) > want_wgs) ch <<= 1;
-    if (probe_ch == 32 || probe_ch == 64 || probe_ch == 128) ch = probe_ch;
+    while (ch < SM_CH_MAX && (uint64_t)batch * 8 * ((n + ch - 1) / ch) > want_wgs) ch <<= 1;
+    if (probe_ch == 64 || probe_ch == 128 || probe_ch == 256) ch = probe_ch;
     const uint32_t G = (n + ch - 1) / ch;
-    PLK_TRY(S.e.reserve((size_t)batch * 2 * G * SM_BUCKETS * sizeof(XyzzW)));
+    PLK_TRY(S.e.reserve((size_t)batch * 4 * G * SM_BUCKETS * sizeof(XyzzW)));
     PLK_TRY(S.c.reserve((size_t)batch * SM_BUCKETS * sizeof(XyzzW) + 16));
     XyzzW *partials = S.e.as<XyzzW>(), *buckets = S.c.as<XyzzW>();
     uint32_t *flag = reinterpret_cast<uint32_t *>(buckets + (size_t)batch * SM_BUCKETS);
     G1Xyzz *planes = static_cast<G1Xyzz *>(host_out);
     PLK_HIP(hipMemsetAsync(flag, 0, 16, stream));
     if (ev_on) PLK_HIP(hipEventRecord(S.ev[0], stream));
-    hipLaunchKernelGGL(msm_small_accumulate, dim3(4 * G, batch), dim3(SM_THREADS), sm_lds(ch), stream, bases, set, n, ch, sm_cap(ch), copy_stride, partials, flag);
+    hipLaunchKernelGGL(msm_small_accumulate, dim3(8 * G, batch), dim3(SM_THREADS), sm_lds(ch), stream, bases, set, n, ch, copy_stride, partials, flag);
     if (ev_on) (void)hipEventRecord(S.ev[1], stream);
     (void)hipEventRecord(S.acc_done, stream);
-    if (batch == 1) hipLaunchKernelGGL(msm_small_fold<true>, dim3(SM_BUCKETS, batch), dim3(256), 0, stream, (const XyzzW *)partials, 2 * G, buckets);
-    else hipLaunchKernelGGL(msm_small_fold<false>, dim3(SM_BUCKETS / 4, batch), dim3(256), 0, stream, (const XyzzW *)partials, 2 * G, buckets);
+    if (batch == 1) hipLaunchKernelGGL(msm_small_fold<true>, dim3(SM_BUCKETS, batch), dim3(256), 0, stream, (const XyzzW *)partials, 4 * G, buckets);
+    else hipLaunchKernelGGL(msm_small_fold<false>, dim3(SM_BUCKETS / 4, batch), dim3(256), 0, stream, (const XyzzW *)partials, 4 * G, buckets);
     hipLaunchKernelGGL(msm_small_planes, dim3(SM_PLANES, batch), dim3(512), 0, stream, (const XyzzW *)buckets, planes, (const uint32_t *)flag,
                        reinterpret_cast<uint32_t *>(planes + (size_t)batch * SM_PLANES), probe_extra);
     PLK_HIP(hipGetLastError());

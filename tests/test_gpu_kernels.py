@@ -218,7 +218,7 @@ def test_msm_scalar_distributions(ctx, srs16, kind, n):
 
 @pytest.mark.parametrize("n", [64, 300, 4096, 8192, 10000])
 def test_msm_short_path_list_overflow(ctx, srs16, n):
-    """short commitments (msm_small.hip, <= 2^14 terms): a bucket list holds 64 entries of a 64-term workgroup; a constant column whose scalar carries
+    """short commitments (msm_small.hip, <= 2^15 terms): a bucket list holds as many entries as its workgroup has terms (64 .. 256); a constant column whose scalar carries
     the SAME digit in several windows (3 * (1 + 2^17 + .. + 2^68): five windows put five entries each into lo bucket 3, and 2^8-multiples
     do the same to a hi bucket) overflows it — the overflow flag makes msm_finish_batch run the ordinary pipeline (or, below 4096 terms,
     the per-term double-and-add) on the same inputs.  Also a mix: half the column constant, half uniform."""
@@ -229,7 +229,7 @@ def test_msm_short_path_list_overflow(ctx, srs16, n):
     rng = random.Random(n)
     ks = [rep if i % 2 else rng.randrange(R_MOD) for i in range(n)]
     assert np.array_equal(ctx.msm(ol.fr_vec(ks)), _trapdoor(ks))
-    ks = [1] * n                                                    # one entry per term, all in lo bucket 1: 64 per list, exactly the capacity
+    ks = [1] * n                                                    # one entry per term, all in lo bucket 1: exactly the capacity of its list
     assert np.array_equal(ctx.msm(ol.fr_vec(ks)), _trapdoor(ks))
 
 
