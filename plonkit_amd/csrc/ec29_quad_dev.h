@@ -36,6 +36,19 @@ __device__ __forceinline__ FqW9 quad_sel(uint32_t role, const FqW9 &v0, const Fq
     return r;
 }
 
+// the point held by lane `src` of the wave (36 ds_bpermute)
+__device__ __forceinline__ XyzzW quad_shfl(const XyzzW &v, int src) {
+    XyzzW r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        r.x.l[i] = __shfl(v.x.l[i], src);
+        r.y.l[i] = __shfl(v.y.l[i], src);
+        r.zz.l[i] = __shfl(v.zz.l[i], src);
+        r.zzz.l[i] = __shfl(v.zzz.l[i], src);
+    }
+    return r;
+}
+
 // a + b; every lane of the quad passes the same a and the same b and receives the same sum
 __device__ __forceinline__ XyzzW xyzzw_add_quad(const XyzzW &a, const XyzzW &b, uint32_t role) {
     const bool inf_a = is_inf(a), inf_b = is_inf(b);
@@ -78,6 +91,94 @@ __device__ __forceinline__ XyzzW xyzzw_add_quad(const XyzzW &a, const XyzzW &b, 
     XyzzW out;
     out.x = pick(o.x, a.x, b.x); out.y = pick(o.y, a.y, b.y); out.zz = pick(o.zz, a.zz, b.zz); out.zzz = pick(o.zzz, a.zzz, b.zzz);
     return out;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// DISTRIBUTED form (late round 6): lane r of a quad holds ONLY coordinate r of a point (0: X, 1: Y, 2: ZZ, 3: ZZZ) — 9 registers per operand
+// instead of 36, and no four-way operand selects: the same four product stages as above with the values placed so that most operands
+// are already where they are needed.  A and B in, A + B out, all in this form:
+//     B' = B by quad_perm [2,3,0,1]                   lane:     0          1          2          3
+//     T1 = A * B'                                               U1         S1         U2         S2
+//     D  = T1 by quad_perm [2,3,0,1] - T1                       P          R          (-P)       (-R)
+//     T2 = (lanes 0,1: D * D; lanes 2,3: A * B)                 PP         RR         ZZ12       ZZZ12
+//     T3 = (D | - | T2 | U1 from lane 0) * PP from lane 0       PPP        -          ZZ3        Q
+//     X3 = RR - PPP - 2 Q (every lane, from three broadcasts)
+//     T4 = (S1 from lane 1 | D | - | T2) * (PPP | Q - X3 | - | PPP)   B    A          -          ZZZ3
+//     out = X3 | A - B | T3 | T4
+// ~80 DPP moves and ~110 selects per addition instead of ~550, and a partner's point is 9 ds_bpermute instead of 36.  The values (and their
+// bounds) are those of xyzzw_add_quad: the Montgomery product does not depend on the order of its operands.
+constexpr int QP_SWAP2 = 2 | (3 << 2) | (0 << 4) | (1 << 6);            // quad_perm:[2,3,0,1]
+template <int CTRL>
+__device__ __forceinline__ FqW9 quad_dpp(const FqW9 &v) {
+    FqW9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[i], CTRL, 0xf, 0xf, false);
+    return r;
+}
+template <int SRC>
+__device__ __forceinline__ bool quad_flag(bool f) { return __builtin_amdgcn_mov_dpp((int)f, SRC * 0x55, 0xf, 0xf, false) != 0; }
+__device__ __forceinline__ FqW9 wsel(bool c, const FqW9 &a, const FqW9 &b) {
+    FqW9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+}
+// coordinate `role` of a point in memory / of a point held in full by this lane
+__device__ __forceinline__ FqW9 load_coord(const XyzzW *p, uint32_t role) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+    const u32x4 a = *reinterpret_cast<const u32x4 *>(w + 8 * role), b = *reinterpret_cast<const u32x4 *>(w + 8 * role + 4);
+    FqW9 r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = w[32 + role];
+    return r;
+}
+__device__ __forceinline__ void store_coord(XyzzW *p, uint32_t role, const FqW9 &v) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(p);
+    *reinterpret_cast<u32x4 *>(w + 8 * role) = u32x4{v.l[0], v.l[1], v.l[2], v.l[3]};
+    *reinterpret_cast<u32x4 *>(w + 8 * role + 4) = u32x4{v.l[4], v.l[5], v.l[6], v.l[7]};
+    w[32 + role] = v.l[8];
+}
+__device__ __forceinline__ FqW9 coord_shfl_xor(const FqW9 &v, int mask) {      // (mask a multiple of 4: the partner quad's lane of the same role)
+    FqW9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = __shfl_xor(v.l[i], mask);
+    return r;
+}
+// the point held in full by lane SRC of the quad, in distributed form
+template <int SRC>
+__device__ __forceinline__ FqW9 quad_distribute(const XyzzW &v, uint32_t role) {
+    const FqW9 x = quad_bcast<SRC>(v.x), y = quad_bcast<SRC>(v.y), zz = quad_bcast<SRC>(v.zz), zzz = quad_bcast<SRC>(v.zzz);
+    return wsel(role < 2, wsel(role == 0, x, y), wsel(role == 2, zz, zzz));
+}
+// distributed -> held in full by every lane of the quad
+__device__ __forceinline__ XyzzW quad_gather(const FqW9 &c) {
+    XyzzW r; r.x = quad_bcast<0>(c); r.y = quad_bcast<1>(c); r.zz = quad_bcast<2>(c); r.zzz = quad_bcast<3>(c);
+    return r;
+}
+
+__device__ __forceinline__ FqW9 xyzzw_add_dist(const FqW9 &A, const FqW9 &B, uint32_t role) {
+    const bool inf_a = quad_flag<2>(w_all_zero(A)), inf_b = quad_flag<2>(w_all_zero(B));
+    const FqW9 T1 = LM(A, quad_dpp<QP_SWAP2>(B));                                   // U1 | S1 | U2 | S2
+    const FqW9 D = sub2(quad_dpp<QP_SWAP2>(T1), T1);                                // P | R | . | .
+    if (!inf_a && !inf_b && quad_flag<0>(maybe_zero_mod_p(D))) {                     // (quad-uniform) doubling, opposite points or a false alarm: rare
+        XyzzW a = quad_gather(A);
+        const XyzzW b = quad_gather(B);
+        xyzzw_add(a, b);
+        return wsel(role < 2, wsel(role == 0, a.x, a.y), wsel(role == 2, a.zz, a.zzz));
+    }
+    const bool low = role < 2;
+    const FqW9 T2 = LM(wsel(low, D, A), wsel(low, D, B));                           // PP | RR | ZZ12 | ZZZ12
+    const FqW9 pp = quad_bcast<0>(T2);
+    const FqW9 T3 = LM(wsel(role == 0, D, wsel(role == 2, T2, quad_bcast<0>(T1))), pp);   // PPP | . | ZZ3 | Q
+    const FqW9 rr = quad_bcast<1>(T2), ppp = quad_bcast<0>(T3), qq = quad_bcast<3>(T3);
+    FqW9 x3;
+#pragma unroll
+    for (int i = 0; i < 9; i++) x3.l[i] = rr.l[i] + FqW::PAD4[i] - ppp.l[i] - 2 * qq.l[i];
+    x3 = normw(x3);
+    const FqW9 rhs = sub6(qq, x3);
+    const FqW9 T4 = LM(wsel(role == 1, D, wsel(role == 3, T2, quad_bcast<1>(T1))), wsel(role == 1, rhs, ppp));   // B | A | . | ZZZ3
+    const FqW9 y3 = sub2(T4, quad_bcast<0>(T4));
+    const FqW9 out = wsel(low, wsel(role == 0, x3, y3), wsel(role == 2, T3, T4));
+    return wsel(inf_b, A, wsel(inf_a, B, out));
 }
 
 }  // namespace plk

@@ -37,6 +37,7 @@
 // everything else (recoding, partition, bucket reduction, drivers, the FIFO of three slots, plk_ctx_share_srs) is here.
 #include "msm_shape.h"
 #include "msm.h"
+#include "ec29_quad_dev.h"
 #include "comm.h"
 #include "hostmath.h"
 #include <cstring>
@@ -494,8 +495,9 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_fold_hot(XyzzW *partials, con
     const uint32_t task = gt / RL, sub = gt % RL;
     const bool live = task < task_start[total_bins];
     const uint32_t *meta = task_meta + (size_t)(live ? task : 0) * META_PER_TASK;
-    const uint32_t nc = live ? meta[FINE + 1] : 0;
-    const uint32_t mu = nc ? (nc + MSM_THREADS - 1) / MSM_THREADS : 1;
+    const uint32_t nc_raw = live ? meta[FINE + 1] : 0, nc = nc_raw & ~TASK_OWNED_BIT;
+    if (!__any(nc != 0 && !(nc_raw & TASK_OWNED_BIT))) return;      // (owned tasks have one sum per bucket: nothing is spread)
+    const uint32_t mu = (nc_raw & TASK_OWNED_BIT) ? 0x7fffffffu : (nc ? (nc + MSM_THREADS - 1) / MSM_THREADS : 1);
     uint32_t hot_mask = 0;                                    // which of this lane's RB buckets are wide
     if (nc) for (uint32_t k = 0; k < RB; k++) if (bucket_span(meta, RB * sub + k, mu) > HOT_SPAN) hot_mask |= 1u << k;
     if (!__any(hot_mask != 0)) return;
@@ -533,8 +535,8 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_task_reduce(const XyzzW *p
     const uint32_t task = gt / RL, sub = gt % RL;
     const bool live = task < task_start[total_bins];
     const uint32_t *meta = task_meta + (size_t)(live ? task : 0) * META_PER_TASK;
-    const uint32_t nc = live ? meta[FINE + 1] : 0;
-    const uint32_t mu = nc ? (nc + MSM_THREADS - 1) / MSM_THREADS : 1;
+    const uint32_t nc_raw = live ? meta[FINE + 1] : 0, nc = nc_raw & ~TASK_OWNED_BIT;
+    const uint32_t mu = (nc_raw & TASK_OWNED_BIT) ? 0x7fffffffu : (nc ? (nc + MSM_THREADS - 1) / MSM_THREADS : 1);   // (owned: every bucket is whole — PRIMARY)
     const XyzzW *P = partials + (size_t)(live ? task : 0) * SLOTS_PER_TASK;
     XyzzW X = xyzzw_identity(), Y = xyzzw_identity();
     uint32_t k = nc ? RB : 0;                                 // buckets of this lane still to open (top first)
@@ -590,6 +592,75 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_task_reduce(const XyzzW *p
         if (to_y) Y = Tacc; else X = Tacc;
     }
     if (live && sub == 0) store_xyzzw(task_out + 2 * (size_t)task, X);
+}
+
+// The same reduction by quads of lanes (late round 6; ec29_quad_dev.h, distributed form): RL = 16 QUADS per task (one wave), RB = FINE / 16 buckets per quad,
+// every step one four-lane addition (2.6 us for a wave alone on its SIMD against 7.3 for the lane-wise addition).  Launched for one or two commitments
+// (1024 / 2048 waves: one / two per SIMD); a batch of three or more keeps the lane-wise kernel, whose 16 lanes per task do the same work in a quarter
+// of the lanes.  The RB_LOG doublings (X + X) leave through the addition's rare branch.
+template <uint32_t FB>
+__global__ void __launch_bounds__(MSM_THREADS) msm_task_reduce_quad(const XyzzW *partials, const uint32_t *task_meta, const uint32_t *task_start, XyzzW *task_out, uint32_t total_bins) {
+    constexpr uint32_t FINE = Shape<FB>::FINE, SLOT_PRIMARY = Shape<FB>::SLOT_PRIMARY, SLOT_HEAD = Shape<FB>::SLOT_HEAD, SLOT_TAIL = Shape<FB>::SLOT_TAIL,
+                       SLOTS_PER_TASK = Shape<FB>::SLOTS_PER_TASK, META_PER_TASK = Shape<FB>::META_PER_TASK, RL_LOG = 4, RL = 1u << RL_LOG, RB = FINE / RL, RB_LOG = FB - RL_LOG;
+    latency_chain_priority();
+    const uint32_t task = blockIdx.x * (MSM_THREADS / 64) + (threadIdx.x >> 6), sub = (threadIdx.x & 63u) >> 2, coord = threadIdx.x & 3u;
+    const bool live = task < task_start[total_bins];
+    const uint32_t *meta = task_meta + (size_t)(live ? task : 0) * META_PER_TASK;
+    const uint32_t nc_raw = live ? meta[FINE + 1] : 0, nc = nc_raw & ~TASK_OWNED_BIT;
+    const uint32_t mu = (nc_raw & TASK_OWNED_BIT) ? 0x7fffffffu : (nc ? (nc + MSM_THREADS - 1) / MSM_THREADS : 1);
+    const XyzzW *P = partials + (size_t)(live ? task : 0) * SLOTS_PER_TASK;
+    FqW9 X = w_zero<FqW>(), Y = w_zero<FqW>();
+    uint32_t k = nc ? RB : 0;                                 // buckets of this quad still to open (top first)
+    uint32_t piece = 0, piece_end = 0;                        // slots of the open bucket still to add
+    bool pending_sum = false;
+    constexpr uint32_t USTEPS = RL_LOG + RB_LOG + 1 + RL_LOG;
+    uint32_t ustep = 0;
+    for (;;) {
+        const bool done = (piece >= piece_end) && !pending_sum && k == 0;
+        const bool lockstep = __all(done);                    // every quad of the wave (= the task) has folded its buckets
+        if (lockstep && ustep == USTEPS) break;
+        FqW9 O = w_zero<FqW>();
+        bool to_y = false;
+        if (!lockstep) {
+            if (piece < piece_end) { O = load_coord(P + piece, coord); piece++; }
+            else if (pending_sum) { to_y = true; pending_sum = false; }
+            else if (k > 0) {
+                k--;
+                const uint32_t b = RB * sub + k, s0 = meta[b], e0 = meta[b + 1];
+                if (e0 > s0) {
+                    const uint32_t tf = s0 / mu, tl = (e0 - 1) / mu;
+                    pending_sum = true;
+                    if (tf == tl) O = load_coord(P + SLOT_PRIMARY + b, coord);
+                    else {
+                        O = load_coord(P + SLOT_TAIL + tf, coord);
+                        if (tl - tf > HOT_SPAN) { piece = SLOT_PRIMARY + b; piece_end = piece + 1; }      // folded by B0
+                        else { piece = SLOT_HEAD + tf + 1; piece_end = SLOT_HEAD + tl + 1; }
+                    }
+                } else to_y = true;                           // empty bucket: only Y += X
+            }
+        } else {
+            // S = sum_sub Y_sub + RB * sum_{sub >= 1} R_sub with R_sub = sum_{s >= sub} X_s (suffix scan); T = R_0
+            if (ustep < RL_LOG) {
+                const uint32_t off = 1u << ustep;
+#pragma unroll
+                for (int i = 0; i < 9; i++) O.l[i] = __shfl_down(X.l[i], 4 * off);
+                if (sub + off >= RL) O = w_zero<FqW>();
+            } else {
+                if (ustep == RL_LOG) {
+                    if (live && sub == 0) store_coord(task_out + 2 * (size_t)task + 1, coord, X);
+                    if (sub == 0) X = w_zero<FqW>();
+                }
+                if (ustep < RL_LOG + RB_LOG) O = X;                               // doubling (the addition's rare branch handles P + P)
+                else if (ustep == RL_LOG + RB_LOG) O = Y;
+                else O = coord_shfl_xor(X, 4 << (ustep - RL_LOG - RB_LOG - 1));
+            }
+            ustep++;
+        }
+        if (to_y) O = Y;
+        const FqW9 Tacc = xyzzw_add_dist(X, O, coord);        // the one addition site of the kernel
+        if (to_y) Y = Tacc; else X = Tacc;
+    }
+    if (live && sub == 0) store_coord(task_out + 2 * (size_t)task, coord, X);
 }
 
 // ------------------------------------------------------------------------ bin folding
@@ -667,6 +738,65 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_window_sums(const XyzzW *t
         xyzzw_add(X, O);                                      // the one addition site of the kernel
     }
     if (tid == 0) store_xyzz(window_out + (size_t)roles * w + role, xyzzw_export(X));
+}
+
+// The same sums by quads of lanes (late round 6; ec29_quad_dev.h, distributed form: lane r of a quad holds coordinate r of its running sum): a full
+// addition is four products deep instead of fourteen — 2.6 us per step for a wave that has its SIMD to itself against 7.3 — and the steps carry no
+// workgroup barrier (waves run their own bins, then ONE exchange through LDS).  One workgroup of 64 quads per (bucket set, role); role 0 is split in two
+// (bins below / from nbins / 2: the second half is the LAST role, the host adds the two) so that no quad walks more than nbins / 128 bins; the G_b roles
+// enumerate their nbins / 2 bins directly.  12 + 6 steps of 2.6 us at 1024 bins against 4 + 8 steps of 8.3 us (msm_window_sums: 100 -> ~45 us on the tail of every
+// commitment of >= 2^16 terms).
+__global__ void __launch_bounds__(MSM_THREADS) msm_window_sums_quad(const XyzzW *task_out, const uint32_t *task_start, G1Xyzz *window_out, uint32_t nbins, uint32_t roles) {
+    __shared__ __attribute__((aligned(16))) uint32_t sh[4][4][9];
+    latency_chain_priority();
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, coord = tid & 3, quad = tid >> 2, w = blockIdx.x, role = blockIdx.y;
+    const bool second_half = role == roles - 1;
+    const uint32_t which = (role == 0 || second_half) ? 0u : 1u;
+    const uint32_t count = role >= WS_FIRST_F_ROLE && !second_half ? MSM_THREADS : nbins / 2;
+    auto bin_of = [&](uint32_t j) -> uint32_t {
+        if (second_half) return nbins / 2 + j;
+        if (role == 0) return j;
+        if (role >= WS_FIRST_F_ROLE) return (role - WS_FIRST_F_ROLE + 1) * MSM_THREADS + j;
+        const uint32_t b = role - 1;                          // the j-th bin index with bit b set
+        return ((j >> b) << (b + 1)) | (1u << b) | (j & ((1u << b) - 1));
+    };
+    uint32_t j = quad, t = 0, t_end = 0;
+    auto open_bin = [&]() {                                   // next non-empty bin of this quad
+        for (; j < count; j += 64) {
+            const uint32_t bin = bin_of(j);
+            if (bin >= nbins) continue;
+            t = task_start[w * nbins + bin]; t_end = task_start[w * nbins + bin + 1];
+            if (t < t_end) { j += 64; return; }
+        }
+        t = t_end = 0;
+    };
+    open_bin();
+    FqW9 X = w_zero<FqW>();
+    uint32_t ustep = 0;
+    for (;;) {
+        const bool lockstep = __all(t >= t_end);              // every quad of the WAVE has walked its bins
+        if (lockstep && ustep == 6) break;
+        FqW9 O = w_zero<FqW>();
+        if (!lockstep) {
+            if (t < t_end) {
+                O = load_coord(task_out + 2 * (size_t)t + which, coord);
+                if (++t == t_end) open_bin();
+            }
+        } else {
+            if (ustep == 4) {                                 // the four waves' sums change hands through LDS (the one barrier of the kernel)
+                if (lane < 4) for (int i = 0; i < 9; i++) sh[wave][coord][i] = X.l[i];
+                __syncthreads();
+                if ((lane >> 2) < 4) { for (int i = 0; i < 9; i++) X.l[i] = sh[lane >> 2][coord][i]; } else X = w_zero<FqW>();
+            }
+            O = coord_shfl_xor(X, 4 << (ustep & 3));
+            ustep++;
+        }
+        X = xyzzw_add_dist(X, O, coord);                      // the one addition site of the kernel
+    }
+    if (tid < 4) {                                            // each lane of the first quad exports its coordinate (canonical, R = 2^256; the identity is all zero)
+        const bool inf = quad_flag<2>(w_all_zero(X));
+        store_fp(&window_out[(size_t)roles * w + role].x + coord, inf ? Fq::zero() : pack<FqParams>(s_from_w(X)));
+    }
 }
 
 // ------------------------------------------------------------------- tiny inputs: no buckets
@@ -755,7 +885,7 @@ static int32_t msm_big_launch(plk_ctx *ctx, plk_ctx::MsmSlot &S, hipStream_t str
     const uint32_t META_PER_TASK = meta_per_task(p.fine_bits), SLOTS_PER_TASK = slots_per_task(p.fine_bits);
     PLK_TRY(S.c.reserve((size_t)max_tasks * 2 * sizeof(XyzzW) + (size_t)max_tasks * META_PER_TASK * 4));  // per-task (S, T) + bucket offsets
     PLK_TRY(S.e.reserve((size_t)max_tasks * SLOTS_PER_TASK * sizeof(XyzzW)));             // lane partial sums
-    PLK_TRY(S.d.reserve((size_t)12 * total_sets * sizeof(G1Xyzz)));                    // per bucket set: sum S, G_0..G_7, F_1..F_3
+    PLK_TRY(S.d.reserve((size_t)13 * total_sets * sizeof(G1Xyzz)));                    // per bucket set: sum S, G_0..G_7, F_1..F_3
     uint32_t *hist = S.a.as<uint32_t>(), *bin_start = hist + total_bins, *task_start = bin_start + total_bins + 1;
     uint32_t *entries = S.b.as<uint32_t>();
     XyzzW *task_out = S.c.as<XyzzW>();
@@ -801,10 +931,21 @@ static int32_t msm_big_launch(plk_ctx *ctx, plk_ctx::MsmSlot &S, hipStream_t str
         constexpr uint32_t FB = decltype(fb_tag)::value;
         // PLK_MSM_ONE_WAVE=1 (measurement knob): the same kernel compiled for one wave per SIMD (512 registers, no spill)
         static const bool one_wave = getenv("PLK_MSM_ONE_WAVE") != nullptr;
-        msm_accumulate_launch(FB, one_wave, max_tasks, stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start, (const uint32_t *)task_start, partials, task_meta, p);
+        // commitments of <= 2^16 terms: the build whose lanes own the buckets of an evenly filled task (msm_accumulate.hip; PLK_MSM_OWNED_MAX overrides, 0 = never)
+        static const long long owned_max = [] { const char *e = getenv("PLK_MSM_OWNED_MAX"); return e ? (long long)strtoull(e, nullptr, 10) : (1ll << 16); }();
+        const int variant = one_wave ? 1 : (FB == 6 && (long long)n <= owned_max ? 2 : 0);
+        msm_accumulate_launch(FB, variant, max_tasks, stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start, (const uint32_t *)task_start, partials, task_meta, p);
         if (ctx->ev_on) (void)hipEventRecord(S.ev[1], stream);
         (void)hipEventRecord(S.acc_done, stream);
-        if (rl_log == 4) {
+        // one or two commitments: the bucket reduction by quads of lanes (PLK_MSM_TR_QUAD=0: the lane-wise kernel for every batch size, A/B knob)
+        static const bool tr_quad = [] { const char *e = getenv("PLK_MSM_TR_QUAD"); return !(e && e[0] == '0'); }();
+        // (only when no other commitment is in flight on this context: the quads do the same additions in 1.5x the lane-instructions, which a stream of
+        //  commitments — whose reductions share the GPU with the next accumulation — pays for: three in flight at 2^16 terms 0.243 -> 0.255 ms, measured)
+        if (tr_quad && probe_rl == 0 && batch <= 2 && ctx->msm_enq == ctx->msm_fin) {
+            hipLaunchKernelGGL((msm_fold_hot<FB, 5>), dim3(rblocks), dim3(MSM_THREADS), 0, stream, partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
+            hipLaunchKernelGGL((msm_task_reduce_quad<FB>), dim3((max_tasks + MSM_THREADS / 64 - 1) / (MSM_THREADS / 64)), dim3(MSM_THREADS), 0, stream,
+                               (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
+        } else if (rl_log == 4) {
             hipLaunchKernelGGL((msm_fold_hot<FB, 4>), dim3(rblocks), dim3(MSM_THREADS), 0, stream, partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
             hipLaunchKernelGGL((msm_task_reduce<FB, 4>), dim3(rblocks), dim3(MSM_THREADS), 0, stream,
                                (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
@@ -816,8 +957,14 @@ static int32_t msm_big_launch(plk_ctx *ctx, plk_ctx::MsmSlot &S, hipStream_t str
     };
     if (p.fine_bits == 6) launch_shape(std::integral_constant<uint32_t, 6>{}); else launch_shape(std::integral_constant<uint32_t, 7>{});
     hipLaunchKernelGGL(msm_bin_fold, dim3((total_bins + MSM_THREADS / 64 - 1) / (MSM_THREADS / 64)), dim3(MSM_THREADS), 0, stream, task_out, (const uint32_t *)task_start, total_bins);
-    const uint32_t roles = WS_FIRST_F_ROLE + (p.nbins + MSM_THREADS - 1) / MSM_THREADS - 1;   // points per bucket set left for the host: S, G_0..G_7, F_1 ..
-    hipLaunchKernelGGL(msm_window_sums, dim3(total_sets, roles), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins, roles);
+    // points per bucket set left for the host: S (bins below nbins / 2), G_0..G_7, F_1 .., S (bins from nbins / 2)
+    const uint32_t roles = WS_FIRST_F_ROLE + (p.nbins + MSM_THREADS - 1) / MSM_THREADS - 1 + 1;
+    static const bool ws_quad = [] { const char *e = getenv("PLK_MSM_WS_QUAD"); return !(e && e[0] == '0'); }();      // A/B knob: 0 = the lane-wise kernel (its last role is the identity)
+    if (ws_quad) hipLaunchKernelGGL(msm_window_sums_quad, dim3(total_sets, roles), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins, roles);
+    else {
+        PLK_HIP(hipMemsetAsync(window_out, 0, (size_t)roles * total_sets * sizeof(G1Xyzz), stream));
+        hipLaunchKernelGGL(msm_window_sums, dim3(total_sets, roles - 1), dim3(MSM_THREADS), 0, stream, (const XyzzW *)task_out, (const uint32_t *)task_start, window_out, p.nbins, roles);
+    }
     PLK_HIP(hipGetLastError());
     PLK_TRY(slot_pinned(S, (size_t)roles * total_sets * sizeof(G1Xyzz)));
     PLK_HIP(hipMemcpyAsync(S.pinned, window_out, (size_t)roles * total_sets * sizeof(G1Xyzz), hipMemcpyDeviceToHost, stream));
@@ -953,17 +1100,17 @@ int32_t msm_finish_batch(plk_ctx *ctx, hipStream_t, host::HJac *out) {
             const uint64_t *raw = reinterpret_cast<const uint64_t *>(S.pinned) + (size_t)16 * SM_PLANES_HOST * m;
             for (int b = (int)SM_PLANES_HOST - 1; b >= 0; b--) acc = jac_add(jac_double(acc), xyzz_host_to_jac(raw + 16 * b));
         } else if (S.windows) {
-            // per bucket set the device leaves (sum S, G_0..G_7, F_1, .., F_{halves-1});
+            // per bucket set the device leaves (sum S over the lower bins, G_0..G_7, F_1, .., F_{halves-1}, sum S over the upper bins);
             // W = sum S + 2^FB * (sum_b 2^b G_b + 2^8 * sum_u u*F_u)
             const size_t per = (size_t)16 * S.roles;
             const uint64_t *raw = reinterpret_cast<const uint64_t *>(S.pinned) + per * m * S.windows;
             for (int w = (int)S.windows - 1; w >= 0; w--) {
                 for (uint32_t i = 0; i < S.c_bits; i++) acc = jac_double(acc);
                 HJac run = HJac::inf(), d = HJac::inf();                  // sum_u u*F_u = sum of the suffix sums of F
-                for (uint32_t r = S.roles - 1; r >= WS_FIRST_F_ROLE; r--) { run = jac_add(run, xyzz_host_to_jac(raw + per * w + 16 * r)); d = jac_add(d, run); }
+                for (uint32_t r = S.roles - 2; r >= WS_FIRST_F_ROLE; r--) { run = jac_add(run, xyzz_host_to_jac(raw + per * w + 16 * r)); d = jac_add(d, run); }
                 for (int b = (int)WS_BIT_ROLES - 1; b >= 0; b--) d = jac_add(jac_double(d), xyzz_host_to_jac(raw + per * w + 16 * (1 + b)));   // Horner over the bit sums
                 for (uint32_t i = 0; i < S.fine_bits; i++) d = jac_double(d);
-                acc = jac_add(acc, jac_add(xyzz_host_to_jac(raw + per * w), d));
+                acc = jac_add(acc, jac_add(jac_add(xyzz_host_to_jac(raw + per * w), xyzz_host_to_jac(raw + per * w + 16 * (S.roles - 1))), d));   // (sum S in two halves)
             }
         } else {
             const uint64_t *raw = reinterpret_cast<const uint64_t *>(S.pinned) + (size_t)16 * m * S.pending_parts;

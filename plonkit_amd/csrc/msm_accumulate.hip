@@ -7,6 +7,7 @@
 // (SQ counters: the SIMDs issue ~100 % of the time, the s_nop wait states of the product chains are hidden by the second wave),
 // so a schedule can only win what a better instruction ORDER wins — about 2 %.
 #include "msm_shape.h"
+#include "ec29_quad_dev.h"
 #include <atomic>
 
 namespace plk {
@@ -23,14 +24,23 @@ namespace plk {
 // branches (P == +-Q: doubling / identity, and the generic addition behind the zero filter's false positives), which round 3's
 // lockstep products pushed out of registers.  Measured harmless for uniform scalars; all-(r-1) scalars, where every addition
 // of a window meets equal points, run 1.27x the uniform time.  Kernel B folds the partial sums.
-template <uint32_t FB, int MINW = 2>
+//
+// OWNED (round 6, the instantiation launched for commitments of <= 2^16 terms; the 2^20 kernel is compiled without it and is the same code as before):
+// with few entries per bucket the equal pieces make every bucket a TAIL and several HEADs — at 2^16 terms a bucket's ~15 entries lie in four lanes' pieces of
+// four, and msm_task_reduce then walks ~5 partial sums per bucket instead of one (a chain of ~44 dependent full additions instead of 19: 0.33 ms of the 0.79 ms
+// of a batch of four commitments, beside an accumulation of 0.24).  A task whose fullest bucket holds <= 8 mu + 24 entries (mu = entries per lane: every task of uniform scalars — the reduction kernels take as long as
+// their slowest wave, so ALL tasks have to qualify for them to gain) is
+// accumulated the way msm_small.hip does it instead: the four lanes 4 b .. 4 b + 3 OWN bucket b, lane j takes entries j, j + 4, .. of its run, the quad adds
+// its four sums up (three four-lane additions) and stores ONE PRIMARY sum per bucket; the entry count in the task's meta carries bit 31, which makes the
+// two reduction kernels treat every bucket as whole.  Hot buckets (repeated scalars) fail the test and keep the equal pieces.
+template <uint32_t FB, int MINW = 2, bool OWNED = false>
 __global__ void __launch_bounds__(MSM_THREADS, MINW) msm_accumulate(const G1Affine *bases, const uint32_t *entries,
                                                                   const uint32_t *bin_start, const uint32_t *task_start,
                                                                   XyzzW *partials, uint32_t *task_meta, MsmParams p) {
     constexpr uint32_t FINE = Shape<FB>::FINE, SLOT_PRIMARY = Shape<FB>::SLOT_PRIMARY, SLOT_HEAD = Shape<FB>::SLOT_HEAD,
                        SLOT_TAIL = Shape<FB>::SLOT_TAIL, SLOTS_PER_TASK = Shape<FB>::SLOTS_PER_TASK, META_PER_TASK = Shape<FB>::META_PER_TASK;
     extern __shared__ uint32_t sorted[];                      // [CHUNK]
-    __shared__ uint32_t cnt[FINE], start[FINE + 1], cursor[FINE];
+    __shared__ uint32_t cnt[FINE], start[FINE + 1], cursor[FINE], max_cnt;
     const uint32_t tid = threadIdx.x, task = blockIdx.x;
     const uint32_t total_bins = p.batch * p.groups * p.nbins;
     if (task >= task_start[total_bins]) return;
@@ -94,11 +104,20 @@ __global__ void __launch_bounds__(MSM_THREADS, MINW) msm_accumulate(const G1Affi
 #pragma unroll
         for (uint32_t k = 0; k < PER; k++) { start[PER * tid + k] = run; run += own[k]; }
         if (tid == 63) start[FINE] = v;
+        if (OWNED) {
+            uint32_t mx = own[0];
+#pragma unroll
+            for (uint32_t k = 1; k < PER; k++) mx = own[k] > mx ? own[k] : mx;
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_xor(mx, off); mx = t > mx ? t : mx; }
+            if (tid == 0) max_cnt = mx;
+        }
     }
     __syncthreads();
     uint32_t *meta = task_meta + (size_t)task * META_PER_TASK;
+    const uint32_t mu = (nc + MSM_THREADS - 1) / MSM_THREADS;
+    const bool owned = OWNED && FINE * 4 == MSM_THREADS && max_cnt <= 8 * mu + 24;     // (workgroup-uniform)
     if (tid <= FINE) meta[tid] = start[tid];
-    if (tid == 0) meta[FINE + 1] = nc;
+    if (tid == 0) meta[FINE + 1] = nc | (owned ? TASK_OWNED_BIT : 0u);
     if (wave_hot) {
         uint32_t base = 0;
         if ((tid & 63) == 0) base = atomicAdd(&cursor[f0], wave_n);
@@ -113,24 +132,32 @@ __global__ void __launch_bounds__(MSM_THREADS, MINW) msm_accumulate(const G1Affi
     }
     __syncthreads();
     if (nc == 0 || p.debug == 3) return;                      // (debug 3: time the sort alone)
-    const uint32_t mu = (nc + MSM_THREADS - 1) / MSM_THREADS;
-    const uint32_t lo = tid * mu < nc ? tid * mu : nc, hi = lo + mu < nc ? lo + mu : nc;
     XyzzW *out = partials + (size_t)task * SLOTS_PER_TASK;
-    if (lo >= hi) return;
-    // one flat loop over the lane's piece: every lane of the wave executes the same number of mixed additions
-    // in lockstep; a bucket boundary only costs the (divergent) 144-byte flush of the finished accumulator
     const uint32_t imask = (1u << p.nbits) - 1;
     auto point_of = [&](uint32_t entry) -> const G1Affine * {          // (copy j, index i) -> address in the table
         const uint32_t t = entry >> 8;
         return bases + (size_t)(t >> p.nbits) * p.copy_stride + (t & imask);
     };
-    uint32_t en = sorted[lo], b = en & (FINE - 1), bend = start[b + 1], run_start = lo;
-    G1Affine pt = load_affine(point_of(en));
+    // one flat loop over the lane's piece: every lane of the wave executes the same number of mixed additions
+    // in lockstep; a bucket boundary only costs the (divergent) 144-byte flush of the finished accumulator.
+    // (The same loop — one mixed-addition site — serves the owned shape: first / step / last differ, and no bucket boundary is ever met.)
+    const bool own = OWNED && owned;
+    const uint32_t step = own ? 4u : 1u;
+    uint32_t lo, hi;
+    if (own) { lo = start[tid >> 2] + (tid & 3u); hi = start[(tid >> 2) + 1]; }
+    else {
+        lo = tid * mu < nc ? tid * mu : nc; hi = lo + mu < nc ? lo + mu : nc;
+        if (lo >= hi) return;
+    }
+    uint32_t en = 0, b = tid >> 2, bend = 0xffffffffu, run_start = lo;
+    G1Affine pt;
+    if (lo < hi) { en = sorted[lo]; pt = load_affine(point_of(en)); }
+    if (!own) { b = en & (FINE - 1); bend = start[b + 1]; }
     XyzzW acc = xyzzw_identity();
-    for (uint32_t i = lo; i < hi; i++) {
+    for (uint32_t i = lo; i < hi; i += step) {
         const uint32_t e_cur = en;
         AffW cur; cur.x = unpack<FqW>(pt.x); cur.y = unpack<FqW>(pt.y);
-        if (i + 1 < hi) { en = sorted[i + 1]; pt = load_affine(point_of(en)); }   // prefetch the next gather
+        if (i + step < hi) { en = sorted[i + step]; pt = load_affine(point_of(en)); }   // prefetch the next gather
         if (i == bend) {                                      // the previous bucket ended inside this piece
             const bool from_prev = (run_start == lo) && (start[b] < lo);
             store_xyzzw(out + (from_prev ? SLOT_HEAD + tid : SLOT_PRIMARY + b), acc);
@@ -138,6 +165,14 @@ __global__ void __launch_bounds__(MSM_THREADS, MINW) msm_accumulate(const G1Affi
             run_start = i; b = e_cur & (FINE - 1); bend = start[b + 1];
         }
         if (p.debug != 1) xyzzw_add_mixed(acc, cur, (e_cur & 0x80u) != 0);
+    }
+    if (OWNED && own) {                                       // the quad's four sums -> one PRIMARY sum per bucket
+        const uint32_t role = tid & 3u;                       // (distributed form, ec29_quad_dev.h: lane r of the quad holds coordinate r)
+        const FqW9 c1 = quad_distribute<1>(acc, role), c2 = quad_distribute<2>(acc, role), c3 = quad_distribute<3>(acc, role);
+        FqW9 X = quad_distribute<0>(acc, role);
+        for (int k = 1; k < 4; k++) X = xyzzw_add_dist(X, wsel(k == 1, c1, wsel(k == 2, c2, c3)), role);     // (one addition site)
+        if (start[b + 1] > start[b]) store_coord(out + SLOT_PRIMARY + b, role, X);
+        return;
     }
     const bool from_prev = (run_start == lo) && (start[b] < lo), into_next = bend > hi;
     store_xyzzw(out + (from_prev ? SLOT_HEAD + tid : (into_next ? SLOT_TAIL + tid : SLOT_PRIMARY + b)), acc);
@@ -150,14 +185,17 @@ int32_t msm_accumulate_prepare() {
     PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<6>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
     PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<7>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
     PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<6, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
+    PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_accumulate<6, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * sizeof(uint32_t)));
     attr_set = true;
     return PLK_OK;
 }
 
-void msm_accumulate_launch(uint32_t fine_bits, bool one_wave, uint32_t max_tasks, hipStream_t stream, const G1Affine *bases, const uint32_t *entries,
+void msm_accumulate_launch(uint32_t fine_bits, int variant, uint32_t max_tasks, hipStream_t stream, const G1Affine *bases, const uint32_t *entries,
                            const uint32_t *bin_start, const uint32_t *task_start, XyzzW *partials, uint32_t *task_meta, const MsmParams &p) {
     const size_t lds = CHUNK * sizeof(uint32_t);
-    if (fine_bits == 6 && one_wave)
+    if (fine_bits == 6 && variant == 2)
+        hipLaunchKernelGGL((msm_accumulate<6, 2, true>), dim3(max_tasks), dim3(MSM_THREADS), lds, stream, bases, entries, bin_start, task_start, partials, task_meta, p);
+    else if (fine_bits == 6 && variant == 1)
         hipLaunchKernelGGL((msm_accumulate<6, 1>), dim3(max_tasks), dim3(MSM_THREADS), lds, stream, bases, entries, bin_start, task_start, partials, task_meta, p);
     else if (fine_bits == 6)
         hipLaunchKernelGGL((msm_accumulate<6>), dim3(max_tasks), dim3(MSM_THREADS), lds, stream, bases, entries, bin_start, task_start, partials, task_meta, p);

@@ -71,10 +71,15 @@ template <uint32_t FB> struct Shape {
     static constexpr uint32_t META_PER_TASK = FINE + 2;   // start[0..FINE] and the entry count
 };
 
-// kernel A (msm_accumulate.hip): one workgroup per task; fine_bits 6 or 7; one_wave = the 512-register / one-wave-per-SIMD build
-// of the fine_bits-6 shape (measurement knob PLK_MSM_ONE_WAVE)
+// bit 31 of a task's entry count in its meta block: the task's buckets were accumulated by the lanes that own them (msm_accumulate<.., OWNED>): one PRIMARY
+// sum per bucket, no HEAD / TAIL pieces
+constexpr uint32_t TASK_OWNED_BIT = 0x80000000u;
+
+// kernel A (msm_accumulate.hip): one workgroup per task; fine_bits 6 or 7; variant 1 = the 512-register / one-wave-per-SIMD build
+// of the fine_bits-6 shape (measurement knob PLK_MSM_ONE_WAVE), variant 2 = the build that lets a task's lanes own its buckets when they are
+// evenly filled (commitments of <= 2^16 terms), 0 = the plain kernel
 int32_t msm_accumulate_prepare();                                   // dynamic-LDS attributes, once per process
-void msm_accumulate_launch(uint32_t fine_bits, bool one_wave, uint32_t max_tasks, hipStream_t stream, const G1Affine *bases, const uint32_t *entries,
+void msm_accumulate_launch(uint32_t fine_bits, int variant, uint32_t max_tasks, hipStream_t stream, const G1Affine *bases, const uint32_t *entries,
                            const uint32_t *bin_start, const uint32_t *task_start, XyzzW *partials, uint32_t *task_meta, const MsmParams &p);
 
 }  // namespace plk

@@ -50,6 +50,9 @@ __device__ __forceinline__ XyzzW sm_shfl_xor(const XyzzW &v, int mask) {
 
 // grid (8 G, batch): workgroup 8 g + s takes terms [g ch, (g + 1) ch) and an EIGHTH of the bucket space — s & 1: lo / hi values, s >> 1: which 64 of the 256 values.
 // bases = copy 0 of the fixed-base table at the commitment's first point; copy w lies w * copy_stride points on.
+// QUADSUM (the default; PLK_MSM_SMALL_QUADSUM=0 is the A/B knob): the four lanes of a bucket add their sums up before they store (three four-lane additions
+// on the end of the kernel): a quarter of the partial sums for msm_small_fold, whose quads walk G2 / Q of them one after the other.
+template <bool QUADSUM>
 __global__ void __launch_bounds__(SM_THREADS, 2) msm_small_accumulate(const G1Affine *bases, ScalarSet set, uint32_t n, uint32_t ch, uint32_t copy_stride,
                                                                      XyzzW *partials, uint32_t *flag) {
     extern __shared__ uint32_t sm_lds_mem[];
@@ -90,72 +93,91 @@ __global__ void __launch_bounds__(SM_THREADS, 2) msm_small_accumulate(const G1Af
         AffW q; q.x = unpack<FqW>(cur.x); q.y = unpack<FqW>(cur.y);
         xyzzw_add_mixed(acc, q, neg);
     }
-    // partial sums: [m][4 g + sub][512 buckets] — msm_small_fold sees 4 G "workgroups"
-    store_xyzzw(partials + ((size_t)m * (gridDim.x >> 3) * 4 + 4 * g + sub) * SM_BUCKETS + hi_set * 256 + eighth * 64 + bucket, acc);
+    if (QUADSUM) {
+        // partial sums: [m][g][512 buckets]; the four sums of the quad in distributed form (ec29_quad_dev.h), three additions, each lane stores its coordinate
+        const FqW9 c1 = quad_distribute<1>(acc, sub), c2 = quad_distribute<2>(acc, sub), c3 = quad_distribute<3>(acc, sub);
+        FqW9 X = quad_distribute<0>(acc, sub);
+        for (int k = 1; k < 4; k++) X = xyzzw_add_dist(X, wsel(k == 1, c1, wsel(k == 2, c2, c3)), sub);     // (one addition site)
+        store_coord(partials + ((size_t)m * (gridDim.x >> 3) + g) * SM_BUCKETS + hi_set * 256 + eighth * 64 + bucket, sub, X);
+    } else {
+        // partial sums: [m][4 g + sub][512 buckets] — msm_small_fold sees 4 G "workgroups"
+        store_xyzzw(partials + ((size_t)m * (gridDim.x >> 3) * 4 + 4 * g + sub) * SM_BUCKETS + hi_set * 256 + eighth * 64 + bucket, acc);
+    }
 }
 
 // The two tree kernels run their full additions four lanes at a time (ec29_quad_dev.h: a quad of lanes shares one addition, four products
-// deep instead of fourteen): ~2.6 us per tree level instead of ~7.3.  One addition site per kernel (the operand is chosen beforehand).
+// deep instead of fourteen), since late round 6 in the DISTRIBUTED form: lane r of a quad holds only coordinate r of the running sum.
+// One addition site per kernel (the operand is chosen beforehand).  Both are sized for ONE wave per SIMD (<= 1024 waves on the chip): a lone wave
+// already issues at its SIMD's rate (tools/ubench_lanes), a second wave on the SIMD doubles the time of every tree level — measured 4.5 us per level
+// with two waves per SIMD (planes of 512 threads, folds of 2048 waves) against 2.3 us alone.
 //
-// buckets[m][b] = sum of the G2 partial sums of bucket b (four per accumulate chunk: the bucket's four lanes).  Two shapes of one kernel:
-//   WIDE  (grid (512, batch), 256 threads = 64 quads per bucket): quad q takes partial sums q, q + 64, .. one after the other, then a tree over the 16 quads of a
-//         wave (shuffles) and over the four waves (LDS) — the shortest chain, for ONE commitment, where the chip is empty anyway;
-//   !WIDE (grid (128, batch), one wave = 16 quads per bucket, four buckets per workgroup): one step more (64 partial sums: 4 + 4 against 1 + 6) for a quarter of the
-//         waves — a batch of four commitments in the wide shape puts eight waves of these chains on every SIMD and ran 3x longer (172 against 49 us, round 6).
-template <bool WIDE>
-__global__ void __launch_bounds__(256) msm_small_fold(const XyzzW *partials, uint32_t G2, XyzzW *buckets) {
-    __shared__ __attribute__((aligned(16))) XyzzW sh[4];
+// buckets[m][b] = sum of the G2 partial sums of bucket b.  Q = 2^QL quads per bucket, chosen by the launch so that batch * 512 * Q quads are about 1024
+// waves: 32 quads for one commitment (two waves per bucket, the last level through LDS), 16 / 8 / 4 for batches of 2 / 3-4 / 5-8.  Quad q of a bucket takes
+// partial sums q, q + Q, .. one after the other, then a tree over the bucket's quads.  Workgroup = 128 threads = 32 quads = 32 / Q buckets.
+template <uint32_t QL>
+__global__ void __launch_bounds__(128) msm_small_fold(const XyzzW *partials, uint32_t G2, XyzzW *buckets) {
+    constexpr uint32_t Q = 1u << QL, BPB = 32u >> QL;
+    __shared__ __attribute__((aligned(16))) uint32_t sh[4][9];
     small_chain_priority();
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, role = tid & 3, m = blockIdx.y;
-    const uint32_t b = WIDE ? blockIdx.x : blockIdx.x * 4 + wave, quad = WIDE ? tid >> 2 : lane >> 2, quads = WIDE ? 64 : 16;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, role = tid & 3, m = blockIdx.y, quad = (tid >> 2) & (Q - 1);
+    const uint32_t b = blockIdx.x * BPB + (tid >> (2 + QL));
     const XyzzW *P = partials + (size_t)m * G2 * SM_BUCKETS + b;
-    const uint32_t nseq = (G2 + quads - 1) / quads, total = nseq + 4 + (WIDE ? 2 : 0);
-    XyzzW X = xyzzw_identity();
+    const uint32_t nseq = (G2 + Q - 1) / Q, total = nseq + QL;
+    FqW9 X = w_zero<FqW>();                                    // (distributed form: lane `role` of the quad holds coordinate `role`; all zero = the identity)
     for (uint32_t step = 0; step < total; step++) {
-        XyzzW O = xyzzw_identity();
+        FqW9 O = w_zero<FqW>();
         if (step < nseq) {
-            const uint32_t g = quad + quads * step;
-            if (g < G2) O = load_xyzzw(P + (size_t)g * SM_BUCKETS);
+            const uint32_t g = quad + Q * step;
+            if (g < G2) O = load_coord(P + (size_t)g * SM_BUCKETS, role);
         } else {
             const uint32_t k = step - nseq;
-            if (WIDE && k == 4) {                             // the four waves' sums change hands through LDS; every wave then folds all four (same result)
-                if (lane == 0) sh[wave] = X;
+            if (QL == 5 && k == 4) {                          // the two waves' sums change hands through LDS
+                if (tid >= 64 && lane < 4) for (int i = 0; i < 9; i++) sh[role][i] = X.l[i];
                 __syncthreads();
-                X = (lane >> 2) < 4 ? sh[lane >> 2] : xyzzw_identity();
-            }
-            O = sm_shfl_xor(X, k < 4 ? 4 << k : 4 << (k - 4));
+                if (tid < 4) for (int i = 0; i < 9; i++) O.l[i] = sh[role][i];
+            } else O = coord_shfl_xor(X, 4 << k);
         }
-        X = xyzzw_add_quad(X, O, role);
+        X = xyzzw_add_dist(X, O, role);                       // the one addition site of the kernel
     }
-    if (WIDE ? tid == 0 : lane == 0) store_xyzzw(buckets + (size_t)m * SM_BUCKETS + b, X);
+    if (quad == 0) store_coord(buckets + (size_t)m * SM_BUCKETS + b, role, X);
 }
 
-// grid (17, batch), 512 threads = 128 quads.  Plane p < 8: bit p of the lo value; plane 8 + b: bit b of the hi value (b = 8: the one bucket hi = 256).
-// Quad q holds the q-th bucket of the plane; tree over the 16 quads of a wave, then over the eight waves.
+// grid (17, batch), 256 threads = 64 quads: one wave per SIMD of its CU.  Plane p < 8: bit p of the lo value; plane 8 + b: bit b of the hi value (b = 8: the
+// one bucket hi = 256).  Quad q takes the q-th and the (q + 64)-th bucket of the plane; tree over the 16 quads of a wave, then over the four waves.
 constexpr uint32_t SM_PLANES = 17;
-__global__ void __launch_bounds__(512) msm_small_planes(const XyzzW *buckets, G1Xyzz *planes, const uint32_t *flag, uint32_t *flag_out, uint32_t extra) {
-    __shared__ __attribute__((aligned(16))) XyzzW sh[8];
+__global__ void __launch_bounds__(256) msm_small_planes(const XyzzW *buckets, G1Xyzz *planes, const uint32_t *flag, uint32_t *flag_out, uint32_t extra) {
+    __shared__ __attribute__((aligned(16))) uint32_t sh[4][4][9];
     small_chain_priority();
     const uint32_t p = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, role = tid & 3, quad = tid >> 2;
     const bool hi = p >= 8;
     const uint32_t bit = hi ? p - 8 : p;
     const XyzzW *B = buckets + (size_t)m * SM_BUCKETS;
-    XyzzW X = xyzzw_identity();
-    if (bit < 8) {
-        const uint32_t v = ((quad >> bit) << (bit + 1)) | (1u << bit) | (quad & ((1u << bit) - 1));   // the 128 values of [1, 255] with `bit` set
-        X = load_xyzzw(B + (hi ? 255 + v : v));
-    } else if (quad == 0) X = load_xyzzw(B + 511);
+    auto bucket_of = [&](uint32_t j) {                        // the j-th of the 128 values of [1, 255] with `bit` set
+        const uint32_t v = ((j >> bit) << (bit + 1)) | (1u << bit) | (j & ((1u << bit) - 1));
+        return B + (hi ? 255 + v : v);
+    };
+    FqW9 X = w_zero<FqW>();
+    if (bit < 8) X = load_coord(bucket_of(quad), role);
+    else if (quad == 0) X = load_coord(B + 511, role);
     for (uint32_t k = 0; k < 7 + extra; k++) {                 // (extra: measurement knob PLK_MSM_SMALL_EXTRA — more levels that add the identity)
-        if (k == 4) {
-            if (lane == 0) sh[wave] = X;
-            __syncthreads();
-            X = (lane >> 2) < 8 ? sh[lane >> 2] : xyzzw_identity();
+        FqW9 O = w_zero<FqW>();
+        if (k == 0) { if (bit < 8) O = load_coord(bucket_of(quad + 64), role); }
+        else if (k < 5) O = coord_shfl_xor(X, 4 << (k - 1));
+        else if (k < 7) {
+            if (k == 5) {
+                if (lane < 4) for (int i = 0; i < 9; i++) sh[wave][role][i] = X.l[i];
+                __syncthreads();
+                if ((lane >> 2) < 4) { for (int i = 0; i < 9; i++) X.l[i] = sh[lane >> 2][role][i]; } else X = w_zero<FqW>();
+            }
+            O = coord_shfl_xor(X, 4 << (k - 5));
         }
-        XyzzW O = sm_shfl_xor(X, k < 4 ? 4 << k : 4 << ((k - 4) & 3));
-        if (k >= 7) O = xyzzw_identity();
-        X = xyzzw_add_quad(X, O, role);                       // the one addition site of the kernel
+        X = xyzzw_add_dist(X, O, role);                       // the one addition site of the kernel
     }
-    if (tid == 0) store_xyzz(planes + (size_t)m * SM_PLANES + p, xyzzw_export(X));
+    if (tid < 4) {                                            // each lane of the first quad exports its coordinate (external form: canonical, R = 2^256; the identity is all zero)
+        const bool inf = quad_flag<2>(w_all_zero(X));
+        Fq *out = &planes[(size_t)m * SM_PLANES + p].x + role;
+        store_fp(out, inf ? Fq::zero() : pack<FqParams>(s_from_w(X)));
+    }
     if (tid == 0 && p == 0 && m == 0) *flag_out = *flag;
 }
 
@@ -165,7 +187,8 @@ int32_t msm_small_launch(plk_ctx::MsmSlot &S, hipStream_t stream, const G1Affine
                          uint32_t batch, uint32_t n, bool ev_on, void *host_out) {
     static std::atomic<bool> attr_set{false};
     if (!attr_set) {
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_small_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_lds(SM_CH_MAX)));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_small_accumulate<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_lds(SM_CH_MAX)));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_small_accumulate<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_lds(SM_CH_MAX)));
         attr_set = true;
     }
     static const uint32_t probe_ch = [] { const char *e = getenv("PLK_MSM_SMALL_CH"); return e ? (uint32_t)atoi(e) : 0u; }();   // A/B knob: 64, 128 or 256
@@ -175,6 +198,9 @@ int32_t msm_small_launch(plk_ctx::MsmSlot &S, hipStream_t stream, const G1Affine
     while (ch < SM_CH_MAX && (uint64_t)batch * 8 * ((n + ch - 1) / ch) > want_wgs) ch <<= 1;
     if (probe_ch == 64 || probe_ch == 128 || probe_ch == 256) ch = probe_ch;
     const uint32_t G = (n + ch - 1) / ch;
+    static const int probe_quadsum = [] { const char *e = getenv("PLK_MSM_SMALL_QUADSUM"); return e ? atoi(e) : -1; }();      // A/B knob: 0 never, 1 always
+    const bool quadsum = probe_quadsum != 0;
+    const uint32_t G2 = quadsum ? G : 4 * G;
     PLK_TRY(S.e.reserve((size_t)batch * 4 * G * SM_BUCKETS * sizeof(XyzzW)));
     PLK_TRY(S.c.reserve((size_t)batch * SM_BUCKETS * sizeof(XyzzW) + 16));
     XyzzW *partials = S.e.as<XyzzW>(), *buckets = S.c.as<XyzzW>();
@@ -182,12 +208,18 @@ int32_t msm_small_launch(plk_ctx::MsmSlot &S, hipStream_t stream, const G1Affine
     G1Xyzz *planes = static_cast<G1Xyzz *>(host_out);
     PLK_HIP(hipMemsetAsync(flag, 0, 16, stream));
     if (ev_on) PLK_HIP(hipEventRecord(S.ev[0], stream));
-    hipLaunchKernelGGL(msm_small_accumulate, dim3(8 * G, batch), dim3(SM_THREADS), sm_lds(ch), stream, bases, set, n, ch, copy_stride, partials, flag);
+    if (quadsum) hipLaunchKernelGGL(msm_small_accumulate<true>, dim3(8 * G, batch), dim3(SM_THREADS), sm_lds(ch), stream, bases, set, n, ch, copy_stride, partials, flag);
+    else hipLaunchKernelGGL(msm_small_accumulate<false>, dim3(8 * G, batch), dim3(SM_THREADS), sm_lds(ch), stream, bases, set, n, ch, copy_stride, partials, flag);
     if (ev_on) (void)hipEventRecord(S.ev[1], stream);
     (void)hipEventRecord(S.acc_done, stream);
-    if (batch == 1) hipLaunchKernelGGL(msm_small_fold<true>, dim3(SM_BUCKETS, batch), dim3(256), 0, stream, (const XyzzW *)partials, 4 * G, buckets);
-    else hipLaunchKernelGGL(msm_small_fold<false>, dim3(SM_BUCKETS / 4, batch), dim3(256), 0, stream, (const XyzzW *)partials, 4 * G, buckets);
-    hipLaunchKernelGGL(msm_small_planes, dim3(SM_PLANES, batch), dim3(512), 0, stream, (const XyzzW *)buckets, planes, (const uint32_t *)flag,
+    static const int probe_ql = [] { const char *e = getenv("PLK_MSM_SMALL_FOLD_QL"); return e ? atoi(e) : 0; }();               // A/B knob: 2 .. 5
+    const uint32_t ql = (probe_ql >= 2 && probe_ql <= 5) ? (uint32_t)probe_ql : (batch == 1 ? 5u : batch == 2 ? 4u : batch <= 4 ? 3u : 2u);
+    const dim3 fgrid(SM_BUCKETS / (32u >> ql), batch);
+    if (ql == 5) hipLaunchKernelGGL(msm_small_fold<5>, fgrid, dim3(128), 0, stream, (const XyzzW *)partials, G2, buckets);
+    else if (ql == 4) hipLaunchKernelGGL(msm_small_fold<4>, fgrid, dim3(128), 0, stream, (const XyzzW *)partials, G2, buckets);
+    else if (ql == 3) hipLaunchKernelGGL(msm_small_fold<3>, fgrid, dim3(128), 0, stream, (const XyzzW *)partials, G2, buckets);
+    else hipLaunchKernelGGL(msm_small_fold<2>, fgrid, dim3(128), 0, stream, (const XyzzW *)partials, G2, buckets);
+    hipLaunchKernelGGL(msm_small_planes, dim3(SM_PLANES, batch), dim3(256), 0, stream, (const XyzzW *)buckets, planes, (const uint32_t *)flag,
                        reinterpret_cast<uint32_t *>(planes + (size_t)batch * SM_PLANES), probe_extra);
     PLK_HIP(hipGetLastError());
     return PLK_OK;

@@ -191,9 +191,10 @@ def test_msm_base_offset(ctx, srs16):
 
 
 @pytest.mark.parametrize("kind", ["zeros", "ones", "minus_one", "witness_like", "small", "one_hot"])
-@pytest.mark.parametrize("n", [300, 1 << 14])
+@pytest.mark.parametrize("n", [300, 1 << 14, 50000])
 def test_msm_scalar_distributions(ctx, srs16, kind, n):
-    """the four distributions of SURVEY.md §8(d) + degenerate ones; hot buckets and all-zero output"""
+    """the four distributions of SURVEY.md §8(d) + degenerate ones; hot buckets and all-zero output (300 / 2^14 terms: the short path of msm_small.hip;
+    50000: the 2^20-shaped pipeline with bucket-owning lanes for evenly filled tasks, equal pieces for the hot ones, and the quad reductions)"""
     ctx.srs_upload(srs16)
     rng = random.Random(11)
     if kind == "zeros":
@@ -246,7 +247,7 @@ def test_msm_duplicate_and_opposite_bases(ctx, srs16):
     assert np.array_equal(ctx.msm(ol.fr_vec([7] * 300)), ol.g1_mul(p, 7 * 300))
 
 
-@pytest.mark.parametrize("n,count", [(100, 3), (5000, 4), (1 << 15, 11)])
+@pytest.mark.parametrize("n,count", [(100, 3), (5000, 4), (1 << 15, 11), (50000, 2), (1 << 16, 4)])
 def test_msm_batch_matches_single(ctx, srs16, n, count):
     """batched commitments (one pass of the kernels) == the same commitments one by one == trapdoor"""
     import torch
