@@ -595,9 +595,8 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_task_reduce(const XyzzW *p
 }
 
 // The same reduction by quads of lanes (late round 6; ec29_quad_dev.h, distributed form): RL = 16 QUADS per task (one wave), RB = FINE / 16 buckets per quad,
-// every step one four-lane addition (2.6 us for a wave alone on its SIMD against 7.3 for the lane-wise addition).  Launched for one or two commitments
-// (1024 / 2048 waves: one / two per SIMD); a batch of three or more keeps the lane-wise kernel, whose 16 lanes per task do the same work in a quarter
-// of the lanes.  The RB_LOG doublings (X + X) leave through the addition's rare branch.
+// every step one four-lane addition (2.6 us for a wave alone on its SIMD against 7.3 for the lane-wise addition).  Launched for ONE commitment (1024 waves:
+// one per SIMD; 191 -> 142 us at 2^20 terms); batches keep the lane-wise kernel, whose lanes do the same work in a quarter of the lane-instructions.  The RB_LOG doublings (X + X) leave through the addition's rare branch.
 template <uint32_t FB>
 __global__ void __launch_bounds__(MSM_THREADS) msm_task_reduce_quad(const XyzzW *partials, const uint32_t *task_meta, const uint32_t *task_start, XyzzW *task_out, uint32_t total_bins) {
     constexpr uint32_t FINE = Shape<FB>::FINE, SLOT_PRIMARY = Shape<FB>::SLOT_PRIMARY, SLOT_HEAD = Shape<FB>::SLOT_HEAD, SLOT_TAIL = Shape<FB>::SLOT_TAIL,
@@ -937,11 +936,12 @@ static int32_t msm_big_launch(plk_ctx *ctx, plk_ctx::MsmSlot &S, hipStream_t str
         msm_accumulate_launch(FB, variant, max_tasks, stream, bases, (const uint32_t *)entries, (const uint32_t *)bin_start, (const uint32_t *)task_start, partials, task_meta, p);
         if (ctx->ev_on) (void)hipEventRecord(S.ev[1], stream);
         (void)hipEventRecord(S.acc_done, stream);
-        // one or two commitments: the bucket reduction by quads of lanes (PLK_MSM_TR_QUAD=0: the lane-wise kernel for every batch size, A/B knob)
+        // ONE commitment: the bucket reduction by quads of lanes (PLK_MSM_TR_QUAD=0: the lane-wise kernel for every batch size, A/B knob).  A batch of two is
+        // 2048 waves of it — two per SIMD, every step twice as long: 269 us inside a proof against ~230 lane-wise —
         static const bool tr_quad = [] { const char *e = getenv("PLK_MSM_TR_QUAD"); return !(e && e[0] == '0'); }();
         // (only when no other commitment is in flight on this context: the quads do the same additions in 1.5x the lane-instructions, which a stream of
         //  commitments — whose reductions share the GPU with the next accumulation — pays for: three in flight at 2^16 terms 0.243 -> 0.255 ms, measured)
-        if (tr_quad && probe_rl == 0 && batch <= 2 && ctx->msm_enq == ctx->msm_fin) {
+        if (tr_quad && probe_rl == 0 && batch == 1 && ctx->msm_enq == ctx->msm_fin) {
             hipLaunchKernelGGL((msm_fold_hot<FB, 5>), dim3(rblocks), dim3(MSM_THREADS), 0, stream, partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
             hipLaunchKernelGGL((msm_task_reduce_quad<FB>), dim3((max_tasks + MSM_THREADS / 64 - 1) / (MSM_THREADS / 64)), dim3(MSM_THREADS), 0, stream,
                                (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
