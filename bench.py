@@ -579,11 +579,15 @@ def compact_line(full):
     return L
 
 
+WRITE_FULL_RECORD = [True]           # False in --msm-only runs (profiling / counter children): they must not overwrite the record of the run that started them
+
+
 def emit(line):
     """prints the compact line (<= ~7 KB) and leaves the full record beside bench.py"""
     try:
-        with open(os.path.join(ROOT, "bench_line_full.json"), "w") as fh:
-            json.dump(line, fh, ensure_ascii=False, indent=1)
+        if WRITE_FULL_RECORD[0]:
+            with open(os.path.join(ROOT, "bench_line_full.json"), "w") as fh:
+                json.dump(line, fh, ensure_ascii=False, indent=1)
     except OSError:
         pass
     out = json.dumps(compact_line(line), ensure_ascii=False)
@@ -897,6 +901,7 @@ def main():
     ap.add_argument("--msm-only", action="store_true", help="only the timed commitments (no cpu_baseline / prove / kernels legs): "
                                                             "the command the rocprofv3 summary under profiles/ is taken from")
     args = ap.parse_args()
+    WRITE_FULL_RECORD[0] = not args.msm_only
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: spawn the N ranks ourselves, exactly as the driver's documented command does
