@@ -90,6 +90,92 @@ __device__ __forceinline__ XyzzW g1_mul_scalar(const XyzzW &b, const Fr &k, uint
     return acc;
 }
 
+// ---- the same multiplication with an EFFECTIVELY AFFINE window table (late round 6).  The four table points b, 2b, 3b, 4b are brought to ONE
+// denominator pair (D_zz = prod ZZ_i, D_zzz = prod ZZZ_i: x_i = X_i' / D_zz, y_i = Y_i' / D_zzz with X_i' = X_i prod_{j != i} ZZ_j, 22 products), and the whole
+// double-and-add runs on the isomorphic curve (x, y) -> (x D_zz, y D_zzz) — for a = 0 neither the addition nor the doubling formulas contain a curve constant —
+// where the table points are AFFINE: 86 MIXED additions of 10 products instead of 86 full additions of 14, table entries of 18 words instead of 36 in LDS,
+// and two products at the end take the accumulator back (ZZ D_zz, ZZZ D_zzz).  129 doublings + 86 mixed additions + 43 products by beta + 56 for the table
+// = ~2100 field products instead of ~2400.  The mixed addition is ec29_dev.h's in the operand-scanning forms (a lone wave per SIMD: field29_dev.h).
+__device__ __forceinline__ void xyzzw_add_mixed_os(XyzzW &acc, const AffW &q, bool neg_q) {
+    if (is_inf(acc)) { acc.x = q.x; acc.y = neg_q ? neg2(q.y) : q.y; acc.zz = w_one<FqW>(); acc.zzz = w_one<FqW>(); return; }
+    const FqW9 u2 = LM(q.x, acc.zz), s2 = LM(q.y, acc.zzz);
+    const FqW9 p = sub6(u2, acc.x);
+    FqW9 r;
+    {
+        const uint32_t m = neg_q ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = FqW::PAD8[i] - acc.y.l[i] + ((s2.l[i] ^ m) - m);
+        r = normw(r);
+    }
+    if (maybe_zero_mod_p(p)) { xyzzw_add_mixed_special(acc, q, neg_q, p, r); return; }       // P == +-Q: rare
+    const FqW9 pp = LS(p), rr = LS(r), ppp = LM(p, pp), qq = LM(acc.x, pp);
+    FqW9 x3;
+#pragma unroll
+    for (int i = 0; i < 9; i++) x3.l[i] = rr.l[i] + FqW::PAD4[i] - ppp.l[i] - 2 * qq.l[i];
+    x3 = normw(x3);
+    const FqW9 zz3 = LM(acc.zz, pp), zzz3 = LM(acc.zzz, ppp);
+    acc.y = LMA(r, sub6(qq, x3), acc.y, neg2(ppp));           // R*(Q - X3) - Y*PPP, one reduction
+    acc.x = x3; acc.zz = zz3; acc.zzz = zzz3;
+}
+constexpr size_t G1NTT_LDS_ISO = (size_t)G1NTT_TABLE * 18 * G1NTT_THREADS * sizeof(uint32_t);   // 73728 B
+__device__ __forceinline__ void lds_put_aff(uint32_t *tab, int e, const FqW9 &x, const FqW9 &y) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) { tab[(e * 18 + k) * G1NTT_THREADS + threadIdx.x] = x.l[k]; tab[(e * 18 + 9 + k) * G1NTT_THREADS + threadIdx.x] = y.l[k]; }
+}
+__device__ __forceinline__ AffW lds_get_aff(const uint32_t *tab, int e) {
+    AffW q;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { q.x.l[k] = tab[(e * 18 + k) * G1NTT_THREADS + threadIdx.x]; q.y.l[k] = tab[(e * 18 + 9 + k) * G1NTT_THREADS + threadIdx.x]; }
+    return q;
+}
+__device__ __forceinline__ XyzzW g1_mul_scalar_iso(const XyzzW &b, const Fr &k, uint32_t *tab) {
+    if (is_inf(b)) return xyzzw_identity();
+    FqW9 dzz, dzzz;
+    {   // table: b, 2b, 3b, 4b over one denominator pair
+        XyzzW t1 = b, t2 = b;
+        g1_double_call(&t2);
+        XyzzW t3 = t2; g1_add_call(&t3, &b);
+        XyzzW t4 = t2; g1_double_call(&t4);
+        {
+            const FqW9 p12 = LM(t1.zz, t2.zz), p34 = LM(t3.zz, t4.zz);
+            t1.x = LM(t1.x, LM(t2.zz, p34)); t2.x = LM(t2.x, LM(t1.zz, p34)); t3.x = LM(t3.x, LM(p12, t4.zz)); t4.x = LM(t4.x, LM(p12, t3.zz));
+            dzz = LM(p12, p34);
+        }
+        {
+            const FqW9 p12 = LM(t1.zzz, t2.zzz), p34 = LM(t3.zzz, t4.zzz);
+            t1.y = LM(t1.y, LM(t2.zzz, p34)); t2.y = LM(t2.y, LM(t1.zzz, p34)); t3.y = LM(t3.y, LM(p12, t4.zzz)); t4.y = LM(t4.y, LM(p12, t3.zzz));
+            dzzz = LM(p12, p34);
+        }
+        lds_put_aff(tab, 0, t1.x, t1.y); lds_put_aff(tab, 1, t2.x, t2.y); lds_put_aff(tab, 2, t3.x, t3.y); lds_put_aff(tab, 3, t4.x, t4.y);
+    }
+    uint32_t dig[2][6];
+    uint32_t flip[2];
+    {
+        const GlvSplit sp = glv_split(k.l);
+        glv_digits(sp.k1, dig[0]);
+        glv_digits(sp.k2, dig[1]);
+        flip[0] = sp.neg1 ? 8u : 0u; flip[1] = sp.neg2 ? 8u : 0u;
+    }
+    FqW9 beta;
+#pragma unroll
+    for (int i = 0; i < 9; i++) beta.l[i] = glv::BETA_W[i];
+    XyzzW acc = xyzzw_identity();
+    for (int w = 42; w >= 0; w--) {
+        for (int r = 0; r < 3; r++) acc = xyzzw_double(acc);      // one inlined doubling site (identity passes through)
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            const uint32_t code = ((dig[h][w >> 3] >> (4 * (w & 7))) & 15u), mag = code & 7u;
+            if (mag) {
+                AffW q = lds_get_aff(tab, (int)mag - 1);
+                if (h) q.x = LM(q.x, beta);                        // phi: x -> beta x (the scaling commutes with it)
+                xyzzw_add_mixed_os(acc, q, ((code ^ flip[h]) & 8u) != 0);     // the one inlined mixed-addition site
+            }
+        }
+    }
+    acc.zz = LM(acc.zz, dzz); acc.zzz = LM(acc.zzz, dzzz);       // back from the isomorphic curve (the identity stays the identity)
+    return acc;
+}
+
 // pts[bitrev(i)] = in[i]   (in: affine, external form; pts: XYZZ on the 29-bit layer).  The factor 1/N is applied by the LAST stage
 // (g1ntt_stage, SCALE): there half of the points are multiplied by a twiddle anyway, which takes 1/N along for nothing, so the
 // scaling costs N/2 scalar multiplications instead of the N of a pass of its own (one stage's worth of the transform's 22).
@@ -106,7 +192,7 @@ __global__ void __launch_bounds__(256) g1ntt_load(XyzzW *pts, const G1Affine *in
 }
 
 // one DIT stage with half-size h = 2^s; SCALE (the last stage): both outputs times n_inv (Montgomery form) — (A n_inv) +- (w n_inv) B
-template <bool SCALE>
+template <bool SCALE, bool ISO>
 __global__ void __launch_bounds__(G1NTT_THREADS, 1) g1ntt_stage(XyzzW *pts, uint32_t log_n, uint32_t s, PowTable tw_inv, Fr n_inv) {
     extern __shared__ uint32_t g1tab[];
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,8 +215,8 @@ __global__ void __launch_bounds__(G1NTT_THREADS, 1) g1ntt_stage(XyzzW *pts, uint
             w = mul(load_fp(tw_inv.lo + (e & (POW_TAB - 1))), load_fp(tw_inv.hi + (e >> POW_SPLIT)));
             if (SCALE) w = mul(w, n_inv);
         }
-        b = g1_mul_scalar(b, to_canonical(w), g1tab);
-        if (SCALE) a = g1_mul_scalar(a, to_canonical(n_inv), g1tab);
+        b = ISO ? g1_mul_scalar_iso(b, to_canonical(w), g1tab) : g1_mul_scalar(b, to_canonical(w), g1tab);
+        if (SCALE) a = ISO ? g1_mul_scalar_iso(a, to_canonical(n_inv), g1tab) : g1_mul_scalar(a, to_canonical(n_inv), g1tab);
     }
     XyzzW lo = a, nb = b;
     nb.y = sub6(w_zero<FqW>(), b.y);
@@ -166,15 +252,24 @@ int32_t g1_intt_dev(plk_ctx *ctx, const G1Affine *in, uint32_t log_n, G1Affine *
     const Fr n_inv = ctx->n_inv[log_n];                           // Montgomery form; 1 for log_n = 0 (no stage, nothing to scale)
     static std::atomic<bool> attr_set{false};
     if (!attr_set) {
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS_ISO));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS_ISO));
         attr_set = true;
     }
+    // PLK_G1NTT_ISO=0 (A/B knob): the window table in XYZZ and full additions, as in rounds 4-5
+    static const bool iso = [] { const char *e = getenv("PLK_G1NTT_ISO"); return !(e && e[0] == '0'); }();
     hipLaunchKernelGGL(g1ntt_load, dim3((n + 255) / 256), dim3(256), 0, st, pts, in, log_n);
     const dim3 sgrid((n / 2 + G1NTT_THREADS - 1) / G1NTT_THREADS);
-    for (uint32_t s = 0; s + 1 < log_n; s++)
-        hipLaunchKernelGGL(g1ntt_stage<false>, sgrid, dim3(G1NTT_THREADS), G1NTT_LDS, st, pts, log_n, s, ctx->tw_inv, n_inv);
-    if (log_n) hipLaunchKernelGGL(g1ntt_stage<true>, sgrid, dim3(G1NTT_THREADS), G1NTT_LDS, st, pts, log_n, log_n - 1, ctx->tw_inv, n_inv);
+    for (uint32_t s = 0; s + 1 < log_n; s++) {
+        if (iso) hipLaunchKernelGGL((g1ntt_stage<false, true>), sgrid, dim3(G1NTT_THREADS), G1NTT_LDS_ISO, st, pts, log_n, s, ctx->tw_inv, n_inv);
+        else hipLaunchKernelGGL((g1ntt_stage<false, false>), sgrid, dim3(G1NTT_THREADS), G1NTT_LDS, st, pts, log_n, s, ctx->tw_inv, n_inv);
+    }
+    if (log_n) {
+        if (iso) hipLaunchKernelGGL((g1ntt_stage<true, true>), sgrid, dim3(G1NTT_THREADS), G1NTT_LDS_ISO, st, pts, log_n, log_n - 1, ctx->tw_inv, n_inv);
+        else hipLaunchKernelGGL((g1ntt_stage<true, false>), sgrid, dim3(G1NTT_THREADS), G1NTT_LDS, st, pts, log_n, log_n - 1, ctx->tw_inv, n_inv);
+    }
     hipLaunchKernelGGL(g1ntt_to_affine, dim3((n + 255) / 256), dim3(256), 0, st, out, (const XyzzW *)pts, n);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
