@@ -17,6 +17,7 @@
 #include "ec29_dev.h"
 #include "glv_dev.h"
 #include "ntt.h"
+#include <type_traits>
 
 namespace plk {
 
@@ -176,6 +177,82 @@ __device__ __forceinline__ XyzzW g1_mul_scalar_iso(const XyzzW &b, const Fr &k, 
     return acc;
 }
 
+// ---- and with EIGHT effectively affine table points b .. 8b (the table entries are half as large now: the same 147 KB of LDS hold twice as many) and signed
+// 4-bit windows: 128 doublings + 64 mixed additions + 32 products by beta + ~138 for the table = ~1960 field products (2400 in rounds 4-5, 2120 with four
+// entries).  The eight points' X, Y wait in the LDS slots while the prefix / suffix products of their ZZ and ZZZ are formed in registers.
+constexpr int G1NTT_TABLE8 = 8;
+constexpr size_t G1NTT_LDS_ISO8 = (size_t)G1NTT_TABLE8 * 18 * G1NTT_THREADS * sizeof(uint32_t);   // 147456 B
+__device__ __forceinline__ XyzzW g1_mul_scalar_iso8(const XyzzW &b, const Fr &k, uint32_t *tab) {
+    if (is_inf(b)) return xyzzw_identity();
+    FqW9 dzz, dzzz;
+    {
+        FqW9 zz[8], zzz[8];
+        {   // b, 2b, .. 8b: X, Y to the LDS slots, ZZ / ZZZ stay
+            XyzzW t[8];
+            t[0] = b;
+            t[1] = b; g1_double_call(&t[1]);
+            t[2] = t[1]; g1_add_call(&t[2], &b);
+            t[3] = t[1]; g1_double_call(&t[3]);
+            t[4] = t[3]; g1_add_call(&t[4], &b);
+            t[5] = t[2]; g1_double_call(&t[5]);
+            t[6] = t[5]; g1_add_call(&t[6], &b);
+            t[7] = t[3]; g1_double_call(&t[7]);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { lds_put_aff(tab, i, t[i].x, t[i].y); zz[i] = t[i].zz; zzz[i] = t[i].zzz; }
+        }
+        // cofactor of entry i = product of the other seven: prefix * suffix; the X (Y) of the slot is scaled in place
+        auto scale = [&](FqW9 (&z)[8], int off) __attribute__((always_inline)) -> FqW9 {
+            FqW9 pre[8];                                          // pre[i] = z_0 .. z_{i-1}
+            pre[1] = z[0];
+#pragma unroll
+            for (int i = 2; i < 8; i++) pre[i] = LM(pre[i - 1], z[i - 1]);
+            FqW9 suf = z[7];                                      // z_{i+1} .. z_7 while walking down
+            const FqW9 all = LM(pre[7], z[7]);
+#pragma unroll
+            for (int i = 7; i >= 0; i--) {
+                FqW9 c;
+                if (i == 7) c = pre[7]; else if (i == 0) c = suf; else c = LM(pre[i], suf);
+                FqW9 v;
+#pragma unroll
+                for (int kk = 0; kk < 9; kk++) v.l[kk] = tab[(i * 18 + off + kk) * G1NTT_THREADS + threadIdx.x];
+                v = LM(v, c);
+#pragma unroll
+                for (int kk = 0; kk < 9; kk++) tab[(i * 18 + off + kk) * G1NTT_THREADS + threadIdx.x] = v.l[kk];
+                if (i > 0 && i < 7) suf = LM(suf, z[i]);
+            }
+            return all;
+        };
+        dzz = scale(zz, 0);
+        dzzz = scale(zzz, 9);
+    }
+    uint32_t dig[2][6];
+    uint32_t flip[2];
+    {
+        const GlvSplit sp = glv_split(k.l);
+        glv_digits4(sp.k1, dig[0]);
+        glv_digits4(sp.k2, dig[1]);
+        flip[0] = sp.neg1 ? 16u : 0u; flip[1] = sp.neg2 ? 16u : 0u;
+    }
+    FqW9 beta;
+#pragma unroll
+    for (int i = 0; i < 9; i++) beta.l[i] = glv::BETA_W[i];
+    XyzzW acc = xyzzw_identity();
+    for (int w = 31; w >= 0; w--) {
+        for (int r = 0; r < 4; r++) acc = xyzzw_double(acc);      // one inlined doubling site (identity passes through)
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            const uint32_t code = (dig[h][w / 6] >> (5 * (w % 6))) & 31u, mag = code & 15u;
+            if (mag) {
+                AffW q = lds_get_aff(tab, (int)mag - 1);
+                if (h) q.x = LM(q.x, beta);                        // phi: x -> beta x (the scaling commutes with it)
+                xyzzw_add_mixed_os(acc, q, ((code ^ flip[h]) & 16u) != 0);    // the one inlined mixed-addition site
+            }
+        }
+    }
+    acc.zz = LM(acc.zz, dzz); acc.zzz = LM(acc.zzz, dzzz);       // back from the isomorphic curve (the identity stays the identity)
+    return acc;
+}
+
 // pts[bitrev(i)] = in[i]   (in: affine, external form; pts: XYZZ on the 29-bit layer).  The factor 1/N is applied by the LAST stage
 // (g1ntt_stage, SCALE): there half of the points are multiplied by a twiddle anyway, which takes 1/N along for nothing, so the
 // scaling costs N/2 scalar multiplications instead of the N of a pass of its own (one stage's worth of the transform's 22).
@@ -192,7 +269,7 @@ __global__ void __launch_bounds__(256) g1ntt_load(XyzzW *pts, const G1Affine *in
 }
 
 // one DIT stage with half-size h = 2^s; SCALE (the last stage): both outputs times n_inv (Montgomery form) — (A n_inv) +- (w n_inv) B
-template <bool SCALE, bool ISO>
+template <bool SCALE, int ISO>
 __global__ void __launch_bounds__(G1NTT_THREADS, 1) g1ntt_stage(XyzzW *pts, uint32_t log_n, uint32_t s, PowTable tw_inv, Fr n_inv) {
     extern __shared__ uint32_t g1tab[];
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -215,8 +292,13 @@ __global__ void __launch_bounds__(G1NTT_THREADS, 1) g1ntt_stage(XyzzW *pts, uint
             w = mul(load_fp(tw_inv.lo + (e & (POW_TAB - 1))), load_fp(tw_inv.hi + (e >> POW_SPLIT)));
             if (SCALE) w = mul(w, n_inv);
         }
-        b = ISO ? g1_mul_scalar_iso(b, to_canonical(w), g1tab) : g1_mul_scalar(b, to_canonical(w), g1tab);
-        if (SCALE) a = ISO ? g1_mul_scalar_iso(a, to_canonical(n_inv), g1tab) : g1_mul_scalar(a, to_canonical(n_inv), g1tab);
+        auto mul = [&](const XyzzW &pt, const Fr &kk) __attribute__((always_inline)) {
+            if constexpr (ISO == 2) return g1_mul_scalar_iso8(pt, kk, g1tab);
+            else if constexpr (ISO == 1) return g1_mul_scalar_iso(pt, kk, g1tab);
+            else return g1_mul_scalar(pt, kk, g1tab);
+        };
+        b = mul(b, to_canonical(w));
+        if (SCALE) a = mul(a, to_canonical(n_inv));
     }
     XyzzW lo = a, nb = b;
     nb.y = sub6(w_zero<FqW>(), b.y);
@@ -252,24 +334,27 @@ int32_t g1_intt_dev(plk_ctx *ctx, const G1Affine *in, uint32_t log_n, G1Affine *
     const Fr n_inv = ctx->n_inv[log_n];                           // Montgomery form; 1 for log_n = 0 (no stage, nothing to scale)
     static std::atomic<bool> attr_set{false};
     if (!attr_set) {
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS_ISO));
-        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS_ISO));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS_ISO));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS_ISO));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS_ISO8));
+        PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g1ntt_stage<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1NTT_LDS_ISO8));
         attr_set = true;
     }
-    // PLK_G1NTT_ISO=0 (A/B knob): the window table in XYZZ and full additions, as in rounds 4-5
-    static const bool iso = [] { const char *e = getenv("PLK_G1NTT_ISO"); return !(e && e[0] == '0'); }();
+    // PLK_G1NTT_ISO (A/B knob): 0 = the window table in XYZZ and full additions, as in rounds 4-5; 1 = four effectively affine entries, 3-bit windows; default 2 = eight, 4-bit windows
+    // (the same chain in Jacobian coordinates — 4S + 3M doublings — was built, verified and measured 3 % SLOWER: profiles/r06b_g1ntt_jacobian.patch)
+    static const int iso = [] { const char *e = getenv("PLK_G1NTT_ISO"); return e ? atoi(e) : 2; }();
     hipLaunchKernelGGL(g1ntt_load, dim3((n + 255) / 256), dim3(256), 0, st, pts, in, log_n);
     const dim3 sgrid((n / 2 + G1NTT_THREADS - 1) / G1NTT_THREADS);
-    for (uint32_t s = 0; s + 1 < log_n; s++) {
-        if (iso) hipLaunchKernelGGL((g1ntt_stage<false, true>), sgrid, dim3(G1NTT_THREADS), G1NTT_LDS_ISO, st, pts, log_n, s, ctx->tw_inv, n_inv);
-        else hipLaunchKernelGGL((g1ntt_stage<false, false>), sgrid, dim3(G1NTT_THREADS), G1NTT_LDS, st, pts, log_n, s, ctx->tw_inv, n_inv);
-    }
-    if (log_n) {
-        if (iso) hipLaunchKernelGGL((g1ntt_stage<true, true>), sgrid, dim3(G1NTT_THREADS), G1NTT_LDS_ISO, st, pts, log_n, log_n - 1, ctx->tw_inv, n_inv);
-        else hipLaunchKernelGGL((g1ntt_stage<true, false>), sgrid, dim3(G1NTT_THREADS), G1NTT_LDS, st, pts, log_n, log_n - 1, ctx->tw_inv, n_inv);
-    }
+    auto stage = [&](auto scale_tag, uint32_t s) {
+        constexpr bool SC = decltype(scale_tag)::value;
+        if (iso == 2) hipLaunchKernelGGL((g1ntt_stage<SC, 2>), sgrid, dim3(G1NTT_THREADS), G1NTT_LDS_ISO8, st, pts, log_n, s, ctx->tw_inv, n_inv);
+        else if (iso == 1) hipLaunchKernelGGL((g1ntt_stage<SC, 1>), sgrid, dim3(G1NTT_THREADS), G1NTT_LDS_ISO, st, pts, log_n, s, ctx->tw_inv, n_inv);
+        else hipLaunchKernelGGL((g1ntt_stage<SC, 0>), sgrid, dim3(G1NTT_THREADS), G1NTT_LDS, st, pts, log_n, s, ctx->tw_inv, n_inv);
+    };
+    for (uint32_t s = 0; s + 1 < log_n; s++) stage(std::false_type{}, s);
+    if (log_n) stage(std::true_type{}, log_n - 1);
     hipLaunchKernelGGL(g1ntt_to_affine, dim3((n + 255) / 256), dim3(256), 0, st, out, (const XyzzW *)pts, n);
     PLK_HIP(hipGetLastError());
     return PLK_OK;

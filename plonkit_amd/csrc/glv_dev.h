@@ -120,4 +120,20 @@ PLK_HD void glv_digits(const uint32_t k[5], uint32_t dig[6]) {
     }
 }
 
+// signed 4-bit windows of a magnitude < 2^127 (both GLV halves are: k1 < A1 + A2, |k2| < max(B1N, B2), all below 2^127), low to high: digits in [-7, 8] as
+// 5-bit codes (bit 4 = negative, bits 0-3 = magnitude), 32 of them packed six to a word.  v = window + carry; v <= 8 -> digit v; v >= 9 -> v - 16, carry 1
+// (the top window holds bits 124..126 <= 7, so no carry leaves it).
+PLK_HD void glv_digits4(const uint32_t k[5], uint32_t dig[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) dig[i] = 0;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < 32; w++) {
+        const uint32_t v = ((k[w >> 3] >> (4 * (w & 7))) & 15u) + carry;
+        uint32_t code;
+        if (v >= 9) { code = 16u | (16u - v); carry = 1; } else { code = v; carry = 0; }
+        dig[w / 6] |= code << (5 * (w % 6));
+    }
+}
+
 }  // namespace plk

@@ -158,7 +158,7 @@ int main() {
         printf("KAT Fq "); hex(cc.l); printf(" "); hex(cc.l); printf(" "); hex(qc.l); printf("\n");
     }
     // GLV split of canonical scalars (glv_dev.h, used by the G1 iNTT): known-answer lines "GLV k |k1| neg1 |k2| neg2"
-    // (Python checks k1 + k2 lambda = k mod r and both halves < 2^128), the signed 3-bit window digits re-summed here, and
+    // (Python checks k1 + k2 lambda = k mod r and both halves < 2^128), the signed 3-bit and 4-bit window digits re-summed here, and
     // phi(P) = (beta x, y) = lambda P on the 29-bit layer by double-and-add with lambda
     int gbad = 0;
     auto hex5 = [](const uint32_t *l) { for (int i = 4; i >= 0; i--) printf("%08x", l[i]); };
@@ -176,6 +176,12 @@ int main() {
             for (int w = 42; w >= 0; w--) { const uint32_t c = (dig[w >> 3] >> (4 * (w & 7))) & 15u; const int d = (c & 8u) ? -(int)(c & 7u) : (int)(c & 7u); if ((c & 7u) > 4 || (c == 12u)) gbad++; acc = acc * 8 + d; }
             for (int i = 3; i >= 0; i--) want = (want << 32) | m[i];
             if (acc < 0 || (unsigned __int128)acc != want) { gbad++; if (gbad < 5) printf("glv digits mismatch at %d half %d\n", it, h); }
+            // the signed 4-bit windows of the eight-entry table (digits in [-7, 8], 32 windows: both halves are below 2^127)
+            if (m[3] >> 31) { gbad++; if (gbad < 5) printf("glv half >= 2^127 at %d\n", it); }
+            uint32_t dig4[6]; glv_digits4(m, dig4);
+            __int128 acc4 = 0;
+            for (int w = 31; w >= 0; w--) { const uint32_t c = (dig4[w / 6] >> (5 * (w % 6))) & 31u; const int d = (c & 16u) ? -(int)(c & 15u) : (int)(c & 15u); if ((c & 15u) > 8 || c == 24u) gbad++; acc4 = acc4 * 16 + d; }
+            if (acc4 < 0 || (unsigned __int128)acc4 != want) { gbad++; if (gbad < 5) printf("glv 4-bit digits mismatch at %d half %d\n", it, h); }
         }
         if (it < 40) { printf("GLV "); hex(k.l); printf(" "); hex5(sp.k1); printf(" %d ", sp.neg1 ? 1 : 0); hex5(sp.k2); printf(" %d\n", sp.neg2 ? 1 : 0); }
     }
