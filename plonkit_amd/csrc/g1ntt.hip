@@ -11,7 +11,8 @@
 // non-zero digit at nearly every bit, so the whole wave pays one addition per bit.  Fixed signed 3-bit windows make
 // all lanes add at the same positions; the window table {1,2,3,4}*B of every lane lives in LDS, limb-major
 // (conflict-free).  Round 1: 255 doublings + 85 additions (~3500 field products).  Round 4: the GLV endomorphism halves
-// the doubling chain — 129 doublings + 86 additions + 43 products by beta (~2400), see g1_mul_scalar / glv_dev.h.
+// the doubling chain — 129 doublings + 86 additions + 43 products by beta (~2400), see g1_mul_scalar / glv_dev.h.  Round 6: the window table made
+// effectively affine on an isomorphic curve (eight points, 4-bit windows, mixed additions): ~1960, see g1_mul_scalar_iso8.
 #include "ctx.h"
 #include "ec_dev.h"
 #include "ec29_dev.h"
