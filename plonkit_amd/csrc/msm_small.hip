@@ -12,7 +12,7 @@
 //     entries j, j + 4, .. of the list (a constant column — ch equal scalars in one bucket — is ch / 4 additions per lane);
 //   * msm_small_fold: the 4 n / ch partial sums of a bucket (one per lane that owned it), a tree of four-lane full additions;
 //   * msm_small_planes: sum_j j * B_j = sum_b 2^b * (sum of the B_j with bit b of j set): seventeen plain tree sums over <= 128
-//     buckets, side by side; the seventeen points go to the host, whose Horner (16 doublings + 16 additions) takes ~15 us.
+//     buckets, side by side; the seventeen points go to the host, whose Horner (16 doublings + 16 additions) takes ~6 us.
 // The longest dependent chain is ~6 mixed + 17 four-lane full additions of 2.6 us (3 in the accumulate kernel, 7 in the fold, 7 in the planes) against ~90 lane-wise
 // ones of 7.3 us + the accumulation before.
 // A list longer than its ch slots (several WINDOWS of one scalar carrying the same digit, in every term of a chunk: not a witness anybody
