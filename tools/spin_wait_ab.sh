@@ -1,3 +1,4 @@
+#!/bin/bash
 cd "$(dirname "$0")/.."
 # usage: tools/spin_wait_ab.sh — proofs at 2^10 / 2^12 / 2^16 / 2^20 with and without ROC_ACTIVE_WAIT_TIMEOUT=2000 (the HIP runtime spinning on completion signals), twice
 for rep in 1 2; do

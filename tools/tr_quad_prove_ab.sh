@@ -1,3 +1,4 @@
+#!/bin/bash
 cd "$(dirname "$0")/.."
 for rep in 1 2 3; do
 for v in 0 1; do
