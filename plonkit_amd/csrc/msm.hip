@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_fold_hot(XyzzW *partials, con
 // L2 write-through traffic than the arithmetic (measured 0.60 ms for this kernel against 0.3 ms of VALU work).
 template <uint32_t FB, uint32_t RL_LOG>
 __global__ void __launch_bounds__(MSM_THREADS, 2) msm_task_reduce(const XyzzW *partials, const uint32_t *task_meta,
-                                                                   const uint32_t *task_start, XyzzW *task_out, uint32_t total_bins) {
+                                                                   const uint32_t *task_start, XyzzW *task_out, uint32_t total_bins, uint32_t early_exit) {
     constexpr uint32_t FINE = Shape<FB>::FINE, SLOT_PRIMARY = Shape<FB>::SLOT_PRIMARY, SLOT_HEAD = Shape<FB>::SLOT_HEAD, SLOT_TAIL = Shape<FB>::SLOT_TAIL,
                        SLOTS_PER_TASK = Shape<FB>::SLOTS_PER_TASK, META_PER_TASK = Shape<FB>::META_PER_TASK, RL = 1u << RL_LOG, RB = FINE / RL, RB_LOG = FB - RL_LOG;
     static_assert(FB >= RL_LOG + 1, "at least two buckets per lane");
@@ -534,6 +534,9 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_task_reduce(const XyzzW *p
     const uint32_t gt = blockIdx.x * MSM_THREADS + threadIdx.x;
     const uint32_t task = gt / RL, sub = gt % RL;
     const bool live = task < task_start[total_bins];
+    // the grid covers the UPPER BOUND of the task count (bins + entries / TASK_MAX: about twice the tasks of uniform scalars); a wave without a live task would
+    // still walk the USTEPS tree steps on identities — and, from three commitments on, share its SIMD with a live wave whose every step it then doubles
+    if (early_exit && !__any(live)) return;
     const uint32_t *meta = task_meta + (size_t)(live ? task : 0) * META_PER_TASK;
     const uint32_t nc_raw = live ? meta[FINE + 1] : 0, nc = nc_raw & ~TASK_OWNED_BIT;
     const uint32_t mu = (nc_raw & TASK_OWNED_BIT) ? 0x7fffffffu : (nc ? (nc + MSM_THREADS - 1) / MSM_THREADS : 1);   // (owned: every bucket is whole — PRIMARY)
@@ -598,12 +601,13 @@ __global__ void __launch_bounds__(MSM_THREADS, 2) msm_task_reduce(const XyzzW *p
 // every step one four-lane addition (2.6 us for a wave alone on its SIMD against 7.3 for the lane-wise addition).  Launched for ONE commitment (1024 waves:
 // one per SIMD; 191 -> 142 us at 2^20 terms); batches keep the lane-wise kernel, whose lanes do the same work in a quarter of the lane-instructions.  The RB_LOG doublings (X + X) leave through the addition's rare branch.
 template <uint32_t FB>
-__global__ void __launch_bounds__(MSM_THREADS) msm_task_reduce_quad(const XyzzW *partials, const uint32_t *task_meta, const uint32_t *task_start, XyzzW *task_out, uint32_t total_bins) {
+__global__ void __launch_bounds__(MSM_THREADS) msm_task_reduce_quad(const XyzzW *partials, const uint32_t *task_meta, const uint32_t *task_start, XyzzW *task_out, uint32_t total_bins, uint32_t early_exit) {
     constexpr uint32_t FINE = Shape<FB>::FINE, SLOT_PRIMARY = Shape<FB>::SLOT_PRIMARY, SLOT_HEAD = Shape<FB>::SLOT_HEAD, SLOT_TAIL = Shape<FB>::SLOT_TAIL,
                        SLOTS_PER_TASK = Shape<FB>::SLOTS_PER_TASK, META_PER_TASK = Shape<FB>::META_PER_TASK, RL_LOG = 4, RL = 1u << RL_LOG, RB = FINE / RL, RB_LOG = FB - RL_LOG;
     latency_chain_priority();
     const uint32_t task = blockIdx.x * (MSM_THREADS / 64) + (threadIdx.x >> 6), sub = (threadIdx.x & 63u) >> 2, coord = threadIdx.x & 3u;
     const bool live = task < task_start[total_bins];
+    if (early_exit && !live) return;                          // (wave-uniform: one wave = one task; see msm_task_reduce)
     const uint32_t *meta = task_meta + (size_t)(live ? task : 0) * META_PER_TASK;
     const uint32_t nc_raw = live ? meta[FINE + 1] : 0, nc = nc_raw & ~TASK_OWNED_BIT;
     const uint32_t mu = (nc_raw & TASK_OWNED_BIT) ? 0x7fffffffu : (nc ? (nc + MSM_THREADS - 1) / MSM_THREADS : 1);
@@ -939,20 +943,21 @@ static int32_t msm_big_launch(plk_ctx *ctx, plk_ctx::MsmSlot &S, hipStream_t str
         // ONE commitment: the bucket reduction by quads of lanes (PLK_MSM_TR_QUAD=0: the lane-wise kernel for every batch size, A/B knob).  A batch of two is
         // 2048 waves of it — two per SIMD, every step twice as long: 269 us inside a proof against ~230 lane-wise —
         static const bool tr_quad = [] { const char *e = getenv("PLK_MSM_TR_QUAD"); return !(e && e[0] == '0'); }();
+        static const uint32_t early_exit = [] { const char *e = getenv("PLK_MSM_REDUCE_EARLY_EXIT"); return (e && e[0] == '0') ? 0u : 1u; }();   // A/B knob: 0 = dead waves walk the tree steps (rounds 1-6)
         // (only when no other commitment is in flight on this context: the quads do the same additions in 1.5x the lane-instructions, which a stream of
         //  commitments — whose reductions share the GPU with the next accumulation — pays for: three in flight at 2^16 terms 0.243 -> 0.255 ms, measured)
         if (tr_quad && probe_rl == 0 && batch == 1 && ctx->msm_enq == ctx->msm_fin) {
             hipLaunchKernelGGL((msm_fold_hot<FB, 5>), dim3(rblocks), dim3(MSM_THREADS), 0, stream, partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
             hipLaunchKernelGGL((msm_task_reduce_quad<FB>), dim3((max_tasks + MSM_THREADS / 64 - 1) / (MSM_THREADS / 64)), dim3(MSM_THREADS), 0, stream,
-                               (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
+                               (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins, early_exit);
         } else if (rl_log == 4) {
             hipLaunchKernelGGL((msm_fold_hot<FB, 4>), dim3(rblocks), dim3(MSM_THREADS), 0, stream, partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
             hipLaunchKernelGGL((msm_task_reduce<FB, 4>), dim3(rblocks), dim3(MSM_THREADS), 0, stream,
-                               (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
+                               (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins, early_exit);
         } else {
             hipLaunchKernelGGL((msm_fold_hot<FB, 5>), dim3(rblocks), dim3(MSM_THREADS), 0, stream, partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
             hipLaunchKernelGGL((msm_task_reduce<FB, 5>), dim3(rblocks), dim3(MSM_THREADS), 0, stream,
-                               (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins);
+                               (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins, early_exit);
         }
     };
     if (p.fine_bits == 6) launch_shape(std::integral_constant<uint32_t, 6>{}); else launch_shape(std::integral_constant<uint32_t, 7>{});
