@@ -928,7 +928,11 @@ static int32_t msm_big_launch(plk_ctx *ctx, plk_ctx::MsmSlot &S, hipStream_t str
     if (ctx->ev_on) PLK_HIP(hipEventRecord(S.ev[0], stream));
     // lanes per task of the bucket reduction (see msm_task_reduce): 16 for a batch of three or more commitments, 32 otherwise; PLK_MSM_RL_LOG=4|5 forces one (A/B runs)
     static const int probe_rl = [] { const char *e = getenv("PLK_MSM_RL_LOG"); return e ? atoi(e) : 0; }();
-    const uint32_t rl_log = (probe_rl == 4 || probe_rl == 5) ? (uint32_t)probe_rl : (batch >= 3 ? 4u : 5u);
+    // (since late round 6 also 16 when another commitment is in flight on this context: a stream of commitments is work-bound — every reduction wave displaces an
+    //  accumulation wave of the next commitment for as long as it lives — and 16 lanes per task are fewer wave-microseconds; PLK_MSM_RL_STREAM=0: 32 as before)
+    static const bool rl_stream = [] { const char *e = getenv("PLK_MSM_RL_STREAM"); return !(e && e[0] == '0'); }();
+    const bool others_in_flight = ctx->msm_enq != ctx->msm_fin;
+    const uint32_t rl_log = (probe_rl == 4 || probe_rl == 5) ? (uint32_t)probe_rl : ((batch >= 3 || (rl_stream && others_in_flight)) ? 4u : 5u);
     const uint32_t rblocks = ((max_tasks << rl_log) + MSM_THREADS - 1) / MSM_THREADS;
     auto launch_shape = [&](auto fb_tag) {
         constexpr uint32_t FB = decltype(fb_tag)::value;
