@@ -1,18 +1,17 @@
 // One XYZZ addition computed by FOUR lanes (a quad: lanes 4q .. 4q+3 of a wave) — for the latency-bound reduction trees.
 //
 // A full addition (add-2008-s, ec29_dev.h: xyzzw_add) is 14 field products; issued by one lane's wave they are a dependent chain of
-// ~7 us on a SIMD the wave has to itself, and every level of a reduction tree pays that chain — the trees behind a short commitment
-// (msm_small.hip: 15 levels) were 110 us of its 165.  The 14 products are only FOUR deep:
+// ~7 us on a SIMD the wave has to itself, and every level of a reduction tree pays that chain.  The 14 products are only FOUR deep:
 //     stage 1   U1 = X1 ZZ2     U2 = X2 ZZ1      S1 = Y1 ZZZ2       S2 = Y2 ZZZ1        P = U2 - U1,  R = S2 - S1
 //     stage 2   PP = P^2       RR = R^2         ZZ12 = ZZ1 ZZ2     ZZZ12 = ZZZ1 ZZZ2
 //     stage 3   PPP = P PP     Q = U1 PP        ZZ3 = ZZ12 PP      —                    X3 = RR - PPP - 2 Q
 //     stage 4   A = R (Q - X3) B = S1 PPP       —                  ZZZ3 = ZZZ12 PPP     Y3 = A - B
-// so the four lanes of a quad hold BOTH operands in full, pick one product of the stage each by their lane number (v_cndmask), and
-// hand the results round with DPP quad_perm moves (no LDS, no wait): four products + ~280 moves / selects per addition instead of
-// fourteen products.  A wave performs 16 such additions at a time; the result is left in all four lanes.  Same value bounds as
-// xyzzw_add (ec29_dev.h) except Y3 = A + 2p - B < 3.2 p (two reductions instead of the fused one).
-// Special cases: an operand at infinity is a select at the end; P = 0 (mod p) — doubling, or a point and its opposite — is rare and
-// leaves through the ordinary single-lane addition, computed by the four lanes redundantly.
+// so the four lanes of a quad take one product of a stage each.  First version (first half of round 6; in the history at d165fbe^): every lane held BOTH
+// operands in full and selected its product's operands — ~550 selects and DPP moves per addition, 5.3 us per tree level.  This file is the second version,
+// the DISTRIBUTED form below: 2.6 us per level for a wave that has its SIMD to itself.  Same value bounds as xyzzw_add (ec29_dev.h) except
+// Y3 = A + 2p - B < 3.2 p (two reductions instead of the fused one).  Special cases: an operand at infinity is a select at the end; P = 0 (mod p) — doubling,
+// or a point and its opposite — is rare and leaves through the ordinary lane-wise addition on gathered operands.
+// Checked on the device against the lane-wise addition: tests/host/quad_add_check.hip (tests/test_gpu_quad_add.py).
 #pragma once
 #include "ec29_dev.h"
 
@@ -25,76 +24,8 @@ __device__ __forceinline__ FqW9 quad_bcast(const FqW9 &v) {
     for (int i = 0; i < 9; i++) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[i], SRC * 0x55, 0xf, 0xf, false);   // quad_perm:[SRC,SRC,SRC,SRC]
     return r;
 }
-// the operand of lane `role`: two levels of bit-field selects by the two bits of the lane number (v_bfi_b32: three instructions per limb, no
-// control flow — written as conditional expressions the selects became branches over pointers to the operands, which put them in scratch memory)
-__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t on, uint32_t off) { return (on & mask) | (off & ~mask); }
-__device__ __forceinline__ FqW9 quad_sel(uint32_t role, const FqW9 &v0, const FqW9 &v1, const FqW9 &v2, const FqW9 &v3) {
-    const uint32_t m0 = 0u - (role & 1u), m1 = 0u - (role >> 1);
-    FqW9 r;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r.l[i] = bfi(m1, bfi(m0, v3.l[i], v2.l[i]), bfi(m0, v1.l[i], v0.l[i]));
-    return r;
-}
 
-// the point held by lane `src` of the wave (36 ds_bpermute)
-__device__ __forceinline__ XyzzW quad_shfl(const XyzzW &v, int src) {
-    XyzzW r;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        r.x.l[i] = __shfl(v.x.l[i], src);
-        r.y.l[i] = __shfl(v.y.l[i], src);
-        r.zz.l[i] = __shfl(v.zz.l[i], src);
-        r.zzz.l[i] = __shfl(v.zzz.l[i], src);
-    }
-    return r;
-}
-
-// a + b; every lane of the quad passes the same a and the same b and receives the same sum
-__device__ __forceinline__ XyzzW xyzzw_add_quad(const XyzzW &a, const XyzzW &b, uint32_t role) {
-    const bool inf_a = is_inf(a), inf_b = is_inf(b);
-    const FqW9 t1 = LM(quad_sel(role, a.x, b.x, a.y, b.y), quad_sel(role, b.zz, a.zz, b.zzz, a.zzz));
-    const FqW9 u1 = quad_bcast<0>(t1), u2 = quad_bcast<1>(t1), s1 = quad_bcast<2>(t1), s2 = quad_bcast<3>(t1);
-    const FqW9 p = sub2(u2, u1), r = sub2(s2, s1);
-    if (!inf_a && !inf_b && maybe_zero_mod_p(p)) {             // (quad-uniform: all four lanes hold the same values)
-        XyzzW t = a;
-        xyzzw_add(t, b);
-        return t;
-    }
-    const FqW9 t2 = LM(quad_sel(role, p, r, a.zz, a.zzz), quad_sel(role, p, r, b.zz, b.zzz));    // PP | RR | ZZ12 | ZZZ12
-    const FqW9 pp = quad_bcast<0>(t2), rr = quad_bcast<1>(t2);
-    const FqW9 t3 = LM(quad_sel(role, p, u1, t2, t2), pp);                                         // PPP | Q | ZZ3 | (unused)
-    const FqW9 ppp = quad_bcast<0>(t3), qq = quad_bcast<1>(t3);
-    XyzzW o;
-    {
-        FqW9 x3;
-#pragma unroll
-        for (int i = 0; i < 9; i++) x3.l[i] = rr.l[i] + FqW::PAD4[i] - ppp.l[i] - 2 * qq.l[i];
-        o.x = normw(x3);
-    }
-    FqW9 rhs = sub6(qq, o.x);
-    {
-        const uint32_t first = 0u - (uint32_t)(role == 0);
-#pragma unroll
-        for (int i = 0; i < 9; i++) rhs.l[i] = bfi(first, rhs.l[i], ppp.l[i]);
-    }
-    const FqW9 t4 = LM(quad_sel(role, r, s1, t2, t2), rhs);                                        // A | B | (unused) | ZZZ3
-    o.y = sub2(quad_bcast<0>(t4), quad_bcast<1>(t4));
-    o.zz = quad_bcast<2>(t3);
-    o.zzz = quad_bcast<3>(t4);
-    const uint32_t ka = 0u - (uint32_t)inf_b, kb = 0u - (uint32_t)(inf_a && !inf_b);       // keep a / keep b
-    auto pick = [&](const FqW9 &g, const FqW9 &va, const FqW9 &vb) __attribute__((always_inline)) {
-        FqW9 r;
-#pragma unroll
-        for (int i = 0; i < 9; i++) r.l[i] = bfi(ka, va.l[i], bfi(kb, vb.l[i], g.l[i]));
-        return r;
-    };
-    XyzzW out;
-    out.x = pick(o.x, a.x, b.x); out.y = pick(o.y, a.y, b.y); out.zz = pick(o.zz, a.zz, b.zz); out.zzz = pick(o.zzz, a.zzz, b.zzz);
-    return out;
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------------
-// DISTRIBUTED form (late round 6): lane r of a quad holds ONLY coordinate r of a point (0: X, 1: Y, 2: ZZ, 3: ZZZ) — 9 registers per operand
+// DISTRIBUTED form: lane r of a quad holds ONLY coordinate r of a point (0: X, 1: Y, 2: ZZ, 3: ZZZ) — 9 registers per operand
 // instead of 36, and no four-way operand selects: the same four product stages as above with the values placed so that most operands
 // are already where they are needed.  A and B in, A + B out, all in this form:
 //     B' = B by quad_perm [2,3,0,1]                   lane:     0          1          2          3
@@ -105,8 +36,8 @@ __device__ __forceinline__ XyzzW xyzzw_add_quad(const XyzzW &a, const XyzzW &b, 
 //     X3 = RR - PPP - 2 Q (every lane, from three broadcasts)
 //     T4 = (S1 from lane 1 | D | - | T2) * (PPP | Q - X3 | - | PPP)   B    A          -          ZZZ3
 //     out = X3 | A - B | T3 | T4
-// ~80 DPP moves and ~110 selects per addition instead of ~550, and a partner's point is 9 ds_bpermute instead of 36.  The values (and their
-// bounds) are those of xyzzw_add_quad: the Montgomery product does not depend on the order of its operands.
+// ~80 DPP moves and ~110 selects per addition instead of ~550, and a partner's point is 9 ds_bpermute instead of 36 (1310 instructions in all, 648 of them
+// multiply-adds).  The Montgomery product does not depend on the order of its operands, so which lane forms which product changes no value.
 constexpr int QP_SWAP2 = 2 | (3 << 2) | (0 << 4) | (1 << 6);            // quad_perm:[2,3,0,1]
 template <int CTRL>
 __device__ __forceinline__ FqW9 quad_dpp(const FqW9 &v) {

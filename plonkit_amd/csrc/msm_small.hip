@@ -37,18 +37,6 @@ static size_t sm_lds(uint32_t ch) { return (size_t)(SM_WG_BUCKETS + SM_WG_BUCKET
 
 __device__ __forceinline__ void small_chain_priority() { __builtin_amdgcn_s_setprio(3); }
 
-__device__ __forceinline__ XyzzW sm_shfl_xor(const XyzzW &v, int mask) {
-    XyzzW r;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        r.x.l[i] = __shfl_xor(v.x.l[i], mask);
-        r.y.l[i] = __shfl_xor(v.y.l[i], mask);
-        r.zz.l[i] = __shfl_xor(v.zz.l[i], mask);
-        r.zzz.l[i] = __shfl_xor(v.zzz.l[i], mask);
-    }
-    return r;
-}
-
 // grid (8 G, batch): workgroup 8 g + s takes terms [g ch, (g + 1) ch) and an EIGHTH of the bucket space — s & 1: lo / hi values, s >> 1: which 64 of the 256 values.
 // bases = copy 0 of the fixed-base table at the commitment's first point; copy w lies w * copy_stride points on.
 // QUADSUM (the default; PLK_MSM_SMALL_QUADSUM=0 is the A/B knob): the four lanes of a bucket add their sums up before they store (three four-lane additions
