@@ -309,19 +309,41 @@ __global__ void __launch_bounds__(G1NTT_THREADS, 1) g1ntt_stage(XyzzW *pts, uint
     store_xyzzw(pts + i1, a);
 }
 
+// XYZZ -> affine with ONE field inversion per G1NTT_NORM_K points (Montgomery's trick on ZZZ; 1 / Z = ZZ / ZZZ, as srs_normalise_kernel does for the MSM table):
+// a Fermat inversion per point was 4.3 ms of a 2^20-point transform.  A thread takes K consecutive points; the second walk reads them again (four products each)
+// rather than keep K x 32 words alive.  Same canonical coordinates as before, bit for bit.
+constexpr uint32_t G1NTT_NORM_K = 8;
 __global__ void __launch_bounds__(256) g1ntt_to_affine(G1Affine *out, const XyzzW *pts, uint32_t n) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    G1Xyzz p = xyzzw_export(load_xyzzw(pts + i));                // back to the external form (canonical, R = 2^256)
-    G1Affine a;
-    if (is_inf(p)) { a.x = Fq::zero(); a.y = Fq::zero(); }
-    else {
-        Fq iv = inv(mul(p.zz, p.zzz));
-        a.x = mul(p.x, mul(iv, p.zzz));
-        a.y = mul(p.y, mul(iv, p.zz));
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lo = t * G1NTT_NORM_K, hi = lo + G1NTT_NORM_K < n ? lo + G1NTT_NORM_K : n;
+    if (lo >= n) return;
+    Fq prefix[G1NTT_NORM_K];
+    Fq acc = Fq::one();
+#pragma unroll
+    for (uint32_t j = 0; j < G1NTT_NORM_K; j++) {
+        if (lo + j < hi) {
+            const XyzzW w = load_xyzzw(pts + lo + j);
+            if (!is_inf(w)) acc = mul(acc, pack<FqParams>(s_from_w(w.zzz)));
+        }
+        prefix[j] = acc;
     }
-    store_fp(&out[i].x, a.x);
-    store_fp(&out[i].y, a.y);
+    Fq inv_acc = inv(acc);
+#pragma unroll
+    for (uint32_t jj = 0; jj < G1NTT_NORM_K; jj++) {
+        const uint32_t j = G1NTT_NORM_K - 1 - jj;
+        if (lo + j >= hi) continue;
+        const G1Xyzz q = xyzzw_export(load_xyzzw(pts + lo + j));  // back to the external form (canonical, R = 2^256); the identity is all zero
+        G1Affine a; a.x = Fq::zero(); a.y = Fq::zero();
+        if (!is_inf(q)) {
+            const Fq zi = j ? mul(inv_acc, prefix[j - 1]) : inv_acc;  // 1 / ZZZ_j
+            inv_acc = mul(inv_acc, q.zzz);
+            const Fq iz = mul(q.zz, zi), izz = mul(iz, iz);       // 1 / Z, 1 / ZZ
+            a.x = mul(q.x, izz);
+            a.y = mul(q.y, zi);
+        }
+        store_fp(&out[lo + j].x, a.x);
+        store_fp(&out[lo + j].y, a.y);
+    }
 }
 
 int32_t g1_intt_dev(plk_ctx *ctx, const G1Affine *in, uint32_t log_n, G1Affine *out, hipStream_t st) {
@@ -356,7 +378,7 @@ int32_t g1_intt_dev(plk_ctx *ctx, const G1Affine *in, uint32_t log_n, G1Affine *
     };
     for (uint32_t s = 0; s + 1 < log_n; s++) stage(std::false_type{}, s);
     if (log_n) stage(std::true_type{}, log_n - 1);
-    hipLaunchKernelGGL(g1ntt_to_affine, dim3((n + 255) / 256), dim3(256), 0, st, out, (const XyzzW *)pts, n);
+    hipLaunchKernelGGL(g1ntt_to_affine, dim3(((n + G1NTT_NORM_K - 1) / G1NTT_NORM_K + 255) / 256), dim3(256), 0, st, out, (const XyzzW *)pts, n);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
 }
