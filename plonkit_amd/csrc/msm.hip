@@ -950,7 +950,8 @@ static int32_t msm_big_launch(plk_ctx *ctx, plk_ctx::MsmSlot &S, hipStream_t str
         static const uint32_t early_exit = [] { const char *e = getenv("PLK_MSM_REDUCE_EARLY_EXIT"); return (e && e[0] == '0') ? 0u : 1u; }();   // A/B knob: 0 = dead waves walk the tree steps (rounds 1-6)
         // (only when no other commitment is in flight on this context: the quads do the same additions in 1.5x the lane-instructions, which a stream of
         //  commitments — whose reductions share the GPU with the next accumulation — pays for: three in flight at 2^16 terms 0.243 -> 0.255 ms, measured)
-        if (tr_quad && probe_rl == 0 && batch == 1 && ctx->msm_enq == ctx->msm_fin) {
+        // and ONE bucket set (above 2^20 terms a commitment has 3 or 5: 5120 tasks are five waves of quads per SIMD — 0.71 ms at 2^22 terms against ~0.45 lane-wise)
+        if (tr_quad && probe_rl == 0 && total_sets == 1 && ctx->msm_enq == ctx->msm_fin) {
             hipLaunchKernelGGL((msm_fold_hot<FB, 5>), dim3(rblocks), dim3(MSM_THREADS), 0, stream, partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, total_bins);
             hipLaunchKernelGGL((msm_task_reduce_quad<FB>), dim3((max_tasks + MSM_THREADS / 64 - 1) / (MSM_THREADS / 64)), dim3(MSM_THREADS), 0, stream,
                                (const XyzzW *)partials, (const uint32_t *)task_meta, (const uint32_t *)task_start, task_out, total_bins, early_exit);
